@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py — MSDeformAttn fwd+bwd samples/s at the Swin-L 4-scale / 300-query shape.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2_decoder] [--no-graph]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one MSDeformAttnFunction.apply forward plus its backward (all three
+gradients) over one batch of synthetic inputs already resident in HBM
+(BASELINE.json configs[1]: N=2, levels 48/24/12/6 from a 384x384 input, 300 queries,
+8 heads, D=32, P=4, fp32).  One sample = one batch element.  With N GPUs every rank
+runs the same per-rank batch on its own data (the op shards over the batch with no
+exchange), so the scaling is weak and there is no data-path collective;
+`value` = samples all ranks processed / max-over-ranks time.
+
+The step is captured once into a HIP graph (two kernel launches + no host work per
+replay) and replayed K times; --no-graph times the eager autograd path instead.
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra
+objects: `roofline` (dominant kernel = backward; algorithmic bytes / HIP-event time
+against the 8 TB/s HBM peak) and `cpu_baseline` (the PyTorch-CPU fallback port timed
+on the host cores of this node; test infrastructure under oracle/, never the thing
+measured as `value`).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+
+WORKLOADS = {
+    # name: (N per GPU, [(H, W)...], M, D, Lq, P)
+    "cfg2_decoder": (2, [(48, 48), (24, 24), (12, 12), (6, 6)], 8, 32, 300, 4),
+    "cfg2_encoder": (2, [(48, 48), (24, 24), (12, 12), (6, 6)], 8, 32, 3060, 4),
+    "cfg4_decoder": (32, [(28, 28), (14, 14), (7, 7), (4, 4)], 8, 32, 300, 4),
+    "cfg4_encoder": (32, [(28, 28), (14, 14), (7, 7), (4, 4)], 8, 32, 1045, 4),
+}
+
+
+def algorithmic_bytes(N, S, M, D, L, Lq, P, e=4):
+    """every input read once, every output written once."""
+    fwd = e * (N * S * M * D + 3 * N * Lq * M * L * P + N * Lq * M * D) + 8 * 3 * L
+    bwd = e * (N * Lq * M * D + N * S * M * D + 3 * N * Lq * M * L * P + N * S * M * D
+               + 3 * N * Lq * M * L * P) + 8 * 3 * L
+    return fwd, bwd
+
+
+def make_inputs(workload, seed, device):
+    """Synthetic inputs, distributions of models/ops/test.py:33-36 (distribution A)."""
+    N, shapes, M, D, Lq, P = WORKLOADS[workload]
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    shapes_t = torch.tensor(shapes, dtype=torch.long)
+    lsi = torch.cat((shapes_t.new_zeros(1), shapes_t.prod(1).cumsum(0)[:-1]))
+    S, L = int(shapes_t.prod(1).sum()), len(shapes)
+    value = torch.rand(N, S, M, D, generator=g) * 0.01
+    loc = torch.rand(N, Lq, M, L, P, 2, generator=g)
+    attn = torch.rand(N, Lq, M, L, P, generator=g) + 1e-5
+    attn = attn / attn.sum((-1, -2), keepdim=True)
+    go = torch.rand(N, Lq, M * D, generator=g)
+    host = dict(value=value, shapes=shapes_t, lsi=lsi, loc=loc, attn=attn, go=go)
+    dev = {k: v.to(device) for k, v in host.items()} if device is not None else None
+    return host, dev, (N, S, M, D, L, Lq, P)
+
+
+def time_cpu_baseline(workload, budget_s=12.0):
+    """The reference's CPU comparator (grid_sample fallback; port under oracle/) on this node's cores."""
+    from oracle.torch_fallback import fwd_bwd
+    host, _, dims = make_inputs(workload, 0, None)
+    N = dims[0]
+    cores = torch.get_num_threads()
+    for _ in range(2):
+        fwd_bwd(host["value"], host["shapes"], host["loc"], host["attn"], host["go"])
+    n, t0 = 0, time.perf_counter()
+    while True:
+        fwd_bwd(host["value"], host["shapes"], host["loc"], host["attn"], host["go"])
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 400:
+            break
+    return {"value": N * n / el, "unit": "samples/s", "cores": cores, "kind": "port",
+            "ms_per_step": 1e3 * el / n,
+            "sample": "%d fwd+bwd calls of the %s batch (N=%d) through oracle/torch_fallback.py "
+                      "(restatement of ms_deform_attn_core_pytorch, fp32, %d intra-op threads)"
+                      % (n, workload, N, cores)}
+
+
+def event_time_ms(fn, iters, stream):
+    """Average duration of fn() over `iters` back-to-back calls, HIP events on `stream`."""
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record(stream)
+    for _ in range(iters):
+        fn()
+    stop.record(stream)
+    stop.synchronize()
+    return start.elapsed_time(stop) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--workload", default="cfg2_decoder", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-graph", action="store_true", help="time the eager autograd path")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-iters", type=int, default=200)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        args.gpus = world
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from uvhand_amd import _native
+    from uvhand_amd.functions import MSDeformAttnFunction
+    _native.load()
+
+    _, d, dims = make_inputs(args.workload, 1000 + rank, device)
+    N, S, M, D, L, Lq, P = dims
+    value = d["value"].requires_grad_(True)
+    loc = d["loc"].requires_grad_(True)
+    attn = d["attn"].requires_grad_(True)
+    shapes, lsi, go = d["shapes"], d["lsi"], d["go"]
+
+    def step():
+        value.grad = loc.grad = attn.grad = None
+        out = MSDeformAttnFunction.apply(value, shapes, lsi, loc, attn, 64)
+        out.backward(go)
+
+    stream = torch.cuda.Stream(device)
+    torch.cuda.synchronize()
+    graph = None
+    with torch.cuda.stream(stream):
+        for _ in range(3):
+            step()
+        stream.synchronize()
+        if not args.no_graph:
+            try:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=stream):
+                    step()
+            except Exception as exc:                      # report, then fall back to eager timing
+                print("bench: HIP graph capture failed (%s); timing eager" % exc, file=sys.stderr)
+                graph = None
+        run = graph.replay if graph is not None else step
+
+        def barrier():
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+
+        for _ in range(args.warmup):
+            run()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run()
+        barrier()
+        elapsed = time.perf_counter() - t0
+
+        # ---- per-kernel timing for the roofline (HIP events on the launch stream) ----
+        vd, ld, ad = value.detach(), loc.detach(), attn.detach()
+        fwd = lambda: _native.ms_deform_attn_forward(vd, shapes, lsi, ld, ad, 64)
+        bwd = lambda: _native.ms_deform_attn_backward(vd, shapes, lsi, ld, ad, go, 64)
+        kt = {}
+        for name, fn in (("fwd", fwd), ("bwd", bwd)):
+            g2 = None
+            try:
+                fn(); stream.synchronize()
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2, stream=stream):
+                    for _ in range(10):
+                        fn()
+                call, per = g2.replay, 10
+            except Exception:
+                call, per = fn, 1
+            for _ in range(5):
+                call()
+            kt[name] = event_time_ms(call, max(1, args.kernel_iters // per), stream) / per
+        stream.synchronize()
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        fwd_b, bwd_b = algorithmic_bytes(N, S, M, D, L, Lq, P)
+        ach = bwd_b / (kt["bwd"] * 1e-3) / 1e9
+        result = {
+            "metric": "MSDeformAttn fwd+bwd samples/sec @ Swin-L 4-scale, 300 queries",
+            "value": world * N * args.steps / elapsed,
+            "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: N=%d/GPU, levels %s (S=%d), Lq=%d, M=%d, D=%d, P=%d, fp32"
+                                   % (args.workload, N, "/".join(str(h) for h, _ in WORKLOADS[args.workload][1]),
+                                      S, Lq, M, D, P),
+                       "step": "MSDeformAttnFunction.apply forward + backward (3 grads)",
+                       "launch": "hipGraph replay" if graph is not None else "eager autograd",
+                       "sharding": "batch-sharded, no collective"},
+            "roofline": {"bound": "hbm", "kernel": "backward (memset + bwd_d32_kernel)",
+                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "traffic": None, "algorithmic_bytes": bwd_b, "ms": kt["bwd"]},
+            "kernels": {"fwd": {"ms": kt["fwd"], "algorithmic_bytes": fwd_b,
+                                "GBps": fwd_b / (kt["fwd"] * 1e-3) / 1e9},
+                        "bwd": {"ms": kt["bwd"], "algorithmic_bytes": bwd_b, "GBps": ach}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = time_cpu_baseline(args.workload)
+            result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,108 @@
+/*
+ * msda.h — C ABI of libmsda_hip.so: multi-scale deformable attention
+ * forward / backward for AMD MI355X (gfx950), hand-written HIP.
+ *
+ * This is the drop-in boundary for the reference's native op.  Each entry point
+ * replaces one function of the reference's pybind module
+ * `MultiScaleDeformableAttention` (paths relative to the UVHand repo):
+ *
+ *   msda_forward_*   <-  ms_deform_attn_forward   models/ops/src/vision.cpp:14,
+ *                        models/ops/src/ms_deform_attn.h:20-39, which dispatches to
+ *                        ms_deform_attn_cuda_forward  models/ops/src/cuda/ms_deform_attn_cuda.cu:20-80
+ *                        (kernel: models/ops/src/cuda/ms_deform_im2col_cuda.cuh:237-299)
+ *   msda_backward_*  <-  ms_deform_attn_backward  models/ops/src/vision.cpp:15,
+ *                        models/ops/src/ms_deform_attn.h:42-61, which dispatches to
+ *                        ms_deform_attn_cuda_backward models/ops/src/cuda/ms_deform_attn_cuda.cu:83-153
+ *                        (kernels: models/ops/src/cuda/ms_deform_im2col_cuda.cuh:301-920)
+ *
+ * The reference passes at::Tensor; this ABI passes what those tensors are: raw
+ * DEVICE pointers into caller-owned, contiguous, row-major storage plus sizes:
+ *
+ *   value          [N, S, M, D]           T      S = sum_l H_l*W_l
+ *   spatial_shapes [L, 2]  (H_l, W_l)     int64  device memory (read in-kernel, as the
+ *   level_start    [L]                    int64  reference does: im2col_cuda.cuh:274-277)
+ *   sampling_loc   [N, Lq, M, L, P, 2]    TL     (x, y), normalised to the level's extent
+ *   attn_weight    [N, Lq, M, L, P]       TL
+ *   out / grad_out [N, Lq, M*D]           T
+ *   grad_value     [N, S, M, D]           T
+ *   grad_sampling_loc, grad_attn_weight   TL     same shapes as sampling_loc / attn_weight
+ *
+ *   suffix  T        TL      accumulation
+ *   f32     float    float   float            (the reference's float instantiation)
+ *   f64     double   double  double           (the reference's double instantiation; gradcheck)
+ *
+ * Semantics kept from the reference: the batch is processed whole (im2col_step
+ * only chunks the reference's launches; results do not depend on it, the host
+ * wrapper validates it); every output element is written by the call — the
+ * caller does NOT need to zero out / grad_* beforehand (the reference zero-fills
+ * them on the host side, ms_deform_attn_cuda.cu:54,121-123).
+ *
+ * Ownership: the library allocates nothing and frees nothing and keeps no global
+ * mutable state except a thread-local error string.  It never synchronises the
+ * device: all work (including the zero-fill of grad_value where a kernel needs
+ * it) is enqueued on `stream` (a hipStream_t; NULL = the default stream).
+ * Re-entrant: forward and backward may be called concurrently from different
+ * host threads (the backward arrives on PyTorch's autograd thread).
+ *
+ * Errors: every function returns 0 on success, non-zero on failure, in which
+ * case msda_last_error() describes it.  Unlike the reference, which only
+ * printf()s a failed launch (im2col_cuda.cuh:948-952, 1321-1325), launch errors
+ * are returned.
+ */
+#ifndef MSDA_H_
+#define MSDA_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSDA_OK            0
+#define MSDA_ERR_ARGUMENT  1   /* null pointer, non-positive size, index range beyond int32 */
+#define MSDA_ERR_LAUNCH    2   /* HIP runtime reported an error at enqueue time */
+
+/* Which kernel family a call would use for the given geometry (for tests/bench):
+ * 0 = generic (any D, any dtype), 1 = D=32 fast path. */
+#define MSDA_PATH_GENERIC  0
+#define MSDA_PATH_D32      1
+
+typedef void *msda_stream_t; /* hipStream_t */
+
+int msda_forward_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                     const float *sampling_loc, const float *attn_weight,
+                     int N, int S, int M, int D, int L, int Lq, int P,
+                     float *out, msda_stream_t stream);
+
+int msda_backward_f32(const float *grad_out, const float *value, const int64_t *spatial_shapes,
+                      const int64_t *level_start, const float *sampling_loc, const float *attn_weight,
+                      int N, int S, int M, int D, int L, int Lq, int P,
+                      float *grad_value, float *grad_sampling_loc, float *grad_attn_weight,
+                      msda_stream_t stream);
+
+int msda_forward_f64(const double *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                     const double *sampling_loc, const double *attn_weight,
+                     int N, int S, int M, int D, int L, int Lq, int P,
+                     double *out, msda_stream_t stream);
+
+int msda_backward_f64(const double *grad_out, const double *value, const int64_t *spatial_shapes,
+                      const int64_t *level_start, const double *sampling_loc, const double *attn_weight,
+                      int N, int S, int M, int D, int L, int Lq, int P,
+                      double *grad_value, double *grad_sampling_loc, double *grad_attn_weight,
+                      msda_stream_t stream);
+
+/* Thread-local description of the last failure on the calling thread ("" if none). */
+const char *msda_last_error(void);
+
+/* Library/ABI version (major*100 + minor) and the kernel family a geometry maps to. */
+int msda_version(void);
+int msda_path_for(int elem_bytes, int M, int D, int L, int P);
+
+/* Testing/benchmark knob: force the kernel family (-1 = automatic, default).
+ * Process-wide; not meant for production callers. */
+void msda_force_path(int path);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSDA_H_ */

@@ -1,0 +1,156 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/msda.h declares, the Python host layer mirrors the reference's interface and error
+behaviour, and the module's parameters / init match the reference's.  No GPU, no compute calls."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "msda.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(msda_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def native():
+    import __graft_entry__
+    __graft_entry__.build()
+    from uvhand_amd import _native
+    _native.load()
+    return _native
+
+
+def test_header_declares_the_expected_entry_points():
+    names = _declared_functions()
+    for must in ("msda_forward_f32", "msda_backward_f32", "msda_forward_f64", "msda_backward_f64",
+                 "msda_last_error"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol(native):
+    lib = ctypes.CDLL(native.LIB_PATH)
+    for name in _declared_functions():
+        assert hasattr(lib, name), "libmsda_hip.so does not export %s" % name
+    lib.msda_version.restype = ctypes.c_int
+    assert lib.msda_version() >= 100
+    lib.msda_last_error.restype = ctypes.c_char_p
+    assert lib.msda_last_error() == b""
+
+
+def test_library_has_gfx950_code_object(native):
+    blob = open(native.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+
+
+def test_path_selection_is_host_logic(native):
+    assert native.path_for(4, 8, 32, 4, 4) == 1          # the model shape -> tiled D=32 kernels
+    assert native.path_for(8, 8, 32, 4, 4) == 0          # fp64 -> generic
+    assert native.path_for(4, 2, 30, 2, 2) == 0
+    assert native.path_for(4, 8, 32, 4, 16) == 0         # L*P beyond the record table
+    native.force_path(0)
+    try:
+        assert native.path_for(4, 8, 32, 4, 4) == 0
+    finally:
+        native.force_path(-1)
+
+
+def _cpu_inputs(dtype=torch.float32, N=2):
+    shapes = torch.tensor([[4, 3], [2, 2]], dtype=torch.long)
+    lsi = torch.tensor([0, 12], dtype=torch.long)
+    value = torch.rand(N, 16, 2, 4, dtype=dtype)
+    loc = torch.rand(N, 5, 2, 2, 3, 2, dtype=dtype)
+    attn = torch.rand(N, 5, 2, 2, 3, dtype=dtype)
+    return value, shapes, lsi, loc, attn
+
+
+def test_cpu_tensors_raise_like_the_reference(native):
+    """ms_deform_attn.h:38 — AT_ERROR("Not implemented on the CPU"); there is no CPU fallback."""
+    from uvhand_amd.functions import MSDeformAttnFunction
+    value, shapes, lsi, loc, attn = _cpu_inputs()
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        MSDeformAttnFunction.apply(value, shapes, lsi, loc, attn, 64)
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        native.ms_deform_attn_backward(value, shapes, lsi, loc, attn, torch.rand(2, 5, 8), 64)
+
+
+def test_function_signature_matches_reference():
+    import inspect
+    from uvhand_amd.functions import MSDeformAttnFunction
+    sig = list(inspect.signature(MSDeformAttnFunction.forward).parameters)
+    assert sig == ["ctx", "value", "value_spatial_shapes", "value_level_start_index",
+                   "sampling_locations", "attention_weights", "im2col_step"]
+    assert issubclass(MSDeformAttnFunction, torch.autograd.Function)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "uvhand_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+                assert "torch_fallback" not in text and "grid_sample" not in text, f
+
+
+def test_missing_library_fails_loudly(native, monkeypatch):
+    monkeypatch.setattr(native, "_lib", None)
+    monkeypatch.setattr(native, "LIB_PATH", os.path.join(ROOT, "uvhand_amd", "no_such_lib.so"))
+    with pytest.raises(RuntimeError, match="no non-HIP fallback"):
+        native.load()
+
+
+# ---------------------------------------------------------------------------------------------
+# module surface (models/ops/modules/ms_deform_attn.py:30-78)
+# ---------------------------------------------------------------------------------------------
+def test_module_surface_and_init_match_reference():
+    from uvhand_amd.modules import MSDeformAttn
+    torch.manual_seed(0)
+    mod = MSDeformAttn(d_model=256, n_levels=4, n_heads=8, n_points=4)
+    assert (mod.im2col_step, mod.d_model, mod.n_levels, mod.n_heads, mod.n_points) == (64, 256, 4, 8, 4)
+    z = load_golden("module_init")            # reference module constructed under manual_seed(0)
+    sd = mod.state_dict()
+    assert list(sd.keys()) == ["sampling_offsets.weight", "sampling_offsets.bias",
+                               "attention_weights.weight", "attention_weights.bias",
+                               "value_proj.weight", "value_proj.bias",
+                               "output_proj.weight", "output_proj.bias"]
+    assert sorted(sd.keys()) == sorted(z.keys())
+    for k, v in sd.items():
+        assert tuple(v.shape) == z[k].shape, k
+        assert np.array_equal(v.numpy(), z[k]), "init of %s differs from the reference's" % k
+    # _reset_parameters is called again from outside (models/arctic_transformer.py:80-81)
+    with torch.no_grad():
+        mod.sampling_offsets.bias.add_(1.0)
+    mod._reset_parameters()
+    assert np.array_equal(mod.sampling_offsets.bias.detach().numpy(), z["sampling_offsets.bias"])
+
+
+def test_module_loads_reference_state_dict_strictly():
+    from uvhand_amd.modules import MSDeformAttn
+    z = load_golden("module_state")
+    mod = MSDeformAttn()
+    missing, unexpected = mod.load_state_dict({k: torch.from_numpy(v) for k, v in z.items()}, strict=True)
+    assert not missing and not unexpected
+
+
+def test_module_argument_errors():
+    from uvhand_amd.modules import MSDeformAttn
+    with pytest.raises(ValueError, match="divisible"):
+        MSDeformAttn(d_model=30, n_heads=4)
+    mod = MSDeformAttn(d_model=32, n_levels=2, n_heads=4, n_points=2)
+    shapes = torch.tensor([[2, 2], [1, 1]], dtype=torch.long)
+    lsi = torch.tensor([0, 4], dtype=torch.long)
+    q, src = torch.rand(1, 3, 32), torch.rand(1, 5, 32)
+    with pytest.raises(ValueError, match="Last dim of reference_points"):
+        mod(q, torch.rand(1, 3, 2, 3), src, shapes, lsi)
+    with pytest.raises(AssertionError):
+        mod(q, torch.rand(1, 3, 2, 2), torch.rand(1, 6, 32), shapes, lsi)
+    # the product path needs the GPU: on CPU tensors it raises, it does not fall back
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        mod(q, torch.rand(1, 3, 2, 2), src, shapes, lsi)

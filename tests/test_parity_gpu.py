@@ -1,0 +1,340 @@
+"""Parity of the HIP path (through the C ABI) with the oracle and with the golden vectors captured
+from the reference's fallback.  All tests here need the GPU (`-m gpu`)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import OP_CASES, load_golden, near_boundary_mask, rel_err
+
+pytestmark = pytest.mark.gpu
+
+PATHS = {"auto": -1, "generic": 0}
+
+
+@pytest.fixture(scope="module")
+def native():
+    from uvhand_amd import _native
+    _native.load()
+    assert torch.cuda.is_available()
+    return _native
+
+
+@pytest.fixture(params=["auto", "generic"])
+def path(request, native):
+    native.force_path(PATHS[request.param])
+    yield request.param
+    native.force_path(-1)
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None and t.is_floating_point():
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def run_hip(z, dtype, im2col_step=64):
+    from uvhand_amd.functions import MSDeformAttnFunction
+    v = dev(z["value"], dtype).requires_grad_(True)
+    l = dev(z["loc"], dtype).requires_grad_(True)
+    a = dev(z["attn"], dtype).requires_grad_(True)
+    out = MSDeformAttnFunction.apply(v, dev(z["shapes"]), dev(z["level_start"]), l, a, im2col_step)
+    out.backward(dev(z["grad_out"], dtype))
+    torch.cuda.synchronize()
+    return [t.detach().cpu().numpy() for t in (out, v.grad, l.grad, a.grad)]
+
+
+# ---------------------------------------------------------------------------------------------
+# golden vectors (reference fallback, fp64)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", OP_CASES)
+def test_fp64_matches_reference_golden(native, case):
+    z = load_golden(case)
+    out, gv, gl, ga = run_hip(z, torch.float64, im2col_step=2)
+    assert out.shape == z["out"].shape and gv.shape == z["grad_value"].shape
+    assert rel_err(out, z["out"]) < 1e-12
+    assert rel_err(gv, z["grad_value"]) < 1e-12
+    assert rel_err(ga, z["grad_attn"]) < 1e-11
+    keep = ~z["exact_m1"] if "exact_m1" in z else np.ones(z["attn"].shape, bool)
+    assert rel_err(gl[keep], z["grad_loc"][keep]) < 1e-11
+    if "exact_m1" in z:
+        assert np.all(gl[z["exact_m1"]] == 0)       # the CUDA kernel's behaviour (cuh:288)
+
+
+@pytest.mark.parametrize("case", OP_CASES)
+def test_fp32_matches_reference_golden(native, path, case):
+    """fp32 tolerance: 5e-6 of the tensor's max magnitude for the forward, 2e-5 for the gradients
+    (float atomics / reduction order); the reference's own float check is rtol=1e-2, atol=1e-3
+    (models/ops/test.py:56), asserted as well."""
+    z = load_golden(case)
+    out, gv, gl, ga = run_hip(z, torch.float32)
+    assert np.allclose(out, z["out"], rtol=1e-2, atol=1e-3)
+    assert rel_err(out, z["out"]) < 5e-6
+    assert rel_err(gv, z["grad_value"]) < 2e-5
+    assert rel_err(ga, z["grad_attn"]) < 2e-5
+    keep = ~near_boundary_mask(z)
+    assert rel_err(gl[keep], z["grad_loc"][keep]) < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------
+# seeded inputs vs the C oracle, both kernel families, ragged sizes
+# ---------------------------------------------------------------------------------------------
+def make_case(seed, N, shapes, M, D, Lq, P, lo=-0.25, hi=1.25):
+    g = torch.Generator().manual_seed(seed)
+    shapes = np.asarray(shapes, dtype=np.int64)
+    L = len(shapes)
+    S = int(shapes.prod(1).sum())
+    lsi = np.concatenate(([0], np.cumsum(shapes.prod(1))[:-1])).astype(np.int64)
+    value = (torch.rand(N, S, M, D, generator=g) * 0.01).numpy()
+    loc = (torch.rand(N, Lq, M, L, P, 2, generator=g) * (hi - lo) + lo).numpy()
+    attn = torch.rand(N, Lq, M, L, P, generator=g) + 1e-5
+    attn = (attn / attn.sum((-1, -2), keepdim=True)).numpy()
+    go = torch.rand(N, Lq, M * D, generator=g).numpy()
+    return dict(value=value, shapes=shapes, level_start=lsi, loc=loc, attn=attn, grad_out=go)
+
+
+ORACLE_CASES = {
+    # name: (N, shapes, M, D, Lq, P)
+    "model_small":   (2, [(12, 12), (6, 6), (3, 3), (2, 2)], 8, 32, 37, 4),     # D=32 path, SPLIT=4
+    "ragged_items":  (3, [(7, 5), (3, 2)], 5, 32, 13, 3),                       # items % 8 != 0, LP=6
+    "one_point":     (1, [(4, 4)], 8, 32, 9, 1),                                # L*P < 4
+    "many_queries":  (2, [(16, 16), (8, 8)], 8, 32, 2100, 4),                   # D=32 path, SPLIT=1
+    "ragged_split1": (1, [(9, 9), (5, 4), (2, 2)], 7, 32, 4711, 2),             # SPLIT=1, items % 32 != 0
+    "d64":           (2, [(8, 8), (4, 4)], 4, 64, 21, 4),
+    "d3_odd":        (2, [(5, 3), (2, 2), (1, 1)], 3, 3, 11, 2),
+    "d200":          (1, [(6, 6)], 2, 200, 5, 3),
+    "five_levels":   (1, [(10, 10), (5, 5), (3, 3), (2, 2), (1, 1)], 8, 32, 50, 2),
+    "wide_map":      (1, [(3, 40), (20, 2)], 8, 32, 64, 4),
+}
+
+
+@pytest.mark.parametrize("name", list(ORACLE_CASES))
+def test_fp32_matches_c_oracle(native, oracle, path, name):
+    z = make_case(1, *ORACLE_CASES[name])
+    out, gv, gl, ga = run_hip(z, torch.float32)
+    args = [z["value"], z["shapes"], z["level_start"], z["loc"], z["attn"]]
+    r_out = oracle.forward(*args)
+    r_gv, r_gl, r_ga = oracle.backward(z["grad_out"], *args)
+    assert rel_err(out, r_out) < 5e-6
+    assert rel_err(gv, r_gv) < 2e-5
+    assert rel_err(ga, r_ga) < 2e-5
+    keep = ~near_boundary_mask(z, tol=1e-5)
+    assert rel_err(gl[keep], r_gl[keep]) < 2e-5
+
+
+@pytest.mark.parametrize("name", ["model_small", "d3_odd", "d200"])
+def test_fp64_matches_c_oracle(native, oracle, name):
+    z = make_case(2, *ORACLE_CASES[name])
+    z = {k: (v.astype(np.float64) if v.dtype == np.float32 else v) for k, v in z.items()}
+    out, gv, gl, ga = run_hip(z, torch.float64)
+    args = [z["value"], z["shapes"], z["level_start"], z["loc"], z["attn"]]
+    r_gv, r_gl, r_ga = oracle.backward(z["grad_out"], *args)
+    assert rel_err(out, oracle.forward(*args)) < 1e-13
+    assert rel_err(gv, r_gv) < 1e-12
+    assert rel_err(gl, r_gl) < 1e-12
+    assert rel_err(ga, r_ga) < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------
+# the reference's own test, restated: models/ops/test.py:31-86
+# ---------------------------------------------------------------------------------------------
+def _testpy_inputs(channels=2):
+    N, M, Lq, L, P = 1, 2, 2, 2, 2
+    shapes = torch.as_tensor([(6, 4), (3, 2)], dtype=torch.long).cuda()
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    S = 30
+    value = torch.rand(N, S, M, channels).cuda() * 0.01
+    loc = torch.rand(N, Lq, M, L, P, 2).cuda()
+    attn = torch.rand(N, Lq, M, L, P).cuda() + 1e-5
+    attn /= attn.sum(-1, keepdim=True).sum(-2, keepdim=True)
+    return value, shapes, lsi, loc, attn
+
+
+def test_reference_test_forward_double_and_float(native, oracle):
+    from uvhand_amd.functions import MSDeformAttnFunction
+    torch.manual_seed(3)
+    value, shapes, lsi, loc, attn = _testpy_inputs()
+    ref = oracle.forward(value.double().cpu().numpy(), shapes.cpu().numpy(), lsi.cpu().numpy(),
+                         loc.double().cpu().numpy(), attn.double().cpu().numpy())
+    out = MSDeformAttnFunction.apply(value.double(), shapes, lsi, loc.double(), attn.double(), 2)
+    assert torch.allclose(out.cpu(), torch.from_numpy(ref))                    # test.py:40 defaults
+    golden = load_golden("testpy_double")                                      # same seed, same draws
+    assert np.array_equal(golden["value"], value.cpu().numpy())
+    assert torch.allclose(out.cpu(), torch.from_numpy(golden["out"]))
+    value, shapes, lsi, loc, attn = _testpy_inputs()
+    ref = oracle.forward(value.cpu().numpy(), shapes.cpu().numpy(), lsi.cpu().numpy(),
+                         loc.cpu().numpy(), attn.cpu().numpy())
+    out = MSDeformAttnFunction.apply(value, shapes, lsi, loc, attn, 2)
+    assert torch.allclose(out.cpu(), torch.from_numpy(ref), rtol=1e-2, atol=1e-3)   # test.py:56
+
+
+@pytest.mark.parametrize("channels", [30, 32, 64, 71, 1025, 2048, 3096])
+def test_reference_test_gradcheck(native, channels):
+    """check_gradient_numerical (test.py:63-78): fp64 gradcheck with torch's defaults."""
+    from uvhand_amd.functions import MSDeformAttnFunction
+    torch.manual_seed(3 + channels)
+    value, shapes, lsi, loc, attn = _testpy_inputs(channels)
+    value.requires_grad = True
+    loc.requires_grad = True
+    attn.requires_grad = True
+    assert torch.autograd.gradcheck(
+        MSDeformAttnFunction.apply,
+        (value.double(), shapes, lsi, loc.double(), attn.double(), 2))
+
+
+# ---------------------------------------------------------------------------------------------
+# edge cases and error behaviour
+# ---------------------------------------------------------------------------------------------
+def test_empty_and_degenerate_inputs(native, path):
+    from uvhand_amd.functions import MSDeformAttnFunction
+    shapes = torch.tensor([[4, 4], [2, 2]], dtype=torch.long).cuda()
+    lsi = torch.tensor([0, 16], dtype=torch.long).cuda()
+    for N, Lq in ((2, 0), (0, 5)):
+        v = torch.rand(N, 20, 8, 32).cuda().requires_grad_(True)
+        l = torch.rand(N, Lq, 8, 2, 4, 2).cuda().requires_grad_(True)
+        a = torch.rand(N, Lq, 8, 2, 4).cuda().requires_grad_(True)
+        out = MSDeformAttnFunction.apply(v, shapes, lsi, l, a, 64)
+        assert tuple(out.shape) == (N, Lq, 256)
+        out.sum().backward()
+        torch.cuda.synchronize()
+        assert not v.grad.any() and tuple(l.grad.shape) == tuple(l.shape)
+    # every location far outside: exact zeros, and NaN locations behave like "outside"
+    v = torch.rand(1, 20, 8, 32).cuda().requires_grad_(True)
+    l = (torch.rand(1, 6, 8, 2, 4, 2).cuda() + 5.0)
+    l[0, 0, 0, 0, 0, 0] = float("nan")
+    l.requires_grad_(True)
+    a = torch.rand(1, 6, 8, 2, 4).cuda().requires_grad_(True)
+    out = MSDeformAttnFunction.apply(v, shapes, lsi, l, a, 64)
+    out.backward(torch.ones_like(out))
+    torch.cuda.synchronize()
+    for t in (out, v.grad, l.grad, a.grad):
+        assert not t.isnan().any() and not t.any()
+
+
+def test_inf_in_value_outside_taps_does_not_leak(native, path):
+    """A tap that is not sampled must not be read into the result (0 * inf)."""
+    from uvhand_amd.functions import MSDeformAttnFunction
+    shapes = torch.tensor([[3, 3]], dtype=torch.long).cuda()
+    lsi = torch.tensor([0], dtype=torch.long).cuda()
+    v = torch.rand(1, 9, 8, 32).cuda()
+    v[0, 0] = float("inf")                      # pixel (0,0)
+    l = torch.full((1, 4, 8, 1, 2, 2), 0.75).cuda()   # pixel coordinate 1.75: taps (1,1)..(2,2)
+    l[..., 1, :] = 1.2                          # second point partly outside on the far side
+    a = torch.full((1, 4, 8, 1, 2), 0.5).cuda()
+    out = MSDeformAttnFunction.apply(v, shapes, lsi, l, a, 64)
+    assert torch.isfinite(out).all()
+
+
+def test_host_errors_follow_the_reference(native):
+    from uvhand_amd.functions import MSDeformAttnFunction
+    z = make_case(0, 4, [(4, 4), (2, 2)], 8, 32, 6, 2)
+    v, l, a = dev(z["value"]), dev(z["loc"]), dev(z["attn"])
+    s, i = dev(z["shapes"]), dev(z["level_start"])
+    with pytest.raises(RuntimeError, match=r"batch\(4\) must divide im2col_step\(3\)"):
+        MSDeformAttnFunction.apply(v, s, i, l, a, 3)              # ms_deform_attn_cuda.cu:52
+    with pytest.raises(RuntimeError, match="sampling_loc tensor has to be contiguous"):
+        MSDeformAttnFunction.apply(v, s, i, l.transpose(1, 2).contiguous().transpose(1, 2), a, 64)
+    with pytest.raises(RuntimeError, match="spatial_shapes must be a CUDA tensor"):
+        MSDeformAttnFunction.apply(v, s.cpu(), i, l, a, 64)
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        MSDeformAttnFunction.apply(v.cpu(), s, i, l, a, 64)
+    with pytest.raises(RuntimeError):                              # dtype mismatch (data<scalar_t>())
+        MSDeformAttnFunction.apply(v, s, i, l.double(), a, 64)
+    # results do not depend on im2col_step; a non-contiguous grad_output is accepted
+    v.requires_grad_(True)
+    o1 = MSDeformAttnFunction.apply(v, s, i, l, a, 2)
+    o2 = MSDeformAttnFunction.apply(v, s, i, l, a, 64)
+    assert torch.equal(o1, o2)
+    go = torch.rand(256, 6, 4).cuda().permute(2, 1, 0)
+    o2.backward(go)
+    assert v.grad is not None and torch.isfinite(v.grad).all()
+
+
+def test_value_is_cast_like_the_reference(native):
+    """functions/ms_deform_attn_func.py:26,37: value.to(float32) in forward and backward."""
+    from uvhand_amd.functions import MSDeformAttnFunction
+    z = make_case(0, 2, [(4, 4), (2, 2)], 8, 32, 6, 2)
+    v16 = dev(z["value"]).half().requires_grad_(True)
+    l, a = dev(z["loc"]), dev(z["attn"])
+    out = MSDeformAttnFunction.apply(v16, dev(z["shapes"]), dev(z["level_start"]), l, a, 64)
+    assert out.dtype == torch.float32
+    out.sum().backward()
+    assert v16.grad.dtype == torch.float16
+    ref = MSDeformAttnFunction.apply(v16.detach().float(), dev(z["shapes"]), dev(z["level_start"]), l, a, 64)
+    assert torch.equal(out, ref)
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json's full sizes: size-independent properties (the oracle would take too long)
+# ---------------------------------------------------------------------------------------------
+FULL = {
+    "cfg2_decoder": (2, [(48, 48), (24, 24), (12, 12), (6, 6)], 8, 32, 300, 4),
+    "cfg2_encoder": (2, [(48, 48), (24, 24), (12, 12), (6, 6)], 8, 32, 3060, 4),
+    "cfg4_decoder": (32, [(28, 28), (14, 14), (7, 7), (4, 4)], 8, 32, 300, 4),
+    "cfg4_encoder": (32, [(28, 28), (14, 14), (7, 7), (4, 4)], 8, 32, 1045, 4),
+}
+
+
+@pytest.mark.parametrize("name", list(FULL))
+def test_full_size_properties(native, name):
+    from uvhand_amd.functions import MSDeformAttnFunction
+    z = make_case(0, *FULL[name], lo=-0.1, hi=1.1)
+    s, i = dev(z["shapes"]), dev(z["level_start"])
+    v = dev(z["value"]).requires_grad_(True)
+    l = dev(z["loc"]).requires_grad_(True)
+    a = dev(z["attn"]).requires_grad_(True)
+    go = dev(z["grad_out"])
+    out = MSDeformAttnFunction.apply(v, s, i, l, a, 64)
+    out.backward(go)
+    torch.cuda.synchronize()
+    dot = (out.double() * go.double()).sum().item()
+    # the op is linear in value: <out, go> = <value, grad_value>
+    assert abs(dot - (v.double() * v.grad.double()).sum().item()) < 1e-5 * abs(dot)
+    # out = sum_p attn_p * sample_p: <out, go> = <attn, grad_attn>
+    assert abs(dot - (a.double() * a.grad.double()).sum().item()) < 1e-5 * abs(dot)
+    # linearity: f(2.5 v) = 2.5 f(v)
+    out2 = MSDeformAttnFunction.apply(2.5 * v.detach(), s, i, l.detach(), a.detach(), 64)
+    assert rel_err(out2.cpu().numpy(), 2.5 * out.detach().cpu().numpy()) < 1e-6
+    # a constant map samples to (sum of in-range bilinear weights) <= 1, and exactly the sum of
+    # attention weights for points well inside every level
+    ones = torch.ones_like(v.detach())
+    inner = l.detach().clamp(0.2, 0.8)
+    o = MSDeformAttnFunction.apply(ones, s, i, inner, a.detach(), 64)
+    assert rel_err(o.cpu().numpy(), np.ones(o.shape, np.float32)) < 1e-5
+    # directional derivative along a random location perturbation vs finite differences (fp64 sums)
+    g = torch.Generator().manual_seed(1)
+    dl = (torch.rand(l.shape, generator=g) - 0.5).cuda()
+    eps = 1e-3
+    fp = (MSDeformAttnFunction.apply(v.detach(), s, i, l.detach() + eps * dl, a.detach(), 64).double() * go).sum()
+    fm = (MSDeformAttnFunction.apply(v.detach(), s, i, l.detach() - eps * dl, a.detach(), 64).double() * go).sum()
+    num = ((fp - fm) / (2 * eps)).item()
+    ana = (l.grad.double() * dl.double()).sum().item()
+    assert abs(num - ana) < 2e-2 * abs(ana) + 1e-6        # kinks at pixel centres make this O(eps)
+
+
+def test_full_size_vs_oracle_subsample(native, oracle):
+    """cfg-2 decoder at full size against the C oracle (it finishes in well under a second)."""
+    z = make_case(0, *FULL["cfg2_decoder"])
+    out, gv, gl, ga = run_hip(z, torch.float32)
+    args = [z["value"], z["shapes"], z["level_start"], z["loc"], z["attn"]]
+    r_gv, r_gl, r_ga = oracle.backward(z["grad_out"], *args)
+    assert rel_err(out, oracle.forward(*args)) < 5e-6
+    assert rel_err(gv, r_gv) < 2e-5
+    assert rel_err(ga, r_ga) < 2e-5
+    keep = ~near_boundary_mask(z, tol=1e-5)
+    assert rel_err(gl[keep], r_gl[keep]) < 2e-5
+
+
+def test_runs_on_the_current_stream_without_sync(native):
+    """Stream-ordered: results are right when launched on a side stream."""
+    from uvhand_amd.functions import MSDeformAttnFunction
+    z = make_case(3, 2, [(8, 8), (4, 4)], 8, 32, 40, 4)
+    ref = run_hip(z, torch.float32)[0]
+    st = torch.cuda.Stream()
+    v, l, a = dev(z["value"]), dev(z["loc"]), dev(z["attn"])
+    s, i = dev(z["shapes"]), dev(z["level_start"])
+    torch.cuda.synchronize()
+    with torch.cuda.stream(st):
+        out = MSDeformAttnFunction.apply(v, s, i, l, a, 64)
+    st.synchronize()
+    assert np.array_equal(out.cpu().numpy(), ref)

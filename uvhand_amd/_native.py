@@ -1,0 +1,171 @@
+"""ctypes binding of ``libmsda_hip.so`` (C ABI: ``include/msda.h``).
+
+This is the only route from Python to the HIP kernels, and there is no other
+implementation behind it: if the library is missing or a call fails, this module
+raises — it never falls back to PyTorch ops or to anything under ``oracle/``.
+
+It stands where the reference's pybind module ``MultiScaleDeformableAttention``
+stands (UVHand models/ops/src/vision.cpp:13-16, imported as ``MSDA`` at
+models/ops/functions/ms_deform_attn_func.py:18) and reproduces the host-side
+checks of models/ops/src/cuda/ms_deform_attn_cuda.cu:28-52, 93-117 and the
+CPU-tensor error of models/ops/src/ms_deform_attn.h:38,60.
+"""
+import ctypes
+import os
+
+import torch
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libmsda_hip.so")
+
+_lib = None
+
+_SYMBOLS = (
+    "msda_forward_f32", "msda_backward_f32", "msda_forward_f64", "msda_backward_f64",
+    "msda_last_error", "msda_version", "msda_path_for", "msda_force_path",
+)
+
+
+def load():
+    """Load (once) and return the ctypes handle; raise if the HIP library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "uvhand_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C uvhand_amd/csrc`). There is no non-HIP fallback for this op." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name in _SYMBOLS:
+        if not hasattr(lib, name):
+            raise RuntimeError("uvhand_amd: %s does not export %s (stale build?)" % (LIB_PATH, name))
+    lib.msda_last_error.restype = ctypes.c_char_p
+    lib.msda_version.restype = ctypes.c_int
+    lib.msda_path_for.restype = ctypes.c_int
+    lib.msda_force_path.restype = None
+    _lib = lib
+    return lib
+
+
+def _suffix(dtype):
+    if dtype == torch.float32:
+        return "f32"
+    if dtype == torch.float64:
+        return "f64"
+    raise RuntimeError('"ms_deform_attn" not implemented for \'%s\'' % str(dtype).replace("torch.", ""))
+
+
+def _check_inputs(named):
+    # order and wording follow ms_deform_attn_cuda.cu:28-38 / :93-105
+    if not named[0][1].is_cuda:
+        raise RuntimeError("Not implemented on the CPU")          # ms_deform_attn.h:38,60
+    for name, t in named:
+        if not t.is_contiguous():
+            raise RuntimeError("%s tensor has to be contiguous" % name)
+    for name, t in named:
+        if not t.is_cuda:
+            raise RuntimeError("%s must be a CUDA tensor" % name)
+    dev = named[0][1].device
+    for name, t in named:
+        if t.device != dev:
+            raise RuntimeError("%s must be on the same device as value (%s vs %s)" % (name, t.device, dev))
+
+
+def _dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
+    if value.dim() != 4 or sampling_loc.dim() != 6 or attn_weight.dim() != 5:
+        raise RuntimeError("ms_deform_attn: expected value[N,S,M,D], sampling_loc[N,Lq,M,L,P,2], "
+                           "attn_weight[N,Lq,M,L,P]")
+    N, S, M, D = value.shape
+    L = spatial_shapes.shape[0]
+    Lq, P = sampling_loc.shape[1], sampling_loc.shape[4]
+    if tuple(sampling_loc.shape) != (N, Lq, M, L, P, 2) or tuple(attn_weight.shape) != (N, Lq, M, L, P):
+        raise RuntimeError("ms_deform_attn: sampling_loc %s / attn_weight %s do not match value %s and %d levels"
+                           % (tuple(sampling_loc.shape), tuple(attn_weight.shape), tuple(value.shape), L))
+    if spatial_shapes.dtype != torch.int64 or level_start_index.dtype != torch.int64:
+        raise RuntimeError("expected scalar type Long for spatial_shapes / level_start_index")
+    if tuple(spatial_shapes.shape) != (L, 2) or tuple(level_start_index.shape) != (L,):
+        raise RuntimeError("ms_deform_attn: spatial_shapes must be [L,2] and level_start_index [L]")
+    step = min(N, int(im2col_step))                                # ms_deform_attn_cuda.cu:50-52
+    if N > 0 and (step <= 0 or N % step != 0):
+        raise RuntimeError("batch(%d) must divide im2col_step(%d)" % (N, step))
+    return N, S, M, D, L, Lq, P
+
+
+def _compute_dtypes(value, sampling_loc, attn_weight):
+    """value-like tensors' dtype T and location-like tensors' dtype TL (include/msda.h)."""
+    if sampling_loc.dtype != attn_weight.dtype:
+        raise RuntimeError("expected sampling_loc and attn_weight to have the same dtype, got %s and %s"
+                           % (sampling_loc.dtype, attn_weight.dtype))
+    suf = _suffix(value.dtype)
+    want_tl = torch.float32 if suf == "bf16" else value.dtype
+    if sampling_loc.dtype != want_tl:
+        raise RuntimeError("expected scalar type %s but found %s"
+                           % (str(want_tl).replace("torch.", "").capitalize(),
+                              str(sampling_loc.dtype).replace("torch.", "").capitalize()))
+    return suf
+
+
+def _raise(lib, rc, what):
+    msg = lib.msda_last_error()
+    raise RuntimeError("%s failed (code %d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
+    """Replaces MSDA.ms_deform_attn_forward (vision.cpp:14). Returns out[N, Lq, M*D]."""
+    lib = load()
+    _check_inputs([("value", value), ("spatial_shapes", spatial_shapes),
+                   ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
+                   ("attn_weight", attn_weight)])
+    N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step)
+    suf = _compute_dtypes(value, sampling_loc, attn_weight)
+    with torch.cuda.device_of(value):
+        out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(value.device).cuda_stream)
+        rc = getattr(lib, "msda_forward_" + suf)(
+            _p(value), _p(spatial_shapes), _p(level_start_index), _p(sampling_loc), _p(attn_weight),
+            ctypes.c_int(N), ctypes.c_int(S), ctypes.c_int(M), ctypes.c_int(D), ctypes.c_int(L),
+            ctypes.c_int(Lq), ctypes.c_int(P), _p(out), stream)
+    if rc != 0:
+        _raise(lib, rc, "ms_deform_attn_forward")
+    return out
+
+
+def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output,
+                            im2col_step):
+    """Replaces MSDA.ms_deform_attn_backward (vision.cpp:15).
+    Returns (grad_value, grad_sampling_loc, grad_attn_weight)."""
+    lib = load()
+    _check_inputs([("value", value), ("spatial_shapes", spatial_shapes),
+                   ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
+                   ("attn_weight", attn_weight), ("grad_output", grad_output)])
+    N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step)
+    suf = _compute_dtypes(value, sampling_loc, attn_weight)
+    if grad_output.dtype != value.dtype or grad_output.numel() != N * Lq * M * D:
+        raise RuntimeError("ms_deform_attn_backward: grad_output must be %s[%d,%d,%d]"
+                           % (value.dtype, N, Lq, M * D))
+    with torch.cuda.device_of(value):
+        grad_value = torch.empty_like(value)
+        grad_loc = torch.empty_like(sampling_loc)
+        grad_attn = torch.empty_like(attn_weight)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(value.device).cuda_stream)
+        rc = getattr(lib, "msda_backward_" + suf)(
+            _p(grad_output), _p(value), _p(spatial_shapes), _p(level_start_index), _p(sampling_loc),
+            _p(attn_weight),
+            ctypes.c_int(N), ctypes.c_int(S), ctypes.c_int(M), ctypes.c_int(D), ctypes.c_int(L),
+            ctypes.c_int(Lq), ctypes.c_int(P), _p(grad_value), _p(grad_loc), _p(grad_attn), stream)
+    if rc != 0:
+        _raise(lib, rc, "ms_deform_attn_backward")
+    return grad_value, grad_loc, grad_attn
+
+
+def path_for(elem_bytes, M, D, L, P):
+    return int(load().msda_path_for(ctypes.c_int(elem_bytes), ctypes.c_int(M), ctypes.c_int(D),
+                                    ctypes.c_int(L), ctypes.c_int(P)))
+
+
+def force_path(path):
+    load().msda_force_path(ctypes.c_int(int(path)))

@@ -1,0 +1,149 @@
+// C ABI of libmsda_hip.so (declared in include/msda.h): argument validation, kernel-family
+// selection, error reporting.  No torch types, no allocation, no device synchronisation.
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+
+#include "msda_launch.h"
+
+namespace msda {
+
+static thread_local char g_err[512] = "";
+static std::atomic<int> g_force_path{-1};
+
+int set_error(int code, const char *msg)
+{
+    std::snprintf(g_err, sizeof(g_err), "%s", msg ? msg : "unknown error");
+    return code;
+}
+
+int check_launch(const char *what)
+{
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return MSDA_OK;
+    char buf[400];
+    std::snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+    return set_error(MSDA_ERR_LAUNCH, buf);
+}
+
+static int check_args(const void *const *ptrs, int nptrs, int N, int S, int M, int D, int L, int Lq,
+                      int P)
+{
+    if (N < 0 || S < 0 || M <= 0 || D <= 0 || L <= 0 || Lq < 0 || P <= 0)
+        return set_error(MSDA_ERR_ARGUMENT, "msda: sizes must be positive (N, S, Lq may be 0)");
+    if (N == 0 || Lq == 0 || S == 0) return MSDA_OK;               // nothing to read
+    for (int i = 0; i < nptrs; ++i)
+        if (ptrs[i] == nullptr) return set_error(MSDA_ERR_ARGUMENT, "msda: null device pointer");
+    return MSDA_OK;
+}
+
+static bool use_d32(int N, int S, int M, int D, int L, int Lq, int P)
+{
+    const int f = g_force_path.load(std::memory_order_relaxed);
+    if (f == MSDA_PATH_GENERIC) return false;
+    return d32_supported(N, S, M, D, L, Lq, P);
+}
+
+template <typename T>
+static int forward_impl(const T *value, const int64_t *shapes, const int64_t *level_start,
+                        const T *loc, const T *attn, int N, int S, int M, int D, int L, int Lq, int P,
+                        T *out, hipStream_t stream, bool d32)
+{
+    const void *ptrs[] = {value, shapes, level_start, loc, attn, out};
+    if (int rc = check_args(ptrs, 6, N, S, M, D, L, Lq, P)) return rc;
+    g_err[0] = 0;
+    if (N == 0 || Lq == 0) return MSDA_OK;                          // empty output
+    if (S == 0) {                                                   // no pixels: every tap is outside
+        const hipError_t e = hipMemsetAsync(out, 0, sizeof(T) * (size_t)N * Lq * M * D, stream);
+        return e == hipSuccess ? MSDA_OK : set_error(MSDA_ERR_LAUNCH, hipGetErrorString(e));
+    }
+    if constexpr (sizeof(T) == 4) {
+        if (d32) return launch_fwd_d32(value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, out, stream);
+    }
+    return launch_fwd_generic<T>(value, shapes, level_start, loc, attn, N, S, M, D, L, Lq, P, out, stream);
+}
+
+template <typename T>
+static int backward_impl(const T *grad_out, const T *value, const int64_t *shapes,
+                         const int64_t *level_start, const T *loc, const T *attn, int N, int S, int M,
+                         int D, int L, int Lq, int P, T *grad_value, T *grad_loc, T *grad_attn,
+                         hipStream_t stream, bool d32)
+{
+    const void *ptrs[] = {grad_out, value, shapes, level_start, loc, attn, grad_value, grad_loc, grad_attn};
+    if (int rc = check_args(ptrs, 9, N, S, M, D, L, Lq, P)) return rc;
+    g_err[0] = 0;
+    if (N == 0) return MSDA_OK;
+    if (Lq == 0 || S == 0) {                                        // no contributions at all
+        hipError_t e = hipSuccess;
+        if (S > 0) e = hipMemsetAsync(grad_value, 0, sizeof(T) * (size_t)N * S * M * D, stream);
+        if (e == hipSuccess && Lq > 0) {
+            e = hipMemsetAsync(grad_loc, 0, sizeof(T) * (size_t)N * Lq * M * L * P * 2, stream);
+            if (e == hipSuccess)
+                e = hipMemsetAsync(grad_attn, 0, sizeof(T) * (size_t)N * Lq * M * L * P, stream);
+        }
+        return e == hipSuccess ? MSDA_OK : set_error(MSDA_ERR_LAUNCH, hipGetErrorString(e));
+    }
+    if constexpr (sizeof(T) == 4) {
+        if (d32) return launch_bwd_d32(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P,
+                                       grad_value, grad_loc, grad_attn, stream);
+    }
+    return launch_bwd_generic<T>(grad_out, value, shapes, level_start, loc, attn, N, S, M, D, L, Lq, P,
+                                 grad_value, grad_loc, grad_attn, stream);
+}
+
+}  // namespace msda
+
+extern "C" {
+
+int msda_forward_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                     const float *sampling_loc, const float *attn_weight, int N, int S, int M, int D,
+                     int L, int Lq, int P, float *out, msda_stream_t stream)
+{
+    return msda::forward_impl<float>(value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S,
+                                     M, D, L, Lq, P, out, (hipStream_t)stream,
+                                     msda::use_d32(N, S, M, D, L, Lq, P));
+}
+
+int msda_backward_f32(const float *grad_out, const float *value, const int64_t *spatial_shapes,
+                      const int64_t *level_start, const float *sampling_loc, const float *attn_weight,
+                      int N, int S, int M, int D, int L, int Lq, int P, float *grad_value,
+                      float *grad_sampling_loc, float *grad_attn_weight, msda_stream_t stream)
+{
+    return msda::backward_impl<float>(grad_out, value, spatial_shapes, level_start, sampling_loc,
+                                      attn_weight, N, S, M, D, L, Lq, P, grad_value, grad_sampling_loc,
+                                      grad_attn_weight, (hipStream_t)stream,
+                                      msda::use_d32(N, S, M, D, L, Lq, P));
+}
+
+int msda_forward_f64(const double *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                     const double *sampling_loc, const double *attn_weight, int N, int S, int M, int D,
+                     int L, int Lq, int P, double *out, msda_stream_t stream)
+{
+    return msda::forward_impl<double>(value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S,
+                                      M, D, L, Lq, P, out, (hipStream_t)stream, false);
+}
+
+int msda_backward_f64(const double *grad_out, const double *value, const int64_t *spatial_shapes,
+                      const int64_t *level_start, const double *sampling_loc,
+                      const double *attn_weight, int N, int S, int M, int D, int L, int Lq, int P,
+                      double *grad_value, double *grad_sampling_loc, double *grad_attn_weight,
+                      msda_stream_t stream)
+{
+    return msda::backward_impl<double>(grad_out, value, spatial_shapes, level_start, sampling_loc,
+                                       attn_weight, N, S, M, D, L, Lq, P, grad_value, grad_sampling_loc,
+                                       grad_attn_weight, (hipStream_t)stream, false);
+}
+
+const char *msda_last_error(void) { return msda::g_err; }
+
+int msda_version(void) { return 100; }
+
+int msda_path_for(int elem_bytes, int M, int D, int L, int P)
+{
+    // N, S, Lq only matter through the int32-offset limits; probe with small ones.
+    return (elem_bytes == 4 && msda::use_d32(1, 1, M, D, L, 1, P)) ? MSDA_PATH_D32 : MSDA_PATH_GENERIC;
+}
+
+void msda_force_path(int path) { msda::g_force_path.store(path, std::memory_order_relaxed); }
+
+}  // extern "C"

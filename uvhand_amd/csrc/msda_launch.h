@@ -1,0 +1,37 @@
+// Host-side plumbing shared by the kernel translation units: the thread-local error
+// string behind msda_last_error() and the declarations of the per-family launchers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "msda.h"
+
+namespace msda {
+
+// Records `msg` for msda_last_error() on this thread and returns `code`.
+int set_error(int code, const char *msg);
+// Returns MSDA_OK, or records hipGetLastError() (prefixed by `what`) and returns MSDA_ERR_LAUNCH.
+int check_launch(const char *what);
+
+// ---- generic family (msda_generic.hip): any D, float / double -------------------------------
+template <typename T>
+int launch_fwd_generic(const T *value, const int64_t *shapes, const int64_t *level_start,
+                       const T *loc, const T *attn, int N, int S, int M, int D, int L, int Lq, int P,
+                       T *out, hipStream_t stream);
+template <typename T>
+int launch_bwd_generic(const T *grad_out, const T *value, const int64_t *shapes,
+                       const int64_t *level_start, const T *loc, const T *attn, int N, int S, int M,
+                       int D, int L, int Lq, int P, T *grad_value, T *grad_loc, T *grad_attn,
+                       hipStream_t stream);
+
+// ---- D = 32 fp32 family (msda_d32.hip): the model's shape ------------------------------------
+bool d32_supported(int N, int S, int M, int D, int L, int Lq, int P);
+int launch_fwd_d32(const float *value, const int64_t *shapes, const int64_t *level_start,
+                   const float *loc, const float *attn, int N, int S, int M, int L, int Lq, int P,
+                   float *out, hipStream_t stream);
+int launch_bwd_d32(const float *grad_out, const float *value, const int64_t *shapes,
+                   const int64_t *level_start, const float *loc, const float *attn, int N, int S,
+                   int M, int L, int Lq, int P, float *grad_value, float *grad_loc, float *grad_attn,
+                   hipStream_t stream);
+
+}  // namespace msda

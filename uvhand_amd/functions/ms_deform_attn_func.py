@@ -1,0 +1,50 @@
+"""``MSDeformAttnFunction`` — the autograd entry point of the op, API-compatible with
+UVHand ``models/ops/functions/ms_deform_attn_func.py:21-39`` but backed by the HIP
+kernels in ``uvhand_amd/csrc`` through the C ABI of ``include/msda.h``.
+
+    out = MSDeformAttnFunction.apply(value[N,S,M,D], value_spatial_shapes int64[L,2],
+                                     value_level_start_index int64[L],
+                                     sampling_locations[N,Lq,M,L,P,2],
+                                     attention_weights[N,Lq,M,L,P], im2col_step)
+    -> out[N, Lq, M*D];  grads for value, sampling_locations, attention_weights only.
+
+Behaviour kept from the reference: ``value`` is cast to the compute dtype before the
+native call in forward and in backward (:26,:37 cast it to float32; here the compute
+dtype is that of ``sampling_locations`` — float32 in the models, float64 under the
+reference test's gradcheck, models/ops/test.py:76, which the upstream un-cast
+wrapper supports); the tensors saved for backward are the un-cast inputs (:28);
+backward is once-differentiable (:32); CPU tensors raise (src/ms_deform_attn.h:38).
+There is no PyTorch fallback in this package: the reference's debug helper
+``ms_deform_attn_core_pytorch`` (:42-62) is restated only under ``oracle/`` as test
+infrastructure.
+"""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .. import _native as MSDA
+
+
+class MSDeformAttnFunction(Function):
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                attention_weights, im2col_step):
+        ctx.im2col_step = im2col_step
+        output = MSDA.ms_deform_attn_forward(
+            value.to(sampling_locations.dtype), value_spatial_shapes, value_level_start_index,
+            sampling_locations, attention_weights, ctx.im2col_step)
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index,
+                              sampling_locations, attention_weights)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights = \
+            ctx.saved_tensors
+        # the reference asserts contiguity of grad_output (ms_deform_attn_cuda.cu:98) and would
+        # raise on e.g. an expanded gradient; making it contiguous is the superset behaviour.
+        grad_value, grad_sampling_loc, grad_attn_weight = MSDA.ms_deform_attn_backward(
+            value.to(sampling_locations.dtype), value_spatial_shapes, value_level_start_index,
+            sampling_locations, attention_weights, grad_output.contiguous(), ctx.im2col_step)
+        return grad_value, None, None, grad_sampling_loc, grad_attn_weight, None

@@ -1,0 +1,142 @@
+"""``MSDeformAttn`` — multi-scale deformable attention module, drop-in for UVHand
+``models/ops/modules/ms_deform_attn.py:30-140`` (imported by
+``models/arctic_transformer.py:20``, ``models/origin_deformable_transformer.py:20``,
+``models/assembly_transformer.py:20``).
+
+Contract kept: constructor signature and defaults; the attributes
+``im2col_step, d_model, n_levels, n_heads, n_points``; the four ``nn.Linear``
+sub-modules named ``sampling_offsets, attention_weights, value_proj, output_proj``
+(checkpoint keys, and ``lr_linear_proj_names`` in util/settings.py:75, depend on the
+names), created in that order so that a seeded construction consumes the RNG stream
+exactly like the reference; ``_reset_parameters()`` (:62-78; called again from
+outside, models/arctic_transformer.py:80-81); the ``forward`` signature and its
+reference-point branches: 2-d (:105-108), the ARCTIC 42-d keypoint branch (21 (x, y)
+keypoints averaged per level, :110-128) and the upstream 4-d box branch that the
+dn_dab copy carries (models/dn_dab_dino_deformable_detr/ops/modules/ms_deform_attn.py:106-108);
+any other width raises ``ValueError`` (:134-136).
+
+The sampling itself is ``MSDeformAttnFunction`` (HIP kernels); the four projections
+stay ``nn.Linear`` (hipBLASLt / MFMA on ROCm), as north_star prescribes.
+"""
+import math
+import warnings
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ..functions import MSDeformAttnFunction
+
+
+# (data_ptr, version, Len_in) of spatial_shapes tensors whose H*W sum was already verified: the
+# reference's assert (:93) costs a device->host sync on every call of every layer; checking each
+# distinct shapes tensor once keeps the check without stalling the launch queue 12x per step.
+_verified_shapes = set()
+
+
+def _check_shapes_sum(spatial_shapes, len_in):
+    key = (spatial_shapes.data_ptr(), spatial_shapes._version, tuple(spatial_shapes.shape), int(len_in))
+    if key in _verified_shapes:
+        return
+    assert (spatial_shapes[:, 0] * spatial_shapes[:, 1]).sum() == len_in
+    if len(_verified_shapes) > 4096:
+        _verified_shapes.clear()
+    _verified_shapes.add(key)
+
+
+def _is_power_of_2(n):
+    if not isinstance(n, int) or n < 0:
+        raise ValueError("invalid input for _is_power_of_2: {} (type: {})".format(n, type(n)))
+    return n != 0 and (n & (n - 1)) == 0
+
+
+class MSDeformAttn(nn.Module):
+    def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4):
+        super().__init__()
+        if d_model % n_heads != 0:
+            raise ValueError("d_model must be divisible by n_heads, but got {} and {}".format(d_model, n_heads))
+        if not _is_power_of_2(d_model // n_heads):
+            warnings.warn("MSDeformAttn: a per-head dimension that is a power of 2 (32 in the UVHand models) "
+                          "takes the tiled HIP kernels; other widths use the generic ones.")
+
+        self.im2col_step = 64
+        self.d_model = d_model
+        self.n_levels = n_levels
+        self.n_heads = n_heads
+        self.n_points = n_points
+
+        self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
+        self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
+        self.value_proj = nn.Linear(d_model, d_model)
+        self.output_proj = nn.Linear(d_model, d_model)
+
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        # sampling offsets start as the n_heads unit directions of a regular polygon, scaled to the
+        # unit square's border and by the point index 1..n_points; attention logits start at zero.
+        nn.init.constant_(self.sampling_offsets.weight.data, 0.0)
+        angles = torch.arange(self.n_heads, dtype=torch.float32) * (2.0 * math.pi / self.n_heads)
+        dirs = torch.stack([angles.cos(), angles.sin()], -1)
+        dirs = dirs / dirs.abs().max(-1, keepdim=True)[0]
+        bias = dirs.view(self.n_heads, 1, 1, 2).repeat(1, self.n_levels, self.n_points, 1)
+        bias = bias * torch.arange(1, self.n_points + 1, dtype=torch.float32).view(1, 1, self.n_points, 1)
+        with torch.no_grad():
+            self.sampling_offsets.bias = nn.Parameter(bias.reshape(-1))
+        nn.init.constant_(self.attention_weights.weight.data, 0.0)
+        nn.init.constant_(self.attention_weights.bias.data, 0.0)
+        nn.init.xavier_uniform_(self.value_proj.weight.data)
+        nn.init.constant_(self.value_proj.bias.data, 0.0)
+        nn.init.xavier_uniform_(self.output_proj.weight.data)
+        nn.init.constant_(self.output_proj.bias.data, 0.0)
+
+    def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
+                input_padding_mask=None):
+        """
+        query                    (N, Len_q, C)
+        reference_points         (N, Len_q, n_levels, 2) in [0, 1] (top-left (0,0), bottom-right (1,1)), or
+                                 (N, Len_q, n_levels, 42): 21 (x, y) keypoints, averaged, or
+                                 (N, Len_q, n_levels, 4): (cx, cy, w, h) reference boxes
+        input_flatten            (N, sum_l H_l*W_l, C)
+        input_spatial_shapes     (n_levels, 2) int64 [(H_0, W_0), ...]
+        input_level_start_index  (n_levels,) int64 [0, H_0*W_0, ...]
+        input_padding_mask       (N, sum_l H_l*W_l) bool, True at padding
+        returns                  (N, Len_q, C)
+        """
+        N, Len_q, _ = query.shape
+        N, Len_in, _ = input_flatten.shape
+        _check_shapes_sum(input_spatial_shapes, Len_in)
+
+        value = self.value_proj(input_flatten)
+        if input_padding_mask is not None:
+            value = value.masked_fill(input_padding_mask[..., None], float(0))
+        value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
+        sampling_offsets = self.sampling_offsets(query).view(
+            N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
+        attention_weights = self.attention_weights(query).view(
+            N, Len_q, self.n_heads, self.n_levels * self.n_points)
+        attention_weights = F.softmax(attention_weights, -1).view(
+            N, Len_q, self.n_heads, self.n_levels, self.n_points)
+
+        ref_dim = reference_points.shape[-1]
+        if ref_dim == 2 or ref_dim == 42:
+            # offsets are in pixels of each level: normalise by (W_l, H_l)
+            wh = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)
+            if ref_dim == 2:
+                centre = reference_points[:, :, None, :, None, :]
+            else:
+                cx = reference_points[:, :, None, :, None, 0::2].mean(-1).unsqueeze(-1)
+                cy = reference_points[:, :, None, :, None, 1::2].mean(-1).unsqueeze(-1)
+                centre = torch.cat([cx, cy], dim=-1)
+            sampling_locations = centre + sampling_offsets / wh[None, None, None, :, None, :]
+        elif ref_dim == 4:
+            sampling_locations = reference_points[:, :, None, :, None, :2] \
+                + sampling_offsets / self.n_points * reference_points[:, :, None, :, None, 2:] * 0.5
+        else:
+            raise ValueError(
+                "Last dim of reference_points must be 2 or 4, but get {} instead.".format(ref_dim))
+
+        output = MSDeformAttnFunction.apply(
+            value, input_spatial_shapes, input_level_start_index, sampling_locations, attention_weights,
+            self.im2col_step)
+        return self.output_proj(output)
