@@ -68,26 +68,39 @@ def make_inputs(workload, seed, device):
     return host, dev, (N, S, M, D, L, Lq, P)
 
 
-def time_cpu_baseline(workload, budget_s=12.0):
-    """The reference's CPU comparator (grid_sample fallback; port under oracle/) on this node's cores."""
+def usable_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def time_cpu_baseline(workload, budget_s=8.0):
+    """The reference's CPU comparator (grid_sample fallback; port under oracle/) on this node's host
+    cores.  Two thread settings: every usable core, capped at the 16-core share
+    a 1-GPU box grants, and 8 (the survey container's setting); the faster one is reported."""
     from oracle.torch_fallback import fwd_bwd
     host, _, dims = make_inputs(workload, 0, None)
     N = dims[0]
-    cores = torch.get_num_threads()
-    for _ in range(2):
-        fwd_bwd(host["value"], host["shapes"], host["loc"], host["attn"], host["go"])
-    n, t0 = 0, time.perf_counter()
-    while True:
-        fwd_bwd(host["value"], host["shapes"], host["loc"], host["attn"], host["go"])
-        n += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or n >= 400:
-            break
-    return {"value": N * n / el, "unit": "samples/s", "cores": cores, "kind": "port",
-            "ms_per_step": 1e3 * el / n,
+    runs = []
+    for threads in sorted({min(16, usable_cores()), min(8, usable_cores())}, reverse=True):
+        torch.set_num_threads(threads)
+        for _ in range(2):
+            fwd_bwd(host["value"], host["shapes"], host["loc"], host["attn"], host["go"])
+        n, t0 = 0, time.perf_counter()
+        while True:
+            fwd_bwd(host["value"], host["shapes"], host["loc"], host["attn"], host["go"])
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget_s or n >= 400:
+                break
+        runs.append({"threads": threads, "calls": n, "ms_per_step": 1e3 * el / n, "samples_per_s": N * n / el})
+    best = max(runs, key=lambda r: r["samples_per_s"])
+    return {"value": best["samples_per_s"], "unit": "samples/s", "cores": best["threads"], "kind": "port",
+            "ms_per_step": best["ms_per_step"], "runs": runs, "host_cpus": os.cpu_count(),
             "sample": "%d fwd+bwd calls of the %s batch (N=%d) through oracle/torch_fallback.py "
                       "(restatement of ms_deform_attn_core_pytorch, fp32, %d intra-op threads)"
-                      % (n, workload, N, cores)}
+                      % (best["calls"], workload, N, best["threads"])}
 
 
 def event_time_ms(fn, iters, stream):
@@ -216,7 +229,7 @@ def main():
                        "step": "MSDeformAttnFunction.apply forward + backward (3 grads)",
                        "launch": "hipGraph replay" if graph is not None else "eager autograd",
                        "sharding": "batch-sharded, no collective"},
-            "roofline": {"bound": "hbm", "kernel": "backward (memset + bwd_d32_kernel)",
+            "roofline": {"bound": "hbm", "kernel": "backward (bwd_value_d32_kernel + bwd_query_d32_kernel)",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": None, "algorithmic_bytes": bwd_b, "ms": kt["bwd"]},
             "kernels": {"fwd": {"ms": kt["fwd"], "algorithmic_bytes": fwd_b,

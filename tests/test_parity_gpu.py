@@ -301,15 +301,17 @@ def test_full_size_properties(native, name):
     inner = l.detach().clamp(0.2, 0.8)
     o = MSDeformAttnFunction.apply(ones, s, i, inner, a.detach(), 64)
     assert rel_err(o.cpu().numpy(), np.ones(o.shape, np.float32)) < 1e-5
-    # directional derivative along a random location perturbation vs finite differences (fp64 sums)
-    g = torch.Generator().manual_seed(1)
-    dl = (torch.rand(l.shape, generator=g) - 0.5).cuda()
-    eps = 1e-3
+    # directional derivative vs central differences, along the direction sign(grad) so that the
+    # analytic value is a sum of magnitudes (no cancellation).  The op is piecewise bilinear in the
+    # location: a point within eps*W pixels of a pixel centre crosses a kink and contributes an O(1)
+    # relative error, i.e. a few percent of the points on the 48-pixel level at eps = 1e-4.
+    dl = 0.5 * torch.sign(l.grad)
+    eps = 1e-4
     fp = (MSDeformAttnFunction.apply(v.detach(), s, i, l.detach() + eps * dl, a.detach(), 64).double() * go).sum()
     fm = (MSDeformAttnFunction.apply(v.detach(), s, i, l.detach() - eps * dl, a.detach(), 64).double() * go).sum()
     num = ((fp - fm) / (2 * eps)).item()
     ana = (l.grad.double() * dl.double()).sum().item()
-    assert abs(num - ana) < 2e-2 * abs(ana) + 1e-6        # kinks at pixel centres make this O(eps)
+    assert ana > 0 and abs(num - ana) < 5e-2 * ana
 
 
 def test_full_size_vs_oracle_subsample(native, oracle):
