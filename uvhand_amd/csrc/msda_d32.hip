@@ -26,12 +26,26 @@
 
 namespace msda {
 
+// Diagnostic build only (tools/micro/kbench.cpp, -DMSDA_STAMPS): per-workgroup phase timestamps
+// (100 MHz s_memrealtime) into a side buffer that no kernel reads.  The shipped library is built
+// without it and executes no stamp.
+#ifdef MSDA_STAMPS
+__device__ unsigned long long *msda_stamp_buf = nullptr;              // [blocks][8]
+#define MSDA_STAMP_AT(region, i)                                                                   \
+    do { if (threadIdx.x == 0 && msda_stamp_buf)                                                   \
+             msda_stamp_buf[((size_t)(region) * 65536 + (blockIdx.x & 65535)) * 8 + (i)] =         \
+                 __builtin_amdgcn_s_memrealtime(); } while (0)
+#define MSDA_STAMP(i) MSDA_STAMP_AT(0, i)
+#else
+#define MSDA_STAMP(i) do { } while (0)
+#define MSDA_STAMP_AT(region, i) do { } while (0)
+#endif
+
 constexpr int kD = 32;
 constexpr int kBlock = 256;
 constexpr int kRecBytes = 32;      // one tap record
 constexpr int kItemPad = 16;       // bytes: shifts consecutive items by one 16-B bank slot so the
                                    // 8 per-item broadcast reads of a wavefront do not collide
-constexpr int kLvBytes = kMaxLevels * 16;
 
 struct alignas(16) LevelInfo { int H, W, start, pad; };
 
@@ -54,6 +68,17 @@ __device__ __forceinline__ void tap_offsets(const PointGeom<float> &g, const Lev
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
+// Row load of a tap that may be absent (off < 0).  The load itself is unconditional — an absent
+// tap reads row 0 of the tensor, which is always mapped — and the result is discarded by a select,
+// so the compiler can keep a whole batch of row loads in flight (per-tap branches made it wait
+// for the memory system between taps) and an Inf/NaN in an unsampled row can never leak in.
+__device__ __forceinline__ float4 ld4_tap(const float *base, int off)
+{
+    const float4 v = ld4(base + (off >= 0 ? off : 0));
+    const bool ok = off >= 0;
+    return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+
 __device__ __forceinline__ void fma4(float4 &acc, float w, const float4 &v)
 {
     acc.x = fmaf(w, v.x, acc.x); acc.y = fmaf(w, v.y, acc.y);
@@ -64,13 +89,32 @@ __device__ __forceinline__ float dot4(const float4 &a, const float4 &b)
     return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)));
 }
 
-// Sum over the 8 lanes that share an item (lanes 8k..8k+7).
+// Sum over the 8 lanes that share an item (lanes 8k..8k+7), on the VALU's DPP path — no LDS
+// crossbar round trips: quad_perm [1,0,3,2], quad_perm [2,3,0,1], then row_half_mirror (lane j of
+// each 8-lane half-row reads lane 7-j, which by then holds the other quad's sum).
+template <int CTRL>
+__device__ __forceinline__ float dpp_read(float x)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false));
+}
 __device__ __forceinline__ float octlane_sum(float x)
 {
-    x += __shfl_xor(x, 1, kWave);
-    x += __shfl_xor(x, 2, kWave);
-    x += __shfl_xor(x, 4, kWave);
+    x += dpp_read<0xB1>(x);
+    x += dpp_read<0x4E>(x);
+    x += dpp_read<0x141>(x);
     return x;
+}
+
+// n / d for a divisor that is usually a power of two (shift >= 0), exact otherwise.
+__device__ __forceinline__ int fdiv(int n, int d, int shift) { return shift >= 0 ? (n >> shift) : n / d; }
+
+// (batch, head) of the il-th item after item0, from the uniform decomposition of item0:
+// b0 = item0 / (Lq*M), r0 = item0 % (Lq*M), m0 = item0 % M.
+__device__ __forceinline__ void item_bm(int il, int b0, int r0, int m0, int LqM, int M, int m_shift, int &b, int &m)
+{
+    const int t = r0 + il;
+    b = b0 + (t >= LqM ? t / LqM : 0);                     // a workgroup rarely straddles a batch boundary
+    m = m_shift >= 0 ? ((m0 + il) & (M - 1)) : (m0 + il) % M;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -80,40 +124,41 @@ template <int SPLIT>
 __global__ __launch_bounds__(kBlock) void fwd_d32_kernel(
     const float *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ level_start, const float *__restrict__ loc,
-    const float *__restrict__ attn, int S, int M, int L, int Lq, int P, int items,
-    float *__restrict__ out)
+    const float *__restrict__ attn, int S, int M, int L, int Lq, int P, int items, int p_shift,
+    int lp_shift, int m_shift, float *__restrict__ out)
 {
     constexpr int IPW = 32 / SPLIT;                       // items per workgroup
+    constexpr int OPW = 4 / SPLIT;                        // octets per workgroup
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    LevelInfo *lv = reinterpret_cast<LevelInfo *>(smem);
-    unsigned char *recs = smem + kLvBytes;
+    unsigned char *recs = smem;
     const int LP = L * P;
     const int item_stride = LP * kRecBytes + kItemPad;
     const int tid = threadIdx.x;
     const int item0 = blockIdx.x * IPW;
+    MSDA_STAMP_AT(2, 0);
+    const int LqM = Lq * M;
+    const int b0 = item0 / LqM, r0 = item0 - b0 * LqM, m0 = item0 % M;      // uniform (scalar unit)
 
-    if (tid < L) {
-        LevelInfo li;
-        li.H = (int)shapes[2 * tid]; li.W = (int)shapes[2 * tid + 1];
-        li.start = (int)level_start[tid]; li.pad = 0;
-        lv[tid] = li;
-    }
-    __syncthreads();
-
-    // ---- one lane per sampling point: loc/attn coalesced from HBM -> tap records in LDS ----
+    // ---- one lane per sampling point: loc/attn coalesced from HBM -> tap records in LDS.
+    // The level's (H, W, start) come straight from global memory (a handful of addresses, served by
+    // the L1/scalar caches) in the same batch of loads as loc/attn: no table stage, no extra barrier.
     for (int idx = tid; idx < IPW * LP; idx += kBlock) {
-        const int il = idx / LP, pt = idx - il * LP;
+        const int il = fdiv(idx, LP, lp_shift), pt = idx - il * LP;
         const int item = item0 + il;
         FwdRec r;
         r.off[0] = r.off[1] = r.off[2] = r.off[3] = -1;
         r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0.f;
         if (item < items) {
+            const int l = fdiv(pt, P, p_shift);
             const float2 xy = reinterpret_cast<const float2 *>(loc)[(long long)item0 * LP + idx];
             const float a = attn[(long long)item0 * LP + idx];
-            const LevelInfo li = lv[pt / P];
+            LevelInfo li;
+            li.H = (int)shapes[2 * l]; li.W = (int)shapes[2 * l + 1]; li.start = (int)level_start[l]; li.pad = 0;
             const PointGeom<float> g = point_geom<float>(xy.x, xy.y, li.H, li.W);
             if (g.inside) {
-                tap_offsets(g, li, item / (Lq * M), item % M, S, M, r.off);
+                int b, m;
+                item_bm(il, b0, r0, m0, LqM, M, m_shift, b, m);
+                tap_offsets(g, li, b, m, S, M, r.off);
                 const float hh = 1.f - g.lh, hw = 1.f - g.lw;
                 r.w[0] = hh * hw * a; r.w[1] = hh * g.lw * a;
                 r.w[2] = g.lh * hw * a; r.w[3] = g.lh * g.lw * a;
@@ -122,37 +167,41 @@ __global__ __launch_bounds__(kBlock) void fwd_d32_kernel(
         *reinterpret_cast<FwdRec *>(recs + il * item_stride + pt * kRecBytes) = r;
     }
     __syncthreads();
+    MSDA_STAMP_AT(2, 1);
 
     // ---- gather: 8 lanes x float4 per item, 8 items per wavefront ----
     const int wave = tid >> 6, lane = tid & 63, grp = lane >> 3, j = lane & 7;
-    const int il = (SPLIT == 1 ? wave * 8 : 0) + grp;
+    const int il = (wave / SPLIT) * 8 + grp;
     const unsigned char *rb = recs + il * item_stride;
     const float *vb = value + j * 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 4
-    for (int p = (SPLIT == 1 ? 0 : wave); p < LP; p += SPLIT) {
+    for (int p = wave % SPLIT; p < LP; p += SPLIT) {
         const int4 off = *reinterpret_cast<const int4 *>(rb + p * kRecBytes);
         const float4 w = *reinterpret_cast<const float4 *>(rb + p * kRecBytes + 16);
-        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0, v2 = v0, v3 = v0;
-        if (off.x >= 0) v0 = ld4(vb + off.x);
-        if (off.y >= 0) v1 = ld4(vb + off.y);
-        if (off.z >= 0) v2 = ld4(vb + off.z);
-        if (off.w >= 0) v3 = ld4(vb + off.w);
+        const float4 v0 = ld4_tap(vb, off.x), v1 = ld4_tap(vb, off.y), v2 = ld4_tap(vb, off.z), v3 = ld4_tap(vb, off.w);
         fma4(acc, w.x, v0); fma4(acc, w.y, v1); fma4(acc, w.z, v2); fma4(acc, w.w, v3);
     }
+    MSDA_STAMP_AT(2, 2);
 
     if (SPLIT == 1) {
         if (item0 + il < items)
             *reinterpret_cast<float4 *>(out + (long long)(item0 + il) * kD + j * 4) = acc;
     } else {
-        // the 4 wavefronts hold partial sums of the same octet: combine through LDS in a
-        // fixed order, then one coalesced 1-KiB store.
+        // the SPLIT wavefronts of an octet hold partial sums: combine through LDS in a fixed
+        // order, then coalesced 1-KiB stores.
         float *red = reinterpret_cast<float *>(recs + IPW * item_stride);
         reinterpret_cast<float4 *>(red)[wave * 64 + lane] = acc;
         __syncthreads();
-        const float s = ((red[tid] + red[256 + tid]) + red[512 + tid]) + red[768 + tid];
-        if (item0 + (tid >> 5) < items) out[(long long)item0 * kD + tid] = s;
+        for (int o = tid; o < OPW * 256; o += kBlock) {
+            const int oct = o >> 8, f = o & 255;
+            float sum = red[(oct * SPLIT) * 256 + f];
+#pragma unroll
+            for (int k = 1; k < SPLIT; ++k) sum += red[(oct * SPLIT + k) * 256 + f];
+            if (item0 + (o >> 5) < items) out[(long long)item0 * kD + o] = sum;
+        }
     }
+    MSDA_STAMP_AT(2, 3);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -163,101 +212,126 @@ __global__ __launch_bounds__(kBlock) void fwd_d32_kernel(
 // ATOMIC = true additionally scatters grad_value with global float atomics (the v1 scheme, kept
 // for A/B measurements: MSDA_BWD_MODE=atomic); the default leaves grad_value to role B.
 // ------------------------------------------------------------------------------------------
-template <int SPLIT, bool ATOMIC>
-__global__ __launch_bounds__(kBlock) void bwd_query_d32_kernel(
+template <int SPLIT, bool ATOMIC, int THREADS>
+__device__ __forceinline__ void bwd_query_body(
     const float *__restrict__ grad_out, const float *__restrict__ value,
     const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
     const float *__restrict__ loc, const float *__restrict__ attn, int S, int M, int L, int Lq,
-    int P, int items, float *__restrict__ grad_value, float *__restrict__ grad_loc,
-    float *__restrict__ grad_attn)
+    int P, int items, int p_shift, int lp_shift, int m_shift, float *__restrict__ grad_value,
+    float *__restrict__ grad_loc, float *__restrict__ grad_attn, int block, unsigned char *smem)
 {
-    constexpr int IPW = 32 / SPLIT;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    LevelInfo *lv = reinterpret_cast<LevelInfo *>(smem);
-    unsigned char *recs = smem + kLvBytes;
+    constexpr int IPW = (THREADS / kWave) * 8 / SPLIT;      // items per workgroup
+    unsigned char *recs = smem;
     const int LP = L * P;
     const int item_stride = LP * kRecBytes + kItemPad;
     float4 *res = reinterpret_cast<float4 *>(recs + IPW * item_stride);   // [IPW*LP] (gx, gy, ga, -)
     const int tid = threadIdx.x;
-    const int item0 = blockIdx.x * IPW;
+    const int item0 = block * IPW;
+    MSDA_STAMP_AT(1, 0);
+    const int LqM = Lq * M;
+    const int b0 = item0 / LqM, r0 = item0 - b0 * LqM, m0 = item0 % M;      // uniform (scalar unit)
 
-    if (tid < L) {
-        LevelInfo li;
-        li.H = (int)shapes[2 * tid]; li.W = (int)shapes[2 * tid + 1];
-        li.start = (int)level_start[tid]; li.pad = 0;
-        lv[tid] = li;
-    }
-    __syncthreads();
-
-    for (int idx = tid; idx < IPW * LP; idx += kBlock) {
-        const int il = idx / LP, pt = idx - il * LP;
+    for (int idx = tid; idx < IPW * LP; idx += THREADS) {
+        const int il = fdiv(idx, LP, lp_shift), pt = idx - il * LP;
         const int item = item0 + il;
         BwdRec r;
         r.off[0] = r.off[1] = r.off[2] = r.off[3] = -1;
         r.lh = r.lw = r.a = r.pad = 0.f;
         if (item < items) {
+            const int l = fdiv(pt, P, p_shift);
             const float2 xy = reinterpret_cast<const float2 *>(loc)[(long long)item0 * LP + idx];
-            const LevelInfo li = lv[pt / P];
+            const float a = attn[(long long)item0 * LP + idx];
+            LevelInfo li;
+            li.H = (int)shapes[2 * l]; li.W = (int)shapes[2 * l + 1]; li.start = (int)level_start[l]; li.pad = 0;
             const PointGeom<float> g = point_geom<float>(xy.x, xy.y, li.H, li.W);
             if (g.inside) {
-                tap_offsets(g, li, item / (Lq * M), item % M, S, M, r.off);
-                r.lh = g.lh; r.lw = g.lw;
-                r.a = attn[(long long)item0 * LP + idx];
+                int b, m;
+                item_bm(il, b0, r0, m0, LqM, M, m_shift, b, m);
+                tap_offsets(g, li, b, m, S, M, r.off);
+                r.lh = g.lh; r.lw = g.lw; r.a = a;
             }
         }
         *reinterpret_cast<BwdRec *>(recs + il * item_stride + pt * kRecBytes) = r;
     }
-    __syncthreads();
 
     const int wave = tid >> 6, lane = tid & 63, grp = lane >> 3, j = lane & 7;
-    const int il = (SPLIT == 1 ? wave * 8 : 0) + grp;
+    const int il = (wave / SPLIT) * 8 + grp;
     const unsigned char *rb = recs + il * item_stride;
     const float *vb = value + j * 4;
     float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (item0 + il < items) g4 = ld4(grad_out + (long long)(item0 + il) * kD + j * 4);
+    __syncthreads();
+    MSDA_STAMP_AT(1, 1);
 
-#pragma unroll 4
-    for (int p = (SPLIT == 1 ? 0 : wave); p < LP; p += SPLIT) {
-        const int4 off = *reinterpret_cast<const int4 *>(rb + p * kRecBytes);
-        const float4 f = *reinterpret_cast<const float4 *>(rb + p * kRecBytes + 16);   // lh lw a -
-        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0, v2 = v0, v3 = v0;
-        if (off.x >= 0) v0 = ld4(vb + off.x);
-        if (off.y >= 0) v1 = ld4(vb + off.y);
-        if (off.z >= 0) v2 = ld4(vb + off.z);
-        if (off.w >= 0) v3 = ld4(vb + off.w);
-        const float lh = f.x, lw = f.y, a = f.z, hh = 1.f - lh, hw = 1.f - lw;
-        const float k1 = hh * hw, k2 = hh * lw, k3 = lh * hw, k4 = lh * lw;
-        if (ATOMIC) {
-            float *gvb = grad_value + j * 4;
-            if (off.x >= 0) { const float c = k1 * a; float *d = gvb + off.x;
-                atomicAdd(d, c * g4.x); atomicAdd(d + 1, c * g4.y); atomicAdd(d + 2, c * g4.z); atomicAdd(d + 3, c * g4.w); }
-            if (off.y >= 0) { const float c = k2 * a; float *d = gvb + off.y;
-                atomicAdd(d, c * g4.x); atomicAdd(d + 1, c * g4.y); atomicAdd(d + 2, c * g4.z); atomicAdd(d + 3, c * g4.w); }
-            if (off.z >= 0) { const float c = k3 * a; float *d = gvb + off.z;
-                atomicAdd(d, c * g4.x); atomicAdd(d + 1, c * g4.y); atomicAdd(d + 2, c * g4.z); atomicAdd(d + 3, c * g4.w); }
-            if (off.w >= 0) { const float c = k4 * a; float *d = gvb + off.w;
-                atomicAdd(d, c * g4.x); atomicAdd(d + 1, c * g4.y); atomicAdd(d + 2, c * g4.z); atomicAdd(d + 3, c * g4.w); }
+    // 4 points per trip: all records, then all 16 row loads, then the arithmetic — so that one
+    // memory round trip covers the trip instead of one per point.
+    for (int p0 = wave % SPLIT; p0 < LP; p0 += 4 * SPLIT) {
+        int4 off[4]; float4 f[4]; float4 v[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = p0 + u * SPLIT;
+            off[u] = make_int4(-1, -1, -1, -1); f[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p < LP) {
+                off[u] = *reinterpret_cast<const int4 *>(rb + p * kRecBytes);
+                f[u] = *reinterpret_cast<const float4 *>(rb + p * kRecBytes + 16);   // lh lw a -
+            }
         }
-        const float d1 = dot4(g4, v0), d2 = dot4(g4, v1), d3 = dot4(g4, v2), d4 = dot4(g4, v3);
-        float s_a = k1 * d1 + k2 * d2 + k3 * d3 + k4 * d4;
-        float s_x = a * (hh * (d2 - d1) + lh * (d4 - d3));
-        float s_y = a * (hw * (d3 - d1) + lw * (d4 - d2));
-        s_a = octlane_sum(s_a); s_x = octlane_sum(s_x); s_y = octlane_sum(s_y);
-        if (j == 0) res[il * LP + p] = make_float4(s_x, s_y, s_a, 0.f);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            v[u][0] = ld4_tap(vb, off[u].x); v[u][1] = ld4_tap(vb, off[u].y);
+            v[u][2] = ld4_tap(vb, off[u].z); v[u][3] = ld4_tap(vb, off[u].w);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = p0 + u * SPLIT;
+            const float lh = f[u].x, lw = f[u].y, a = f[u].z, hh = 1.f - lh, hw = 1.f - lw;
+            const float k1 = hh * hw, k2 = hh * lw, k3 = lh * hw, k4 = lh * lw;
+            if (ATOMIC) {
+                float *gvb = grad_value + j * 4;
+                const int o4[4] = {off[u].x, off[u].y, off[u].z, off[u].w};
+                const float k[4] = {k1, k2, k3, k4};
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (o4[t] >= 0) { const float c = k[t] * a; float *d = gvb + o4[t];
+                        atomicAdd(d, c * g4.x); atomicAdd(d + 1, c * g4.y); atomicAdd(d + 2, c * g4.z); atomicAdd(d + 3, c * g4.w); }
+            }
+            const float d1 = dot4(g4, v[u][0]), d2 = dot4(g4, v[u][1]), d3 = dot4(g4, v[u][2]), d4 = dot4(g4, v[u][3]);
+            float s_a = k1 * d1 + k2 * d2 + k3 * d3 + k4 * d4;
+            float s_x = a * (hh * (d2 - d1) + lh * (d4 - d3));
+            float s_y = a * (hw * (d3 - d1) + lw * (d4 - d2));
+            s_a = octlane_sum(s_a); s_x = octlane_sum(s_x); s_y = octlane_sum(s_y);
+            if (j == 0 && p < LP) res[il * LP + p] = make_float4(s_x, s_y, s_a, 0.f);
+        }
     }
     __syncthreads();
+    MSDA_STAMP_AT(1, 2);
 
     // ---- coalesced write-out of grad_sampling_loc / grad_attn_weight for the workgroup's items ----
-    for (int idx = tid; idx < IPW * LP; idx += kBlock) {
-        const int il2 = idx / LP, pt = idx - il2 * LP;
+    for (int idx = tid; idx < IPW * LP; idx += THREADS) {
+        const int il2 = fdiv(idx, LP, lp_shift), pt = idx - il2 * LP;
         if (item0 + il2 < items) {
-            const LevelInfo li = lv[pt / P];
+            const int l = fdiv(pt, P, p_shift);
             const float4 r = res[idx];
             reinterpret_cast<float2 *>(grad_loc)[(long long)item0 * LP + idx] =
-                make_float2(r.x * (float)li.W, r.y * (float)li.H);
+                make_float2(r.x * (float)(int)shapes[2 * l + 1], r.y * (float)(int)shapes[2 * l]);
             grad_attn[(long long)item0 * LP + idx] = r.z;
         }
     }
+    MSDA_STAMP_AT(1, 3);
+}
+
+template <int SPLIT, bool ATOMIC>
+__global__ __launch_bounds__(kBlock) void bwd_query_d32_kernel(
+    const float *__restrict__ grad_out, const float *__restrict__ value,
+    const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
+    const float *__restrict__ loc, const float *__restrict__ attn, int S, int M, int L, int Lq,
+    int P, int items, int p_shift, int lp_shift, int m_shift, float *__restrict__ grad_value,
+    float *__restrict__ grad_loc, float *__restrict__ grad_attn)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bwd_query_body<SPLIT, ATOMIC, kBlock>(grad_out, value, shapes, level_start, loc, attn, S, M, L, Lq, P, items,
+                                          p_shift, lp_shift, m_shift, grad_value, grad_loc, grad_attn,
+                                          (int)blockIdx.x, smem);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -293,26 +367,13 @@ constexpr int kSBlock = 512;
 constexpr int kSWaves = kSBlock / kWave;
 struct alignas(8) SRec { float w; int q; };
 
-struct TapSet { int dest[4]; float w[4]; };      // dest < 0: tap not in this workgroup's range
+// role-B sizing: single pass while 4*Lq*P records (8 B) fit beside the histogram in 64 KB of LDS
+constexpr int kSinglePPT = 3;               // points per thread: 3*512 = 1536 points, 48 KB of records
+constexpr int kSingleMaxPoints = kSinglePPT * 512;
+constexpr int kSingleMaxRows = 1920;        // 15 KB of histogram + prefix
+constexpr int kMultiRows = 256;             // 32 KB LDS tile
+constexpr int kMultiPPT = 6;                // 3072 points per pass, 96 KB of records
 
-__device__ __forceinline__ bool point_taps(const float *__restrict__ loc, const float *__restrict__ attn,
-                                           long long pi, int H, int Wd, int px0, int npx, TapSet &t)
-{
-    const float2 xy = reinterpret_cast<const float2 *>(loc)[pi];
-    const PointGeom<float> g = point_geom<float>(xy.x, xy.y, H, Wd);
-    if (!g.inside) return false;
-    const int pix = g.h0 * Wd + g.w0 - px0;                  // range-local index of tap (h0, w0)
-    const int p01 = pix + 1, p10 = pix + Wd, p11 = pix + Wd + 1;
-    t.dest[0] = (g.ok00 && pix >= 0 && pix < npx) ? pix : -1;
-    t.dest[1] = (g.ok01 && p01 >= 0 && p01 < npx) ? p01 : -1;
-    t.dest[2] = (g.ok10 && p10 >= 0 && p10 < npx) ? p10 : -1;
-    t.dest[3] = (g.ok11 && p11 >= 0 && p11 < npx) ? p11 : -1;
-    if ((t.dest[0] & t.dest[1] & t.dest[2] & t.dest[3]) < 0) return false;   // all four are -1
-    const float a = attn[pi];
-    const float hh = 1.f - g.lh, hw = 1.f - g.lw;
-    t.w[0] = hh * hw * a; t.w[1] = hh * g.lw * a; t.w[2] = g.lh * hw * a; t.w[3] = g.lh * g.lw * a;
-    return true;
-}
 
 __device__ __forceinline__ float4 shfl_xor4(const float4 &v, int m)
 {
@@ -321,7 +382,9 @@ __device__ __forceinline__ float4 shfl_xor4(const float4 &v, int m)
 }
 __device__ __forceinline__ void add4(float4 &a, const float4 &b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
 
-// Step 4.  SLOTS lanes-groups of 8 lanes share one row's segment; 8/SLOTS rows per wavefront pass.
+// Step 4.  SLOTS lane-groups of 8 lanes share one row's segment; 8/SLOTS rows per wavefront trip.
+// A lane group takes its records four at a time: 4 record reads, then 4 independent 128-B row
+// loads in flight, then the FMAs — one memory round trip per 4*SLOTS records of a row.
 template <int SLOTS, bool MULTIPASS>
 __device__ __forceinline__ void gather_rows(const float *__restrict__ go_base, float *__restrict__ gv_base,
                                             const int *cnt, const int *start, const SRec *rec, float *tile,
@@ -330,84 +393,109 @@ __device__ __forceinline__ void gather_rows(const float *__restrict__ go_base, f
     constexpr int DPW = 8 / SLOTS;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int dsub = lane / (SLOTS * 8), slot = (lane >> 3) % SLOTS, j = lane & 7;
-    for (int d0 = wave * DPW; d0 < npx; d0 += kSWaves * DPW) {
-        const int d = d0 + dsub;
-        float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
-        if (d < npx) {
-            const int n = cnt[d];
-            const SRec *r = rec + start[d];
-            int i = slot;
-            for (; i + SLOTS < n; i += 2 * SLOTS) {                 // two records in flight per lane
-                const SRec r0 = r[i], r1 = r[i + SLOTS];
-                const float4 g0 = ld4(go_base + (long long)r0.q * row_stride);
-                const float4 g1 = ld4(go_base + (long long)r1.q * row_stride);
-                fma4(acc0, r0.w, g0); fma4(acc1, r1.w, g1);
+    for (int d = wave * DPW + dsub; d < npx; d += kSWaves * DPW) {
+        const int n = cnt[d];
+        const SRec *r = rec + start[d];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i0 = slot; i0 < n; i0 += 4 * SLOTS) {
+            SRec rr[4]; float4 g[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { rr[u].w = 0.f; rr[u].q = -1; if (i0 + u * SLOTS < n) rr[u] = r[i0 + u * SLOTS]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 t = ld4(go_base + (long long)(rr[u].q >= 0 ? rr[u].q : 0) * row_stride);
+                const bool ok = rr[u].q >= 0;
+                g[u] = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
             }
-            if (i < n) {
-                const SRec r0 = r[i];
-                fma4(acc0, r0.w, ld4(go_base + (long long)r0.q * row_stride));
-            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) fma4(acc, rr[u].w, g[u]);
         }
-        add4(acc0, acc1);
-        if (SLOTS >= 2) add4(acc0, shfl_xor4(acc0, 8));
-        if (SLOTS >= 4) add4(acc0, shfl_xor4(acc0, 16));
-        if (SLOTS >= 8) add4(acc0, shfl_xor4(acc0, 32));
-        if (d < npx && slot == 0) {
+        if (SLOTS >= 2) add4(acc, shfl_xor4(acc, 8));
+        if (SLOTS >= 4) add4(acc, shfl_xor4(acc, 16));
+        if (SLOTS >= 8) add4(acc, shfl_xor4(acc, 32));
+        if (slot == 0) {
             if (MULTIPASS) {
                 float4 *t = reinterpret_cast<float4 *>(tile) + d * 8 + j;   // same lane owns it in every pass
-                if (first_pass) *t = acc0; else { float4 o = *t; add4(o, acc0); *t = o; }
+                if (first_pass) *t = acc; else { float4 o = *t; add4(o, acc); *t = o; }
             } else {
-                *reinterpret_cast<float4 *>(gv_base + (long long)d * row_stride) = acc0;
+                *reinterpret_cast<float4 *>(gv_base + (long long)d * row_stride) = acc;
             }
         }
     }
 }
 
-template <bool MULTIPASS>
-__global__ __launch_bounds__(kSBlock) void bwd_value_d32_kernel(
+// PPT = sampling points per thread per pass: all of a thread's points are loaded up front (2*PPT
+// independent global loads in flight), their taps and histogram ranks stay in registers between
+// step 1 and step 3, so loc / attn are read exactly once and step 3 needs no atomics.
+template <bool MULTIPASS, int PPT>
+__device__ __forceinline__ void bwd_value_body(
     const float *__restrict__ grad_out, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ level_start, const float *__restrict__ loc,
-    const float *__restrict__ attn, int S, int M, int L, int Lq, int P, int W, int tp_cap,
-    int np_chunk, float *__restrict__ grad_value)
+    const float *__restrict__ attn, int S, int M, int L, int Lq, int P, int p_shift, int tp_cap,
+    float *__restrict__ grad_value, int ti, int W, int l, int pr, unsigned char *smem)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // LDS: [tile: tp_cap*32 floats if MULTIPASS] [cnt tp_cap] [start tp_cap] [cursor tp_cap] [wsum 16] [rec ...]
+    constexpr int NPC = PPT * kSBlock;                       // points per pass
+    // LDS: [tile: tp_cap*32 floats if MULTIPASS] [cnt tp_cap] [start tp_cap] [wsum 16] [rec 4*NPC]
     float *tile = reinterpret_cast<float *>(smem);
     int *cnt = reinterpret_cast<int *>(smem + (MULTIPASS ? (size_t)tp_cap * kD * 4 : 0));
     int *start = cnt + tp_cap;
-    int *cursor = start + tp_cap;
-    int *wsum = cursor + tp_cap;
+    int *wsum = start + tp_cap;
     SRec *rec = reinterpret_cast<SRec *>(wsum + 16);
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int bid = blockIdx.x;
-    const int ti = bid % W, l = (bid / W) % L, pr = bid / (W * L);          // uniform -> scalar loads below
+    MSDA_STAMP(0);
+    // (ti of W ranges, level l, pair pr = b*M + m): all uniform, scalar unit; 32-bit on purpose (the
+    // host checks S*W < 2^31).
     const int H = (int)shapes[2 * l], Wd = (int)shapes[2 * l + 1], lstart = (int)level_start[l];
     const int HW = H * Wd;
-    const int px0 = (int)((long long)ti * HW / W), px1 = (int)((long long)(ti + 1) * HW / W);
+    const int px0 = (int)((unsigned)(ti * HW) / (unsigned)W), px1 = (int)((unsigned)((ti + 1) * HW) / (unsigned)W);
     const int npx = px1 - px0;
     if (npx <= 0 || npx > tp_cap) return;                                    // empty range (uniform)
-    const int b = pr / M, m = pr % M;
+    const int b = pr / M, m = pr - b * M;
     const int NP = Lq * P;
     const long long item_base = (long long)b * Lq * M + m;                   // item(q) = item_base + q*M
     const int row_stride = M * kD;
     const float *go_base = grad_out + item_base * kD + (lane & 7) * 4;
     float *gv_base = grad_value + ((long long)(b * S + lstart + px0) * M + m) * kD + (lane & 7) * 4;
 
-    for (int c0 = 0; c0 < NP; c0 += np_chunk) {
-        const int c1 = min(NP, c0 + np_chunk);
-        for (int i = tid; i < npx; i += kSBlock) cnt[i] = 0;
-        __syncthreads();
-        // ---- 1. histogram of taps per row ----
-        for (int idx = c0 + tid; idx < c1; idx += kSBlock) {
-            const int q = idx / P, p = idx - q * P;
-            TapSet t;
-            if (point_taps(loc, attn, ((item_base + (long long)q * M) * L + l) * P + p, H, Wd, px0, npx, t)) {
+    for (int c0 = 0; c0 < NP; c0 += NPC) {
+        // ---- loads of this pass's points first: they overlap the histogram reset ----
+        float2 xy[PPT]; float at[PPT]; int qq[PPT];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) if (t.dest[k] >= 0) atomicAdd(&cnt[t.dest[k]], 1);
+        for (int k = 0; k < PPT; ++k) {
+            const int idx = c0 + tid + k * kSBlock;
+            qq[k] = -1; xy[k] = make_float2(-8.f, -8.f); at[k] = 0.f;
+            if (idx < NP) {
+                const int q = fdiv(idx, P, p_shift), p = idx - q * P;
+                const long long pi = ((item_base + (long long)q * M) * L + l) * P + p;
+                xy[k] = reinterpret_cast<const float2 *>(loc)[pi];
+                at[k] = attn[pi];
+                qq[k] = q;
             }
         }
+        for (int i = tid; i < npx; i += kSBlock) cnt[i] = 0;
         __syncthreads();
+        MSDA_STAMP(1);
+        // ---- 1. taps of each point; histogram rank of each tap on its row ----
+        int dest[PPT][4], rank[PPT][4]; float tw[PPT][4];
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const PointGeom<float> g = point_geom<float>(xy[k].x, xy[k].y, H, Wd);
+            const int pix = g.h0 * Wd + g.w0 - px0;                          // range-local index of tap (h0, w0)
+            const int p01 = pix + 1, p10 = pix + Wd, p11 = pix + Wd + 1;
+            const bool live = g.inside && qq[k] >= 0;
+            dest[k][0] = (live && g.ok00 && pix >= 0 && pix < npx) ? pix : -1;
+            dest[k][1] = (live && g.ok01 && p01 >= 0 && p01 < npx) ? p01 : -1;
+            dest[k][2] = (live && g.ok10 && p10 >= 0 && p10 < npx) ? p10 : -1;
+            dest[k][3] = (live && g.ok11 && p11 >= 0 && p11 < npx) ? p11 : -1;
+            const float hh = 1.f - g.lh, hw = 1.f - g.lw;
+            tw[k][0] = hh * hw * at[k]; tw[k][1] = hh * g.lw * at[k];
+            tw[k][2] = g.lh * hw * at[k]; tw[k][3] = g.lh * g.lw * at[k];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { rank[k][t] = 0; if (dest[k][t] >= 0) rank[k][t] = atomicAdd(&cnt[dest[k][t]], 1); }
+        }
+        __syncthreads();
+        MSDA_STAMP(2);
         // ---- 2. exclusive prefix sum over the rows (512 threads x CH consecutive rows) ----
         const int CH = (npx + kSBlock - 1) / kSBlock;
         const int r0 = tid * CH;
@@ -419,30 +507,32 @@ __global__ __launch_bounds__(kSBlock) void bwd_value_d32_kernel(
         if (lane == kWave - 1) wsum[wave] = incl;
         __syncthreads();
         int excl = incl - mine, total = 0;
-        for (int w2 = 0; w2 < kSWaves; ++w2) { const int v = wsum[w2]; if (w2 < wave) excl += v; total += v; }
-        for (int k = 0; k < CH; ++k) if (r0 + k < npx) { const int c = cnt[r0 + k]; start[r0 + k] = excl; cursor[r0 + k] = excl; excl += c; }
-        __syncthreads();
-        // ---- 3. counting sort: records into their row's segment ----
-        for (int idx = c0 + tid; idx < c1; idx += kSBlock) {
-            const int q = idx / P, p = idx - q * P;
-            TapSet t;
-            if (point_taps(loc, attn, ((item_base + (long long)q * M) * L + l) * P + p, H, Wd, px0, npx, t)) {
+        {
+            const int4 wa = *reinterpret_cast<const int4 *>(wsum), wb = *reinterpret_cast<const int4 *>(wsum + 4);
+            const int ws[kSWaves] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
 #pragma unroll
-                for (int k = 0; k < 4; ++k) if (t.dest[k] >= 0) {
-                    SRec r; r.w = t.w[k]; r.q = q;
-                    rec[atomicAdd(&cursor[t.dest[k]], 1)] = r;
-                }
-            }
+            for (int w2 = 0; w2 < kSWaves; ++w2) { if (w2 < wave) excl += ws[w2]; total += ws[w2]; }
         }
+        for (int k = 0; k < CH; ++k) if (r0 + k < npx) { start[r0 + k] = excl; excl += cnt[r0 + k]; }
         __syncthreads();
+        MSDA_STAMP(3);
+        // ---- 3. counting sort: each tap's record goes to start[row] + rank ----
+#pragma unroll
+        for (int k = 0; k < PPT; ++k)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (dest[k][t] >= 0) { SRec r; r.w = tw[k][t]; r.q = qq[k]; rec[start[dest[k][t]] + rank[k][t]] = r; }
+        __syncthreads();
+        MSDA_STAMP(4);
         // ---- 4. gather; lanes per row chosen from the mean segment length (uniform) ----
         const int mean2 = (2 * total) / npx;                                  // 2 x mean records per row
         const bool first = (c0 == 0);
-        if (mean2 <= 3)       gather_rows<1, MULTIPASS>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
-        else if (mean2 <= 7)  gather_rows<2, MULTIPASS>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
-        else if (mean2 <= 15) gather_rows<4, MULTIPASS>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
+        if (mean2 <= 8)       gather_rows<1, MULTIPASS>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
+        else if (mean2 <= 16) gather_rows<2, MULTIPASS>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
+        else if (mean2 <= 32) gather_rows<4, MULTIPASS>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
         else                  gather_rows<8, MULTIPASS>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
-        __syncthreads();
+        if (MULTIPASS) __syncthreads();
+        MSDA_STAMP(5);
     }
 
     if (MULTIPASS) {
@@ -455,6 +545,44 @@ __global__ __launch_bounds__(kSBlock) void bwd_value_d32_kernel(
     }
 }
 
+template <bool MULTIPASS, int PPT>
+__global__ __launch_bounds__(kSBlock) void bwd_value_d32_kernel(
+    const float *__restrict__ grad_out, const int64_t *__restrict__ shapes,
+    const int64_t *__restrict__ level_start, const float *__restrict__ loc,
+    const float *__restrict__ attn, int S, int M, int L, int Lq, int P, int p_shift, int tp_cap,
+    float *__restrict__ grad_value)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // grid = (W ranges, L levels, N*M pairs)
+    bwd_value_body<MULTIPASS, PPT>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, tp_cap,
+                                   grad_value, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y, (int)blockIdx.z, smem);
+}
+
+// One launch for the whole backward of a single-pass problem: the first nB workgroups are role B
+// (grad_value), the rest role A (grad_sampling_loc / grad_attn_weight).  The two roles share no
+// data, so this is plain concurrency inside one grid — it removes a dependent kernel boundary
+// (~1.5 us) and lets role A's short workgroups fill the CUs around role B's longer ones.
+template <int SPLIT>
+__global__ __launch_bounds__(kSBlock) void bwd_fused_d32_kernel(
+    const float *__restrict__ grad_out, const float *__restrict__ value,
+    const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
+    const float *__restrict__ loc, const float *__restrict__ attn, int S, int M, int L, int Lq,
+    int P, int items, int p_shift, int lp_shift, int m_shift, int tp_cap, int W, int nB,
+    float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attn)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int bid = (int)blockIdx.x;
+    if (bid < nB) {
+        const int ti = bid % W, l = (bid / W) % L, pr = bid / (W * L);
+        bwd_value_body<false, kSinglePPT>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, tp_cap,
+                                          grad_value, ti, W, l, pr, smem);
+    } else {
+        bwd_query_body<SPLIT, false, kSBlock>(grad_out, value, shapes, level_start, loc, attn, S, M, L, Lq, P, items,
+                                              p_shift, lp_shift, m_shift, grad_value, grad_loc, grad_attn,
+                                              bid - nB, smem);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
@@ -464,13 +592,29 @@ bool d32_supported(int N, int S, int M, int D, int L, int Lq, int P)
     const long long items = (long long)N * Lq * M;
     if ((long long)N * S * M * kD >= (1LL << 31)) return false;        // int32 element offsets
     if (items * L * P * 2 >= (1LL << 31) || items >= (1LL << 30)) return false;
+    if ((long long)N * M > 65535 || S > (1 << 19)) return false;       // role-B grid (W, L, N*M), 32-bit S*W
     return true;
 }
 
+static int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+static int pow2_shift(int x) { return (x > 0 && (x & (x - 1)) == 0) ? __builtin_ctz((unsigned)x) : -1; }
+
+// Wavefronts per octet (SPLIT).  Small problems are latency-bound: more wavefronts with fewer
+// points each keep more row loads in flight; large ones want no cross-wave reduction.
+// MSDA_SPLIT=1|2|4 overrides (tuning knob, read once).
 static int pick_split(int items, int LP)
 {
+    static const int forced = env_int("MSDA_SPLIT", 0);
+    if (forced == 1 || forced == 2 || forced == 4) return (LP >= forced) ? forced : 1;
     const int octets = (items + 7) / 8;
-    return (octets <= 4096 && LP >= 4) ? 4 : 1;
+    if (LP >= 4 && octets <= 2048) return 4;
+    if (LP >= 2 && octets <= 8192) return 2;
+    return 1;
 }
 
 int launch_fwd_d32(const float *value, const int64_t *shapes, const int64_t *level_start,
@@ -479,31 +623,23 @@ int launch_fwd_d32(const float *value, const int64_t *shapes, const int64_t *lev
 {
     const int items = N * Lq * M, LP = L * P;
     const int item_stride = LP * kRecBytes + kItemPad;
-    if (pick_split(items, LP) == 4) {
-        const size_t lds = kLvBytes + 8 * item_stride + 4096;
-        hipLaunchKernelGGL(fwd_d32_kernel<4>, dim3((items + 7) / 8), dim3(kBlock), lds, stream, value,
-                           shapes, level_start, loc, attn, S, M, L, Lq, P, items, out);
-    } else {
-        const size_t lds = kLvBytes + 32 * item_stride;
-        hipLaunchKernelGGL(fwd_d32_kernel<1>, dim3((items + 31) / 32), dim3(kBlock), lds, stream,
-                           value, shapes, level_start, loc, attn, S, M, L, Lq, P, items, out);
-    }
+    const int split = pick_split(items, LP);
+    const int ipw = 32 / split;
+    const size_t lds = (size_t)ipw * item_stride + (split > 1 ? 4096 : 0);
+    const dim3 grid((items + ipw - 1) / ipw), block(kBlock);
+    if (split == 4)
+        hipLaunchKernelGGL(fwd_d32_kernel<4>, grid, block, lds, stream, value, shapes, level_start, loc, attn,
+                           S, M, L, Lq, P, items, pow2_shift(P), pow2_shift(LP), pow2_shift(M), out);
+    else if (split == 2)
+        hipLaunchKernelGGL(fwd_d32_kernel<2>, grid, block, lds, stream, value, shapes, level_start, loc, attn,
+                           S, M, L, Lq, P, items, pow2_shift(P), pow2_shift(LP), pow2_shift(M), out);
+    else
+        hipLaunchKernelGGL(fwd_d32_kernel<1>, grid, block, lds, stream, value, shapes, level_start, loc, attn,
+                           S, M, L, Lq, P, items, pow2_shift(P), pow2_shift(LP), pow2_shift(M), out);
     return check_launch("msda forward (d32)");
 }
 
-// role-B sizing: single pass while 4*Lq*P records (8 B) fit beside the histogram in 64 KB of LDS
-constexpr int kSingleMaxPoints = 1536;      // 48 KB of records
-constexpr int kSingleMaxRows = 1280;        // 15 KB of histogram / prefix / cursor
-constexpr int kMultiRows = 256;             // 32 KB LDS tile
-constexpr int kMultiChunkPoints = 3072;     // 96 KB of records per pass
-
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
-
-static int env_int(const char *name, int dflt)
-{
-    const char *v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
-}
 
 int launch_bwd_d32(const float *grad_out, const float *value, const int64_t *shapes,
                    const int64_t *level_start, const float *loc, const float *attn, int N, int S,
@@ -513,9 +649,13 @@ int launch_bwd_d32(const float *grad_out, const float *value, const int64_t *sha
     const int items = N * Lq * M, LP = L * P;
     const int item_stride = LP * kRecBytes + kItemPad;
     // tuning / A-B knobs, read once per process: MSDA_BWD_MODE=atomic selects the v1 global-atomic
-    // scatter; MSDA_BWD_WGS the number of role-B workgroups to aim for on small problems.
-    static const bool atomic_mode = [] { const char *v = getenv("MSDA_BWD_MODE"); return v && !strcmp(v, "atomic"); }();
-    static const int target_wgs = [] { int v = env_int("MSDA_BWD_WGS", 512); return v < 1 ? 1 : v; }();
+    // scatter, =split launches role B and role A as two kernels; MSDA_BWD_WGS is the number of role-B
+    // workgroups to aim for on small problems.
+    static const int bwd_mode = [] {                       // 0 fused (default), 1 split launches, 2 v1 atomics
+        const char *v = getenv("MSDA_BWD_MODE");
+        return (v && !strcmp(v, "atomic")) ? 2 : (v && !strcmp(v, "split")) ? 1 : 0; }();
+    const bool atomic_mode = bwd_mode == 2;
+    static const int target_wgs = [] { int v = env_int("MSDA_BWD_WGS", 256); return v < 1 ? 1 : v; }();
     const int split = pick_split(items, LP);
 
     if (atomic_mode) {
@@ -526,57 +666,64 @@ int launch_bwd_d32(const float *grad_out, const float *value, const int64_t *sha
         const int NP = Lq * P;
         const bool multipass = NP > kSingleMaxPoints;
         const int pairs_levels = N * M * L;
-        int W, tp_cap, np_chunk;
+        int W, tp_cap;
         if (!multipass) {
             W = max(ceil_div(S, kSingleMaxRows), ceil_div(target_wgs, pairs_levels));
             W = max(1, min(W, max(1, S / 16)));
             tp_cap = ceil_div(S, W);
-            np_chunk = max(NP, 1);
         } else {
             tp_cap = kMultiRows;
             W = ceil_div(S, tp_cap);
-            np_chunk = kMultiChunkPoints;
         }
-        const long long blocks = (long long)pairs_levels * W;
-        if (blocks > 0x7fffffffLL) return set_error(MSDA_ERR_ARGUMENT, "msda backward: too many tiles");
-        const size_t lds = (multipass ? (size_t)tp_cap * kD * 4 : 0) + (3 * (size_t)tp_cap + 16) * 4 +
-                           (size_t)4 * np_chunk * sizeof(SRec);
+        tp_cap = (tp_cap + 3) & ~3;                                   // keeps the LDS arrays 16-B aligned
+        if ((long long)S * (W + 1) >= (1LL << 31) || W > 65535 || L > 65535 || (long long)N * M > 65535)
+            return set_error(MSDA_ERR_ARGUMENT, "msda backward (d32): geometry exceeds the tile grid limits");
+        const dim3 grid((unsigned)W, (unsigned)L, (unsigned)(N * M));
+        const size_t lds = (multipass ? (size_t)tp_cap * kD * 4 : 0) + (2 * (size_t)tp_cap + 16) * 4 +
+                           (size_t)4 * (multipass ? kMultiPPT : kSinglePPT) * kSBlock * sizeof(SRec);
+        if (!multipass && bwd_mode == 0) {
+            // ---- whole backward in one launch: nB role-B workgroups, then the role-A ones ----
+            const int ipw = 64 / split;                                 // 512-thread role-A workgroups
+            const size_t lds_a = (size_t)ipw * item_stride + (size_t)ipw * LP * 16;
+            const long long nB = (long long)W * pairs_levels, nA = (items + ipw - 1) / ipw;
+            if (nB + nA > 0x7fffffffLL) return set_error(MSDA_ERR_ARGUMENT, "msda backward (d32): grid too large");
+            const dim3 fgrid((unsigned)(nB + nA));
+            const size_t flds = lds > lds_a ? lds : lds_a;
+#define MSDA_LAUNCH_F(SP)                                                                              \
+            hipLaunchKernelGGL((bwd_fused_d32_kernel<SP>), fgrid, dim3(kSBlock), flds, stream, grad_out, value, shapes, \
+                               level_start, loc, attn, S, M, L, Lq, P, items, pow2_shift(P), pow2_shift(LP),   \
+                               pow2_shift(M), tp_cap, W, (int)nB, grad_value, grad_loc, grad_attn)
+            if (split == 4) MSDA_LAUNCH_F(4); else if (split == 2) MSDA_LAUNCH_F(2); else MSDA_LAUNCH_F(1);
+#undef MSDA_LAUNCH_F
+            return check_launch("msda backward (d32, fused)");
+        }
         if (multipass) {
             static thread_local size_t granted = 0;
             if (lds > granted) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bwd_value_d32_kernel<true>),
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bwd_value_d32_kernel<true, kMultiPPT>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (e != hipSuccess) return set_error(MSDA_ERR_LAUNCH, hipGetErrorString(e));
                 granted = lds;
             }
-            hipLaunchKernelGGL(bwd_value_d32_kernel<true>, dim3((unsigned)blocks), dim3(kSBlock), lds, stream,
-                               grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, W, tp_cap, np_chunk, grad_value);
+            hipLaunchKernelGGL((bwd_value_d32_kernel<true, kMultiPPT>), grid, dim3(kSBlock), lds, stream,
+                               grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, pow2_shift(P), tp_cap, grad_value);
         } else {
-            hipLaunchKernelGGL(bwd_value_d32_kernel<false>, dim3((unsigned)blocks), dim3(kSBlock), lds, stream,
-                               grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, W, tp_cap, np_chunk, grad_value);
+            hipLaunchKernelGGL((bwd_value_d32_kernel<false, kSinglePPT>), grid, dim3(kSBlock), lds, stream,
+                               grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, pow2_shift(P), tp_cap, grad_value);
         }
         if (int rc = check_launch("msda backward (d32, grad_value sort+gather)")) return rc;
     }
-    if (split == 4) {
-        const size_t lds = kLvBytes + 8 * item_stride + 8 * LP * 16;
-        if (atomic_mode)
-            hipLaunchKernelGGL((bwd_query_d32_kernel<4, true>), dim3((items + 7) / 8), dim3(kBlock), lds, stream,
-                               grad_out, value, shapes, level_start, loc, attn, S, M, L, Lq, P, items,
-                               grad_value, grad_loc, grad_attn);
-        else
-            hipLaunchKernelGGL((bwd_query_d32_kernel<4, false>), dim3((items + 7) / 8), dim3(kBlock), lds, stream,
-                               grad_out, value, shapes, level_start, loc, attn, S, M, L, Lq, P, items,
-                               grad_value, grad_loc, grad_attn);
-    } else {
-        const size_t lds = kLvBytes + 32 * item_stride + 32 * LP * 16;
-        if (atomic_mode)
-            hipLaunchKernelGGL((bwd_query_d32_kernel<1, true>), dim3((items + 31) / 32), dim3(kBlock), lds, stream,
-                               grad_out, value, shapes, level_start, loc, attn, S, M, L, Lq, P, items,
-                               grad_value, grad_loc, grad_attn);
-        else
-            hipLaunchKernelGGL((bwd_query_d32_kernel<1, false>), dim3((items + 31) / 32), dim3(kBlock), lds, stream,
-                               grad_out, value, shapes, level_start, loc, attn, S, M, L, Lq, P, items,
-                               grad_value, grad_loc, grad_attn);
+    {
+        const int ipw = 32 / split;
+        const size_t lds = (size_t)ipw * item_stride + (size_t)ipw * LP * 16;
+        const dim3 grid((items + ipw - 1) / ipw), block(kBlock);
+#define MSDA_LAUNCH_A(SP, AT)                                                                          \
+        hipLaunchKernelGGL((bwd_query_d32_kernel<SP, AT>), grid, block, lds, stream, grad_out, value, shapes, \
+                           level_start, loc, attn, S, M, L, Lq, P, items, pow2_shift(P), pow2_shift(LP), pow2_shift(M), \
+                           grad_value, grad_loc, grad_attn)
+        if (atomic_mode) { if (split == 4) MSDA_LAUNCH_A(4, true); else if (split == 2) MSDA_LAUNCH_A(2, true); else MSDA_LAUNCH_A(1, true); }
+        else             { if (split == 4) MSDA_LAUNCH_A(4, false); else if (split == 2) MSDA_LAUNCH_A(2, false); else MSDA_LAUNCH_A(1, false); }
+#undef MSDA_LAUNCH_A
     }
     return check_launch("msda backward (d32, query-major)");
 }
