@@ -103,6 +103,19 @@ def time_cpu_baseline(workload, budget_s=8.0):
                       % (best["calls"], workload, N, best["threads"])}
 
 
+def pmc_traffic(workload, which):
+    """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
+    collected in separate runs by tools/profile_gpu.sh, corrected as MI355X_MICROARCH.md prescribes:
+    KiB units, FETCH_SIZE doubled on gfx950).  The summary is committed under profiles/; None if the
+    workload has not been profiled."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)[workload][which]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def event_time_ms(fn, iters, stream):
     """Average duration of fn() over `iters` back-to-back calls, HIP events on `stream`."""
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -229,9 +242,10 @@ def main():
                        "step": "MSDeformAttnFunction.apply forward + backward (3 grads)",
                        "launch": "hipGraph replay" if graph is not None else "eager autograd",
                        "sharding": "batch-sharded, no collective"},
-            "roofline": {"bound": "hbm", "kernel": "backward (bwd_value_d32_kernel + bwd_query_d32_kernel)",
+            "roofline": {"bound": "hbm", "kernel": "backward: msda::bwd_fused_d32_kernel (grad_value sort+gather "
+                                                    "workgroups and grad_loc/grad_attn workgroups in one launch)",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes": bwd_b, "ms": kt["bwd"]},
+                         "traffic": pmc_traffic(args.workload, "bwd"), "algorithmic_bytes": bwd_b, "ms": kt["bwd"]},
             "kernels": {"fwd": {"ms": kt["fwd"], "algorithmic_bytes": fwd_b,
                                 "GBps": fwd_b / (kt["fwd"] * 1e-3) / 1e9},
                         "bwd": {"ms": kt["bwd"], "algorithmic_bytes": bwd_b, "GBps": ach}},
