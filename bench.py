@@ -138,9 +138,8 @@ def main():
     ap.add_argument("--kernel-iters", type=int, default=200)
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from uvhand_amd import harness
+    rank, local_rank, world = harness.dist_env()
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
@@ -148,15 +147,13 @@ def main():
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+    harness.init_process_group("nccl", device)
 
     from uvhand_amd import _native
     from uvhand_amd.functions import MSDeformAttnFunction
     _native.load()
 
-    _, d, dims = make_inputs(args.workload, 1000 + rank, device)
+    _, d, dims = make_inputs(args.workload, harness.rank_seed(1000, rank), device)
     N, S, M, D, L, Lq, P = dims
     value = d["value"].requires_grad_(True)
     loc = d["loc"].requires_grad_(True)
@@ -186,9 +183,7 @@ def main():
         run = graph.replay if graph is not None else step
 
         def barrier():
-            torch.cuda.synchronize()
-            if world > 1:
-                dist.barrier()
+            harness.barrier(device)
 
         for _ in range(args.warmup):
             run()
@@ -220,17 +215,15 @@ def main():
             kt[name] = event_time_ms(call, max(1, args.kernel_iters // per), stream) / per
         stream.synchronize()
 
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    total_samples = harness.sum_over_ranks(N * args.steps, device)
+    elapsed = harness.max_over_ranks(elapsed, device)
 
     if rank == 0:
         fwd_b, bwd_b = algorithmic_bytes(N, S, M, D, L, Lq, P)
         ach = bwd_b / (kt["bwd"] * 1e-3) / 1e9
         result = {
             "metric": "MSDeformAttn fwd+bwd samples/sec @ Swin-L 4-scale, 300 queries",
-            "value": world * N * args.steps / elapsed,
+            "value": total_samples / elapsed,
             "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,

@@ -1,0 +1,76 @@
+"""Small host-side helpers for running the op data-parallel, one process per GPU.
+
+The op shards over the batch with no exchange (every (b, q, m) output depends only on value[b],
+loc[b, q, m], attn[b, q, m]; grad_value[b] only receives from queries of b — reference kernel
+ms_deform_im2col_cuda.cuh:255-297), which is how the reference trains: DistributedSampler gives each
+rank whole samples (datasets/samplers.py:16) and DDP all-reduces parameter gradients (main.py:96-98).
+These helpers hold what `bench.py` and the tests share: rank discovery from the torchrun
+environment (tools/launch.py:158-187 sets the same variables), per-rank seeds / batch slices, and the
+max-over-ranks timing reduction.  They work on any torch.distributed backend (RCCL on the GPUs, gloo in
+the CPU tests) and contain no compute.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def dist_env():
+    """(rank, local_rank, world_size) from the launcher's environment (defaults: single process)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init_process_group(backend, device=None):
+    """env:// rendezvous on 127.0.0.1 unless the launcher says otherwise; no-op for one process."""
+    rank, _, world = dist_env()
+    if world <= 1:
+        return False
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    kwargs = {}
+    if device is not None and backend == "nccl":
+        kwargs["device_id"] = device
+    dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
+    return True
+
+
+def rank_seed(base_seed, rank):
+    """Distinct, reproducible input seed per rank (each rank synthesises its own batch shard)."""
+    return int(base_seed) + 1000003 * int(rank)
+
+
+def shard_batch(global_batch, rank, world):
+    """Contiguous slice [lo, hi) of a global batch owned by `rank`; sizes differ by at most one."""
+    base, extra = divmod(int(global_batch), int(world))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def barrier(device=None):
+    if device is not None and device.type == "cuda":
+        torch.cuda.synchronize(device)
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(seconds, device=None):
+    """Slowest rank's elapsed time (what the whole job waited for)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(seconds)
+    t = torch.tensor([float(seconds)], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value, device=None):
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def job_throughput(samples_this_rank, seconds_this_rank, device=None):
+    """Whole-job samples/s: all ranks' samples over the slowest rank's time."""
+    return sum_over_ranks(samples_this_rank, device) / max_over_ranks(seconds_this_rank, device)
