@@ -43,11 +43,11 @@ WORKLOADS = {
 }
 
 
-def algorithmic_bytes(N, S, M, D, L, Lq, P, e=4):
-    """every input read once, every output written once."""
-    fwd = e * (N * S * M * D + 3 * N * Lq * M * L * P + N * Lq * M * D) + 8 * 3 * L
-    bwd = e * (N * Lq * M * D + N * S * M * D + 3 * N * Lq * M * L * P + N * S * M * D
-               + 3 * N * Lq * M * L * P) + 8 * 3 * L
+def algorithmic_bytes(N, S, M, D, L, Lq, P, e=4, el=4):
+    """every input read once, every output written once.  e = bytes per element of the
+    value-like tensors (value, out, grad_out, grad_value), el = of the location-like ones."""
+    fwd = e * (N * S * M * D + N * Lq * M * D) + el * 3 * N * Lq * M * L * P + 8 * 3 * L
+    bwd = e * (N * Lq * M * D + 2 * N * S * M * D) + el * 6 * N * Lq * M * L * P + 8 * 3 * L
     return fwd, bwd
 
 
@@ -136,6 +136,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="time the eager autograd path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-iters", type=int, default=200)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="storage type of value/out/grad tensors (bf16 = BASELINE config 3, MSDeformAttnBF16Function)")
     args = ap.parse_args()
 
     from uvhand_amd import harness
@@ -150,19 +152,23 @@ def main():
     harness.init_process_group("nccl", device)
 
     from uvhand_amd import _native
-    from uvhand_amd.functions import MSDeformAttnFunction
+    from uvhand_amd.functions import MSDeformAttnBF16Function, MSDeformAttnFunction
     _native.load()
+    bf16 = args.dtype == "bf16"
+    esize = 2 if bf16 else 4
+    fn_apply = MSDeformAttnBF16Function.apply if bf16 else MSDeformAttnFunction.apply
 
     _, d, dims = make_inputs(args.workload, harness.rank_seed(1000, rank), device)
     N, S, M, D, L, Lq, P = dims
-    value = d["value"].requires_grad_(True)
+    value = (d["value"].to(torch.bfloat16) if bf16 else d["value"]).requires_grad_(True)
     loc = d["loc"].requires_grad_(True)
     attn = d["attn"].requires_grad_(True)
-    shapes, lsi, go = d["shapes"], d["lsi"], d["go"]
+    shapes, lsi = d["shapes"], d["lsi"]
+    go = d["go"].to(torch.bfloat16) if bf16 else d["go"]
 
     def step():
         value.grad = loc.grad = attn.grad = None
-        out = MSDeformAttnFunction.apply(value, shapes, lsi, loc, attn, 64)
+        out = fn_apply(value, shapes, lsi, loc, attn, 64)
         out.backward(go)
 
     stream = torch.cuda.Stream(device)
@@ -196,6 +202,8 @@ def main():
 
         # ---- per-kernel timing for the roofline (HIP events on the launch stream) ----
         vd, ld, ad = value.detach(), loc.detach(), attn.detach()
+        if bf16:
+            ld, ad = ld.float(), ad.float()
         fwd = lambda: _native.ms_deform_attn_forward(vd, shapes, lsi, ld, ad, 64)
         bwd = lambda: _native.ms_deform_attn_backward(vd, shapes, lsi, ld, ad, go, 64)
         kt = {}
@@ -219,7 +227,7 @@ def main():
     elapsed = harness.max_over_ranks(elapsed, device)
 
     if rank == 0:
-        fwd_b, bwd_b = algorithmic_bytes(N, S, M, D, L, Lq, P)
+        fwd_b, bwd_b = algorithmic_bytes(N, S, M, D, L, Lq, P, e=esize)
         ach = bwd_b / (kt["bwd"] * 1e-3) / 1e9
         result = {
             "metric": "MSDeformAttn fwd+bwd samples/sec @ Swin-L 4-scale, 300 queries",
@@ -228,17 +236,17 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: N=%d/GPU, levels %s (S=%d), Lq=%d, M=%d, D=%d, P=%d, fp32"
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "%s: N=%d/GPU, levels %s (S=%d), Lq=%d, M=%d, D=%d, P=%d, %s"
                                    % (args.workload, N, "/".join(str(h) for h, _ in WORKLOADS[args.workload][1]),
-                                      S, Lq, M, D, P),
+                                      S, Lq, M, D, P, "fp32" if not bf16 else "bf16 storage / fp32 accumulate"),
                        "step": "MSDeformAttnFunction.apply forward + backward (3 grads)",
                        "launch": "hipGraph replay" if graph is not None else "eager autograd",
                        "sharding": "batch-sharded, no collective"},
             "roofline": {"bound": "hbm", "kernel": "backward: msda::bwd_fused_d32_kernel (grad_value sort+gather "
                                                     "workgroups and grad_loc/grad_attn workgroups in one launch)",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(args.workload, "bwd"), "algorithmic_bytes": bwd_b, "ms": kt["bwd"]},
+                         "traffic": pmc_traffic(args.workload, "bwd") if not bf16 else None, "algorithmic_bytes": bwd_b, "ms": kt["bwd"]},
             "kernels": {"fwd": {"ms": kt["fwd"], "algorithmic_bytes": fwd_b,
                                 "GBps": fwd_b / (kt["fwd"] * 1e-3) / 1e9},
                         "bwd": {"ms": kt["bwd"], "algorithmic_bytes": bwd_b, "GBps": ach}},

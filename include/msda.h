@@ -30,6 +30,8 @@
  *   suffix  T        TL      accumulation
  *   f32     float    float   float            (the reference's float instantiation)
  *   f64     double   double  double           (the reference's double instantiation; gradcheck)
+ *   bf16    bf16     float   float            (new capability, no reference counterpart: bf16 storage
+ *                                              of the value-like tensors, D = 32 family only)
  *
  * Semantics kept from the reference: the batch is processed whole (im2col_step
  * only chunks the reference's launches; results do not depend on it, the host
@@ -90,6 +92,19 @@ int msda_backward_f64(const double *grad_out, const double *value, const int64_t
                       int N, int S, int M, int D, int L, int Lq, int P,
                       double *grad_value, double *grad_sampling_loc, double *grad_attn_weight,
                       msda_stream_t stream);
+
+/* bf16 tensors are passed as uint16_t* (raw bfloat16 bits).  Returns MSDA_ERR_ARGUMENT for
+ * geometries outside the D = 32 kernel family. */
+int msda_forward_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                      const float *sampling_loc, const float *attn_weight,
+                      int N, int S, int M, int D, int L, int Lq, int P,
+                      uint16_t *out, msda_stream_t stream);
+
+int msda_backward_bf16(const uint16_t *grad_out, const uint16_t *value, const int64_t *spatial_shapes,
+                       const int64_t *level_start, const float *sampling_loc, const float *attn_weight,
+                       int N, int S, int M, int D, int L, int Lq, int P,
+                       uint16_t *grad_value, float *grad_sampling_loc, float *grad_attn_weight,
+                       msda_stream_t stream);
 
 /* Thread-local description of the last failure on the calling thread ("" if none). */
 const char *msda_last_error(void);

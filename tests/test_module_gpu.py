@@ -67,3 +67,16 @@ def test_module_runs_under_autocast_like_reference():
         out = mod(*args)
     assert torch.isfinite(out).all()
     assert rel_err(out.float().detach().cpu().numpy(), ref.detach().cpu().numpy()) < 2e-2
+
+
+def test_module_bf16_storage_option():
+    mod = _module()
+    z = load_golden("module_2d")
+    args = [torch.from_numpy(z[k]).cuda() for k in ("query", "refp", "src", "shapes", "level_start")]
+    ref = mod(*args)
+    mod.bf16_storage = True
+    q = args[0].clone().requires_grad_(True)
+    out = mod(q, *args[1:])
+    out.sum().backward()
+    assert out.dtype == torch.float32 and torch.isfinite(q.grad).all()
+    assert rel_err(out.detach().cpu().numpy(), ref.detach().cpu().numpy()) < 1e-2

@@ -340,3 +340,55 @@ def test_runs_on_the_current_stream_without_sync(native):
         out = MSDeformAttnFunction.apply(v, s, i, l, a, 64)
     st.synchronize()
     assert np.array_equal(out.cpu().numpy(), ref)
+
+
+# ---------------------------------------------------------------------------------------------
+# bf16 storage (BASELINE config 3): new capability, judged against the fp32/fp64 oracle
+# ---------------------------------------------------------------------------------------------
+def _bf16_round(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(torch.bfloat16).float().numpy()
+
+
+@pytest.mark.parametrize("name", ["model_small", "ragged_items", "many_queries", "cfg2_decoder"])
+def test_bf16_storage_matches_oracle_on_rounded_inputs(native, oracle, name):
+    """Tolerances (stated): with value and grad_out pre-rounded to bf16 the only
+    differences from the fp32 oracle are fp32 summation order and the single final rounding to bf16
+    (relative 2^-9 = 0.2 %): forward and grad_value within 4e-3 of the tensor's max, grad_loc and
+    grad_attn (stored in fp32) within 2e-5."""
+    from uvhand_amd.functions import MSDeformAttnBF16Function
+    case = ORACLE_CASES[name] if name in ORACLE_CASES else FULL[name]
+    z = make_case(4, *case)
+    z["value"] = _bf16_round(z["value"])
+    z["grad_out"] = _bf16_round(z["grad_out"])
+    v = dev(z["value"]).to(torch.bfloat16).requires_grad_(True)
+    l = dev(z["loc"]).requires_grad_(True)
+    a = dev(z["attn"]).requires_grad_(True)
+    out = MSDeformAttnBF16Function.apply(v, dev(z["shapes"]), dev(z["level_start"]), l, a, 64)
+    assert out.dtype == torch.bfloat16
+    out.backward(dev(z["grad_out"]).to(torch.bfloat16))
+    torch.cuda.synchronize()
+    assert v.grad.dtype == torch.bfloat16 and l.grad.dtype == torch.float32
+    args = [z["value"], z["shapes"], z["level_start"], z["loc"], z["attn"]]
+    r_out = oracle.forward(*args)
+    r_gv, r_gl, r_ga = oracle.backward(z["grad_out"], *args)
+    assert rel_err(out.detach().float().cpu().numpy(), r_out) < 4e-3
+    assert rel_err(v.grad.float().cpu().numpy(), r_gv) < 4e-3
+    assert rel_err(a.grad.cpu().numpy(), r_ga) < 2e-5
+    keep = ~near_boundary_mask(z, tol=1e-5)
+    assert rel_err(l.grad.cpu().numpy()[keep], r_gl[keep]) < 2e-5
+
+
+def test_bf16_storage_vs_fp32_path_and_errors(native):
+    from uvhand_amd.functions import MSDeformAttnBF16Function, MSDeformAttnFunction
+    z = make_case(5, *ORACLE_CASES["model_small"])
+    s, i = dev(z["shapes"]), dev(z["level_start"])
+    v, l, a = dev(z["value"]), dev(z["loc"]), dev(z["attn"])
+    o32 = MSDeformAttnFunction.apply(v, s, i, l, a, 64)
+    o16 = MSDeformAttnBF16Function.apply(v, s, i, l, a, 64)         # fp32 value is rounded on entry
+    # bf16 rounding of value (2^-9) and of the result: rtol 2e-2, atol 1e-3*max|out| (SURVEY §8d C3)
+    assert torch.allclose(o16.float(), o32, rtol=2e-2, atol=1e-3 * o32.abs().max().item())
+    # D != 32 has no bf16 kernel: loud error, no silent fallback
+    zz = make_case(5, *ORACLE_CASES["d64"])
+    with pytest.raises(RuntimeError, match="bf16"):
+        MSDeformAttnBF16Function.apply(dev(zz["value"]), dev(zz["shapes"]), dev(zz["level_start"]),
+                                       dev(zz["loc"]), dev(zz["attn"]), 64)

@@ -22,6 +22,7 @@ _lib = None
 
 _SYMBOLS = (
     "msda_forward_f32", "msda_backward_f32", "msda_forward_f64", "msda_backward_f64",
+    "msda_forward_bf16", "msda_backward_bf16",
     "msda_last_error", "msda_version", "msda_path_for", "msda_force_path",
 )
 
@@ -52,6 +53,8 @@ def _suffix(dtype):
         return "f32"
     if dtype == torch.float64:
         return "f64"
+    if dtype == torch.bfloat16:
+        return "bf16"
     raise RuntimeError('"ms_deform_attn" not implemented for \'%s\'' % str(dtype).replace("torch.", ""))
 
 

@@ -134,6 +134,51 @@ int msda_backward_f64(const double *grad_out, const double *value, const int64_t
                                        grad_attn_weight, (hipStream_t)stream, false);
 }
 
+int msda_forward_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                      const float *sampling_loc, const float *attn_weight, int N, int S, int M, int D, int L,
+                      int Lq, int P, uint16_t *out, msda_stream_t stream)
+{
+    const void *ptrs[] = {value, spatial_shapes, level_start, sampling_loc, attn_weight, out};
+    if (int rc = msda::check_args(ptrs, 6, N, S, M, D, L, Lq, P)) return rc;
+    msda::g_err[0] = 0;
+    if (N == 0 || Lq == 0) return MSDA_OK;
+    if (S == 0) {
+        const hipError_t e = hipMemsetAsync(out, 0, 2 * (size_t)N * Lq * M * D, (hipStream_t)stream);
+        return e == hipSuccess ? MSDA_OK : msda::set_error(MSDA_ERR_LAUNCH, hipGetErrorString(e));
+    }
+    if (!msda::d32_supported(N, S, M, D, L, Lq, P))
+        return msda::set_error(MSDA_ERR_ARGUMENT, "msda bf16: only the D=32 kernel family implements bf16 storage "
+                                                  "(needs D == 32, L <= 16, L*P <= 32)");
+    return msda::launch_fwd_d32_bf16(value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M, L, Lq, P,
+                                     out, (hipStream_t)stream);
+}
+
+int msda_backward_bf16(const uint16_t *grad_out, const uint16_t *value, const int64_t *spatial_shapes,
+                       const int64_t *level_start, const float *sampling_loc, const float *attn_weight, int N,
+                       int S, int M, int D, int L, int Lq, int P, uint16_t *grad_value, float *grad_sampling_loc,
+                       float *grad_attn_weight, msda_stream_t stream)
+{
+    const void *ptrs[] = {grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, grad_value,
+                          grad_sampling_loc, grad_attn_weight};
+    if (int rc = msda::check_args(ptrs, 9, N, S, M, D, L, Lq, P)) return rc;
+    msda::g_err[0] = 0;
+    if (N == 0) return MSDA_OK;
+    if (Lq == 0 || S == 0) {
+        hipError_t e = hipSuccess;
+        if (S > 0) e = hipMemsetAsync(grad_value, 0, 2 * (size_t)N * S * M * D, (hipStream_t)stream);
+        if (e == hipSuccess && Lq > 0) {
+            e = hipMemsetAsync(grad_sampling_loc, 0, 4 * (size_t)N * Lq * M * L * P * 2, (hipStream_t)stream);
+            if (e == hipSuccess) e = hipMemsetAsync(grad_attn_weight, 0, 4 * (size_t)N * Lq * M * L * P, (hipStream_t)stream);
+        }
+        return e == hipSuccess ? MSDA_OK : msda::set_error(MSDA_ERR_LAUNCH, hipGetErrorString(e));
+    }
+    if (!msda::d32_supported(N, S, M, D, L, Lq, P))
+        return msda::set_error(MSDA_ERR_ARGUMENT, "msda bf16: only the D=32 kernel family implements bf16 storage "
+                                                  "(needs D == 32, L <= 16, L*P <= 32)");
+    return msda::launch_bwd_d32_bf16(grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M,
+                                     L, Lq, P, grad_value, grad_sampling_loc, grad_attn_weight, (hipStream_t)stream);
+}
+
 const char *msda_last_error(void) { return msda::g_err; }
 
 int msda_version(void) { return 100; }

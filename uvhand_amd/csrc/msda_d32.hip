@@ -68,17 +68,51 @@ __device__ __forceinline__ void tap_offsets(const PointGeom<float> &g, const Lev
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
+// Storage type of the value-like tensors (value, out, grad_out, grad_value): float, or bfloat16
+// bits (uint16_t) with all arithmetic and accumulation in fp32 and ONE rounding at the final store.
+using bf16_t = uint16_t;
+
+// A lane's 4 consecutive channels of a row.
+template <typename VT> struct Row;
+template <> struct Row<float> {
+    static __device__ __forceinline__ float4 load(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+    static __device__ __forceinline__ void store(float *p, const float4 &v) { *reinterpret_cast<float4 *>(p) = v; }
+    static __device__ __forceinline__ void store1(float *p, float v) { *p = v; }
+};
+template <> struct Row<bf16_t> {
+    static __device__ __forceinline__ float4 load(const bf16_t *p)
+    {
+        const uint2 u = *reinterpret_cast<const uint2 *>(p);                 // 4 x bf16 = 8 B per lane
+        return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                           __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+    }
+    static __device__ __forceinline__ unsigned pack2(float lo, float hi)
+    {
+        // plain casts: hipcc emits v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN stays NaN)
+        const __bf16 a = static_cast<__bf16>(lo), b = static_cast<__bf16>(hi);
+        return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+    }
+    static __device__ __forceinline__ void store(bf16_t *p, const float4 &v)
+    {
+        *reinterpret_cast<uint2 *>(p) = make_uint2(pack2(v.x, v.y), pack2(v.z, v.w));
+    }
+    static __device__ __forceinline__ void store1(bf16_t *p, float v)
+    {
+        *p = __builtin_bit_cast(unsigned short, static_cast<__bf16>(v));
+    }
+};
+
 // Row load of a tap that may be absent (off < 0).  The load itself is unconditional — an absent
 // tap reads row 0 of the tensor, which is always mapped — and the result is discarded by a select,
 // so the compiler can keep a whole batch of row loads in flight (per-tap branches made it wait
 // for the memory system between taps) and an Inf/NaN in an unsampled row can never leak in.
-__device__ __forceinline__ float4 ld4_tap(const float *base, int off)
+template <typename VT>
+__device__ __forceinline__ float4 ld4_tap(const VT *base, int off)
 {
-    const float4 v = ld4(base + (off >= 0 ? off : 0));
+    const float4 v = Row<VT>::load(base + (off >= 0 ? off : 0));
     const bool ok = off >= 0;
     return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
 }
-
 __device__ __forceinline__ void fma4(float4 &acc, float w, const float4 &v)
 {
     acc.x = fmaf(w, v.x, acc.x); acc.y = fmaf(w, v.y, acc.y);
@@ -120,12 +154,12 @@ __device__ __forceinline__ void item_bm(int il, int b0, int r0, int m0, int LqM,
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
-template <int SPLIT>
+template <int SPLIT, typename VT>
 __global__ __launch_bounds__(kBlock) void fwd_d32_kernel(
-    const float *__restrict__ value, const int64_t *__restrict__ shapes,
+    const VT *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ level_start, const float *__restrict__ loc,
     const float *__restrict__ attn, int S, int M, int L, int Lq, int P, int items, int p_shift,
-    int lp_shift, int m_shift, float *__restrict__ out)
+    int lp_shift, int m_shift, VT *__restrict__ out)
 {
     constexpr int IPW = 32 / SPLIT;                       // items per workgroup
     constexpr int OPW = 4 / SPLIT;                        // octets per workgroup
@@ -173,7 +207,7 @@ __global__ __launch_bounds__(kBlock) void fwd_d32_kernel(
     const int wave = tid >> 6, lane = tid & 63, grp = lane >> 3, j = lane & 7;
     const int il = (wave / SPLIT) * 8 + grp;
     const unsigned char *rb = recs + il * item_stride;
-    const float *vb = value + j * 4;
+    const VT *vb = value + j * 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 4
     for (int p = wave % SPLIT; p < LP; p += SPLIT) {
@@ -186,7 +220,7 @@ __global__ __launch_bounds__(kBlock) void fwd_d32_kernel(
 
     if (SPLIT == 1) {
         if (item0 + il < items)
-            *reinterpret_cast<float4 *>(out + (long long)(item0 + il) * kD + j * 4) = acc;
+            Row<VT>::store(out + (long long)(item0 + il) * kD + j * 4, acc);
     } else {
         // the SPLIT wavefronts of an octet hold partial sums: combine through LDS in a fixed
         // order, then coalesced 1-KiB stores.
@@ -198,7 +232,7 @@ __global__ __launch_bounds__(kBlock) void fwd_d32_kernel(
             float sum = red[(oct * SPLIT) * 256 + f];
 #pragma unroll
             for (int k = 1; k < SPLIT; ++k) sum += red[(oct * SPLIT + k) * 256 + f];
-            if (item0 + (o >> 5) < items) out[(long long)item0 * kD + o] = sum;
+            if (item0 + (o >> 5) < items) Row<VT>::store1(out + (long long)item0 * kD + o, sum);
         }
     }
     MSDA_STAMP_AT(2, 3);
@@ -212,12 +246,12 @@ __global__ __launch_bounds__(kBlock) void fwd_d32_kernel(
 // ATOMIC = true additionally scatters grad_value with global float atomics (the v1 scheme, kept
 // for A/B measurements: MSDA_BWD_MODE=atomic); the default leaves grad_value to role B.
 // ------------------------------------------------------------------------------------------
-template <int SPLIT, bool ATOMIC, int THREADS>
+template <int SPLIT, bool ATOMIC, int THREADS, typename VT>
 __device__ __forceinline__ void bwd_query_body(
-    const float *__restrict__ grad_out, const float *__restrict__ value,
+    const VT *__restrict__ grad_out, const VT *__restrict__ value,
     const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
     const float *__restrict__ loc, const float *__restrict__ attn, int S, int M, int L, int Lq,
-    int P, int items, int p_shift, int lp_shift, int m_shift, float *__restrict__ grad_value,
+    int P, int items, int p_shift, int lp_shift, int m_shift, VT *__restrict__ grad_value,
     float *__restrict__ grad_loc, float *__restrict__ grad_attn, int block, unsigned char *smem)
 {
     constexpr int IPW = (THREADS / kWave) * 8 / SPLIT;      // items per workgroup
@@ -257,9 +291,9 @@ __device__ __forceinline__ void bwd_query_body(
     const int wave = tid >> 6, lane = tid & 63, grp = lane >> 3, j = lane & 7;
     const int il = (wave / SPLIT) * 8 + grp;
     const unsigned char *rb = recs + il * item_stride;
-    const float *vb = value + j * 4;
+    const VT *vb = value + j * 4;
     float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (item0 + il < items) g4 = ld4(grad_out + (long long)(item0 + il) * kD + j * 4);
+    if (item0 + il < items) g4 = Row<VT>::load(grad_out + (long long)(item0 + il) * kD + j * 4);
     __syncthreads();
     MSDA_STAMP_AT(1, 1);
 
@@ -286,8 +320,8 @@ __device__ __forceinline__ void bwd_query_body(
             const int p = p0 + u * SPLIT;
             const float lh = f[u].x, lw = f[u].y, a = f[u].z, hh = 1.f - lh, hw = 1.f - lw;
             const float k1 = hh * hw, k2 = hh * lw, k3 = lh * hw, k4 = lh * lw;
-            if (ATOMIC) {
-                float *gvb = grad_value + j * 4;
+            if constexpr (ATOMIC && sizeof(VT) == 4) {
+                float *gvb = reinterpret_cast<float *>(grad_value) + j * 4;
                 const int o4[4] = {off[u].x, off[u].y, off[u].z, off[u].w};
                 const float k[4] = {k1, k2, k3, k4};
 #pragma unroll
@@ -320,16 +354,16 @@ __device__ __forceinline__ void bwd_query_body(
     MSDA_STAMP_AT(1, 3);
 }
 
-template <int SPLIT, bool ATOMIC>
+template <int SPLIT, bool ATOMIC, typename VT>
 __global__ __launch_bounds__(kBlock) void bwd_query_d32_kernel(
-    const float *__restrict__ grad_out, const float *__restrict__ value,
+    const VT *__restrict__ grad_out, const VT *__restrict__ value,
     const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
     const float *__restrict__ loc, const float *__restrict__ attn, int S, int M, int L, int Lq,
-    int P, int items, int p_shift, int lp_shift, int m_shift, float *__restrict__ grad_value,
+    int P, int items, int p_shift, int lp_shift, int m_shift, VT *__restrict__ grad_value,
     float *__restrict__ grad_loc, float *__restrict__ grad_attn)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    bwd_query_body<SPLIT, ATOMIC, kBlock>(grad_out, value, shapes, level_start, loc, attn, S, M, L, Lq, P, items,
+    bwd_query_body<SPLIT, ATOMIC, kBlock, VT>(grad_out, value, shapes, level_start, loc, attn, S, M, L, Lq, P, items,
                                           p_shift, lp_shift, m_shift, grad_value, grad_loc, grad_attn,
                                           (int)blockIdx.x, smem);
 }
@@ -385,8 +419,8 @@ __device__ __forceinline__ void add4(float4 &a, const float4 &b) { a.x += b.x; a
 // Step 4.  SLOTS lane-groups of 8 lanes share one row's segment; 8/SLOTS rows per wavefront trip.
 // A lane group takes its records four at a time: 4 record reads, then 4 independent 128-B row
 // loads in flight, then the FMAs — one memory round trip per 4*SLOTS records of a row.
-template <int SLOTS, bool MULTIPASS>
-__device__ __forceinline__ void gather_rows(const float *__restrict__ go_base, float *__restrict__ gv_base,
+template <int SLOTS, bool MULTIPASS, typename VT>
+__device__ __forceinline__ void gather_rows(const VT *__restrict__ go_base, VT *__restrict__ gv_base,
                                             const int *cnt, const int *start, const SRec *rec, float *tile,
                                             int npx, int row_stride, bool first_pass)
 {
@@ -403,7 +437,7 @@ __device__ __forceinline__ void gather_rows(const float *__restrict__ go_base, f
             for (int u = 0; u < 4; ++u) { rr[u].w = 0.f; rr[u].q = -1; if (i0 + u * SLOTS < n) rr[u] = r[i0 + u * SLOTS]; }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const float4 t = ld4(go_base + (long long)(rr[u].q >= 0 ? rr[u].q : 0) * row_stride);
+                const float4 t = Row<VT>::load(go_base + (long long)(rr[u].q >= 0 ? rr[u].q : 0) * row_stride);
                 const bool ok = rr[u].q >= 0;
                 g[u] = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
             }
@@ -418,7 +452,7 @@ __device__ __forceinline__ void gather_rows(const float *__restrict__ go_base, f
                 float4 *t = reinterpret_cast<float4 *>(tile) + d * 8 + j;   // same lane owns it in every pass
                 if (first_pass) *t = acc; else { float4 o = *t; add4(o, acc); *t = o; }
             } else {
-                *reinterpret_cast<float4 *>(gv_base + (long long)d * row_stride) = acc;
+                Row<VT>::store(gv_base + (long long)d * row_stride, acc);
             }
         }
     }
@@ -427,12 +461,12 @@ __device__ __forceinline__ void gather_rows(const float *__restrict__ go_base, f
 // PPT = sampling points per thread per pass: all of a thread's points are loaded up front (2*PPT
 // independent global loads in flight), their taps and histogram ranks stay in registers between
 // step 1 and step 3, so loc / attn are read exactly once and step 3 needs no atomics.
-template <bool MULTIPASS, int PPT>
+template <bool MULTIPASS, int PPT, typename VT>
 __device__ __forceinline__ void bwd_value_body(
-    const float *__restrict__ grad_out, const int64_t *__restrict__ shapes,
+    const VT *__restrict__ grad_out, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ level_start, const float *__restrict__ loc,
     const float *__restrict__ attn, int S, int M, int L, int Lq, int P, int p_shift, int tp_cap,
-    float *__restrict__ grad_value, int ti, int W, int l, int pr, unsigned char *smem)
+    VT *__restrict__ grad_value, int ti, int W, int l, int pr, unsigned char *smem)
 {
     constexpr int NPC = PPT * kSBlock;                       // points per pass
     // LDS: [tile: tp_cap*32 floats if MULTIPASS] [cnt tp_cap] [start tp_cap] [wsum 16] [rec 4*NPC]
@@ -455,8 +489,8 @@ __device__ __forceinline__ void bwd_value_body(
     const int NP = Lq * P;
     const long long item_base = (long long)b * Lq * M + m;                   // item(q) = item_base + q*M
     const int row_stride = M * kD;
-    const float *go_base = grad_out + item_base * kD + (lane & 7) * 4;
-    float *gv_base = grad_value + ((long long)(b * S + lstart + px0) * M + m) * kD + (lane & 7) * 4;
+    const VT *go_base = grad_out + item_base * kD + (lane & 7) * 4;
+    VT *gv_base = grad_value + ((long long)(b * S + lstart + px0) * M + m) * kD + (lane & 7) * 4;
 
     for (int c0 = 0; c0 < NP; c0 += NPC) {
         // ---- loads of this pass's points first: they overlap the histogram reset ----
@@ -527,10 +561,10 @@ __device__ __forceinline__ void bwd_value_body(
         // ---- 4. gather; lanes per row chosen from the mean segment length (uniform) ----
         const int mean2 = (2 * total) / npx;                                  // 2 x mean records per row
         const bool first = (c0 == 0);
-        if (mean2 <= 8)       gather_rows<1, MULTIPASS>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
-        else if (mean2 <= 16) gather_rows<2, MULTIPASS>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
-        else if (mean2 <= 32) gather_rows<4, MULTIPASS>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
-        else                  gather_rows<8, MULTIPASS>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
+        if (mean2 <= 8)       gather_rows<1, MULTIPASS, VT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
+        else if (mean2 <= 16) gather_rows<2, MULTIPASS, VT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
+        else if (mean2 <= 32) gather_rows<4, MULTIPASS, VT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
+        else                  gather_rows<8, MULTIPASS, VT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
         if (MULTIPASS) __syncthreads();
         MSDA_STAMP(5);
     }
@@ -540,21 +574,21 @@ __device__ __forceinline__ void bwd_value_body(
         for (int i = tid; i < npx * 8; i += kSBlock) {
             const int d = i >> 3, jj = i & 7;
             const float4 v = NP > 0 ? reinterpret_cast<const float4 *>(tile)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4 *>(grad_value + ((long long)(b * S + lstart + px0 + d) * M + m) * kD + jj * 4) = v;
+            Row<VT>::store(grad_value + ((long long)(b * S + lstart + px0 + d) * M + m) * kD + jj * 4, v);
         }
     }
 }
 
-template <bool MULTIPASS, int PPT>
+template <bool MULTIPASS, int PPT, typename VT>
 __global__ __launch_bounds__(kSBlock) void bwd_value_d32_kernel(
-    const float *__restrict__ grad_out, const int64_t *__restrict__ shapes,
+    const VT *__restrict__ grad_out, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ level_start, const float *__restrict__ loc,
     const float *__restrict__ attn, int S, int M, int L, int Lq, int P, int p_shift, int tp_cap,
-    float *__restrict__ grad_value)
+    VT *__restrict__ grad_value)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // grid = (W ranges, L levels, N*M pairs)
-    bwd_value_body<MULTIPASS, PPT>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, tp_cap,
+    bwd_value_body<MULTIPASS, PPT, VT>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, tp_cap,
                                    grad_value, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y, (int)blockIdx.z, smem);
 }
 
@@ -562,22 +596,22 @@ __global__ __launch_bounds__(kSBlock) void bwd_value_d32_kernel(
 // (grad_value), the rest role A (grad_sampling_loc / grad_attn_weight).  The two roles share no
 // data, so this is plain concurrency inside one grid — it removes a dependent kernel boundary
 // (~1.5 us) and lets role A's short workgroups fill the CUs around role B's longer ones.
-template <int SPLIT>
+template <int SPLIT, typename VT>
 __global__ __launch_bounds__(kSBlock) void bwd_fused_d32_kernel(
-    const float *__restrict__ grad_out, const float *__restrict__ value,
+    const VT *__restrict__ grad_out, const VT *__restrict__ value,
     const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
     const float *__restrict__ loc, const float *__restrict__ attn, int S, int M, int L, int Lq,
     int P, int items, int p_shift, int lp_shift, int m_shift, int tp_cap, int W, int nB,
-    float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attn)
+    VT *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attn)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int bid = (int)blockIdx.x;
     if (bid < nB) {
         const int ti = bid % W, l = (bid / W) % L, pr = bid / (W * L);
-        bwd_value_body<false, kSinglePPT>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, tp_cap,
+        bwd_value_body<false, kSinglePPT, VT>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, tp_cap,
                                           grad_value, ti, W, l, pr, smem);
     } else {
-        bwd_query_body<SPLIT, false, kSBlock>(grad_out, value, shapes, level_start, loc, attn, S, M, L, Lq, P, items,
+        bwd_query_body<SPLIT, false, kSBlock, VT>(grad_out, value, shapes, level_start, loc, attn, S, M, L, Lq, P, items,
                                               p_shift, lp_shift, m_shift, grad_value, grad_loc, grad_attn,
                                               bid - nB, smem);
     }
@@ -617,9 +651,10 @@ static int pick_split(int items, int LP)
     return 1;
 }
 
-int launch_fwd_d32(const float *value, const int64_t *shapes, const int64_t *level_start,
-                   const float *loc, const float *attn, int N, int S, int M, int L, int Lq, int P,
-                   float *out, hipStream_t stream)
+template <typename VT>
+static int launch_fwd_d32_t(const VT *value, const int64_t *shapes, const int64_t *level_start,
+                            const float *loc, const float *attn, int N, int S, int M, int L, int Lq, int P,
+                            VT *out, hipStream_t stream)
 {
     const int items = N * Lq * M, LP = L * P;
     const int item_stride = LP * kRecBytes + kItemPad;
@@ -627,39 +662,38 @@ int launch_fwd_d32(const float *value, const int64_t *shapes, const int64_t *lev
     const int ipw = 32 / split;
     const size_t lds = (size_t)ipw * item_stride + (split > 1 ? 4096 : 0);
     const dim3 grid((items + ipw - 1) / ipw), block(kBlock);
-    if (split == 4)
-        hipLaunchKernelGGL(fwd_d32_kernel<4>, grid, block, lds, stream, value, shapes, level_start, loc, attn,
-                           S, M, L, Lq, P, items, pow2_shift(P), pow2_shift(LP), pow2_shift(M), out);
-    else if (split == 2)
-        hipLaunchKernelGGL(fwd_d32_kernel<2>, grid, block, lds, stream, value, shapes, level_start, loc, attn,
-                           S, M, L, Lq, P, items, pow2_shift(P), pow2_shift(LP), pow2_shift(M), out);
-    else
-        hipLaunchKernelGGL(fwd_d32_kernel<1>, grid, block, lds, stream, value, shapes, level_start, loc, attn,
-                           S, M, L, Lq, P, items, pow2_shift(P), pow2_shift(LP), pow2_shift(M), out);
+#define MSDA_LAUNCH_FWD(SP)                                                                            \
+    hipLaunchKernelGGL((fwd_d32_kernel<SP, VT>), grid, block, lds, stream, value, shapes, level_start, loc, attn, \
+                       S, M, L, Lq, P, items, pow2_shift(P), pow2_shift(LP), pow2_shift(M), out)
+    if (split == 4) MSDA_LAUNCH_FWD(4); else if (split == 2) MSDA_LAUNCH_FWD(2); else MSDA_LAUNCH_FWD(1);
+#undef MSDA_LAUNCH_FWD
     return check_launch("msda forward (d32)");
 }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
-int launch_bwd_d32(const float *grad_out, const float *value, const int64_t *shapes,
-                   const int64_t *level_start, const float *loc, const float *attn, int N, int S,
-                   int M, int L, int Lq, int P, float *grad_value, float *grad_loc, float *grad_attn,
-                   hipStream_t stream)
+template <typename VT>
+static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *shapes,
+                            const int64_t *level_start, const float *loc, const float *attn, int N, int S,
+                            int M, int L, int Lq, int P, VT *grad_value, float *grad_loc, float *grad_attn,
+                            hipStream_t stream)
 {
     const int items = N * Lq * M, LP = L * P;
     const int item_stride = LP * kRecBytes + kItemPad;
     // tuning / A-B knobs, read once per process: MSDA_BWD_MODE=atomic selects the v1 global-atomic
-    // scatter, =split launches role B and role A as two kernels; MSDA_BWD_WGS is the number of role-B
-    // workgroups to aim for on small problems.
-    static const int bwd_mode = [] {                       // 0 fused (default), 1 split launches, 2 v1 atomics
+    // scatter (fp32 only), =split launches role B and role A as two kernels; MSDA_BWD_WGS is the number
+    // of role-B workgroups to aim for on small problems.
+    static const int bwd_mode_env = [] {                   // 0 fused (default), 1 split launches, 2 v1 atomics
         const char *v = getenv("MSDA_BWD_MODE");
         return (v && !strcmp(v, "atomic")) ? 2 : (v && !strcmp(v, "split")) ? 1 : 0; }();
+    const int bwd_mode = (bwd_mode_env == 2 && sizeof(VT) != 4) ? 0 : bwd_mode_env;
     const bool atomic_mode = bwd_mode == 2;
     static const int target_wgs = [] { int v = env_int("MSDA_BWD_WGS", 256); return v < 1 ? 1 : v; }();
     const int split = pick_split(items, LP);
+    const int ps = pow2_shift(P), lps = pow2_shift(LP), ms = pow2_shift(M);
 
     if (atomic_mode) {
-        hipError_t e = hipMemsetAsync(grad_value, 0, sizeof(float) * (size_t)N * S * M * kD, stream);
+        hipError_t e = hipMemsetAsync(grad_value, 0, sizeof(VT) * (size_t)N * S * M * kD, stream);
         if (e != hipSuccess) return set_error(MSDA_ERR_LAUNCH, hipGetErrorString(e));
     } else {
         // role B: counting sort + gather, W pixel ranges per level (see the kernel's header)
@@ -676,8 +710,6 @@ int launch_bwd_d32(const float *grad_out, const float *value, const int64_t *sha
             W = ceil_div(S, tp_cap);
         }
         tp_cap = (tp_cap + 3) & ~3;                                   // keeps the LDS arrays 16-B aligned
-        if ((long long)S * (W + 1) >= (1LL << 31) || W > 65535 || L > 65535 || (long long)N * M > 65535)
-            return set_error(MSDA_ERR_ARGUMENT, "msda backward (d32): geometry exceeds the tile grid limits");
         const dim3 grid((unsigned)W, (unsigned)L, (unsigned)(N * M));
         const size_t lds = (multipass ? (size_t)tp_cap * kD * 4 : 0) + (2 * (size_t)tp_cap + 16) * 4 +
                            (size_t)4 * (multipass ? kMultiPPT : kSinglePPT) * kSBlock * sizeof(SRec);
@@ -690,9 +722,9 @@ int launch_bwd_d32(const float *grad_out, const float *value, const int64_t *sha
             const dim3 fgrid((unsigned)(nB + nA));
             const size_t flds = lds > lds_a ? lds : lds_a;
 #define MSDA_LAUNCH_F(SP)                                                                              \
-            hipLaunchKernelGGL((bwd_fused_d32_kernel<SP>), fgrid, dim3(kSBlock), flds, stream, grad_out, value, shapes, \
-                               level_start, loc, attn, S, M, L, Lq, P, items, pow2_shift(P), pow2_shift(LP),   \
-                               pow2_shift(M), tp_cap, W, (int)nB, grad_value, grad_loc, grad_attn)
+            hipLaunchKernelGGL((bwd_fused_d32_kernel<SP, VT>), fgrid, dim3(kSBlock), flds, stream, grad_out, value,  \
+                               shapes, level_start, loc, attn, S, M, L, Lq, P, items, ps, lps, ms, tp_cap, W,    \
+                               (int)nB, grad_value, grad_loc, grad_attn)
             if (split == 4) MSDA_LAUNCH_F(4); else if (split == 2) MSDA_LAUNCH_F(2); else MSDA_LAUNCH_F(1);
 #undef MSDA_LAUNCH_F
             return check_launch("msda backward (d32, fused)");
@@ -700,16 +732,16 @@ int launch_bwd_d32(const float *grad_out, const float *value, const int64_t *sha
         if (multipass) {
             static thread_local size_t granted = 0;
             if (lds > granted) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bwd_value_d32_kernel<true, kMultiPPT>),
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bwd_value_d32_kernel<true, kMultiPPT, VT>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (e != hipSuccess) return set_error(MSDA_ERR_LAUNCH, hipGetErrorString(e));
                 granted = lds;
             }
-            hipLaunchKernelGGL((bwd_value_d32_kernel<true, kMultiPPT>), grid, dim3(kSBlock), lds, stream,
-                               grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, pow2_shift(P), tp_cap, grad_value);
+            hipLaunchKernelGGL((bwd_value_d32_kernel<true, kMultiPPT, VT>), grid, dim3(kSBlock), lds, stream,
+                               grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, ps, tp_cap, grad_value);
         } else {
-            hipLaunchKernelGGL((bwd_value_d32_kernel<false, kSinglePPT>), grid, dim3(kSBlock), lds, stream,
-                               grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, pow2_shift(P), tp_cap, grad_value);
+            hipLaunchKernelGGL((bwd_value_d32_kernel<false, kSinglePPT, VT>), grid, dim3(kSBlock), lds, stream,
+                               grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, ps, tp_cap, grad_value);
         }
         if (int rc = check_launch("msda backward (d32, grad_value sort+gather)")) return rc;
     }
@@ -718,14 +750,39 @@ int launch_bwd_d32(const float *grad_out, const float *value, const int64_t *sha
         const size_t lds = (size_t)ipw * item_stride + (size_t)ipw * LP * 16;
         const dim3 grid((items + ipw - 1) / ipw), block(kBlock);
 #define MSDA_LAUNCH_A(SP, AT)                                                                          \
-        hipLaunchKernelGGL((bwd_query_d32_kernel<SP, AT>), grid, block, lds, stream, grad_out, value, shapes, \
-                           level_start, loc, attn, S, M, L, Lq, P, items, pow2_shift(P), pow2_shift(LP), pow2_shift(M), \
-                           grad_value, grad_loc, grad_attn)
+        hipLaunchKernelGGL((bwd_query_d32_kernel<SP, AT, VT>), grid, block, lds, stream, grad_out, value, shapes, \
+                           level_start, loc, attn, S, M, L, Lq, P, items, ps, lps, ms, grad_value, grad_loc, grad_attn)
         if (atomic_mode) { if (split == 4) MSDA_LAUNCH_A(4, true); else if (split == 2) MSDA_LAUNCH_A(2, true); else MSDA_LAUNCH_A(1, true); }
         else             { if (split == 4) MSDA_LAUNCH_A(4, false); else if (split == 2) MSDA_LAUNCH_A(2, false); else MSDA_LAUNCH_A(1, false); }
 #undef MSDA_LAUNCH_A
     }
     return check_launch("msda backward (d32, query-major)");
+}
+
+int launch_fwd_d32(const float *value, const int64_t *shapes, const int64_t *level_start, const float *loc,
+                   const float *attn, int N, int S, int M, int L, int Lq, int P, float *out, hipStream_t stream)
+{
+    return launch_fwd_d32_t<float>(value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, out, stream);
+}
+int launch_bwd_d32(const float *grad_out, const float *value, const int64_t *shapes, const int64_t *level_start,
+                   const float *loc, const float *attn, int N, int S, int M, int L, int Lq, int P,
+                   float *grad_value, float *grad_loc, float *grad_attn, hipStream_t stream)
+{
+    return launch_bwd_d32_t<float>(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, grad_value,
+                                   grad_loc, grad_attn, stream);
+}
+int launch_fwd_d32_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *level_start, const float *loc,
+                        const float *attn, int N, int S, int M, int L, int Lq, int P, uint16_t *out,
+                        hipStream_t stream)
+{
+    return launch_fwd_d32_t<bf16_t>(value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, out, stream);
+}
+int launch_bwd_d32_bf16(const uint16_t *grad_out, const uint16_t *value, const int64_t *shapes,
+                        const int64_t *level_start, const float *loc, const float *attn, int N, int S, int M, int L,
+                        int Lq, int P, uint16_t *grad_value, float *grad_loc, float *grad_attn, hipStream_t stream)
+{
+    return launch_bwd_d32_t<bf16_t>(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, grad_value,
+                                    grad_loc, grad_attn, stream);
 }
 
 }  // namespace msda

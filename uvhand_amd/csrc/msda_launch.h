@@ -34,4 +34,13 @@ int launch_bwd_d32(const float *grad_out, const float *value, const int64_t *sha
                    int M, int L, int Lq, int P, float *grad_value, float *grad_loc, float *grad_attn,
                    hipStream_t stream);
 
+// bf16 storage (uint16_t bits) of value / out / grad_out / grad_value; loc, attn and their gradients fp32.
+int launch_fwd_d32_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *level_start,
+                        const float *loc, const float *attn, int N, int S, int M, int L, int Lq, int P,
+                        uint16_t *out, hipStream_t stream);
+int launch_bwd_d32_bf16(const uint16_t *grad_out, const uint16_t *value, const int64_t *shapes,
+                        const int64_t *level_start, const float *loc, const float *attn, int N, int S,
+                        int M, int L, int Lq, int P, uint16_t *grad_value, float *grad_loc, float *grad_attn,
+                        hipStream_t stream);
+
 }  // namespace msda

@@ -1,3 +1,3 @@
-from .ms_deform_attn_func import MSDeformAttnFunction
+from .ms_deform_attn_func import MSDeformAttnBF16Function, MSDeformAttnFunction
 
-__all__ = ["MSDeformAttnFunction"]
+__all__ = ["MSDeformAttnFunction", "MSDeformAttnBF16Function"]

@@ -48,3 +48,38 @@ class MSDeformAttnFunction(Function):
             value.to(sampling_locations.dtype), value_spatial_shapes, value_level_start_index,
             sampling_locations, attention_weights, grad_output.contiguous(), ctx.im2col_step)
         return grad_value, None, None, grad_sampling_loc, grad_attn_weight, None
+
+
+class MSDeformAttnBF16Function(Function):
+    """bfloat16-storage variant — new capability, no reference counterpart (the reference op is
+    fp32/fp64 only: AT_DISPATCH_FLOATING_TYPES, ms_deform_attn_cuda.cu:64,134; BASELINE config 3).
+
+    ``value`` is rounded to bfloat16 and the output / grad_value come back in bfloat16 (half the
+    HBM bytes of every row gather and store); sampling locations, attention weights and their
+    gradients stay float32, and all arithmetic and accumulation inside the kernels is float32 with
+    one rounding at the final store.  Same call signature as ``MSDeformAttnFunction``; only the
+    D = 32 kernel family implements it.
+    """
+
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                attention_weights, im2col_step):
+        ctx.im2col_step = im2col_step
+        output = MSDA.ms_deform_attn_forward(
+            value.to(torch.bfloat16), value_spatial_shapes, value_level_start_index,
+            sampling_locations.float(), attention_weights.float(), ctx.im2col_step)
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index,
+                              sampling_locations, attention_weights)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights = \
+            ctx.saved_tensors
+        grad_value, grad_sampling_loc, grad_attn_weight = MSDA.ms_deform_attn_backward(
+            value.to(torch.bfloat16), value_spatial_shapes, value_level_start_index,
+            sampling_locations.float(), attention_weights.float(),
+            grad_output.to(torch.bfloat16).contiguous(), ctx.im2col_step)
+        return (grad_value.to(value.dtype), None, None, grad_sampling_loc.to(sampling_locations.dtype),
+                grad_attn_weight.to(attention_weights.dtype), None)

@@ -25,7 +25,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..functions import MSDeformAttnFunction
+from ..functions import MSDeformAttnBF16Function, MSDeformAttnFunction
 
 
 # (data_ptr, version, Len_in) of spatial_shapes tensors whose H*W sum was already verified: the
@@ -60,6 +60,8 @@ class MSDeformAttn(nn.Module):
                           "takes the tiled HIP kernels; other widths use the generic ones.")
 
         self.im2col_step = 64
+        # opt-in, not in the reference: keep value / sampled output in bfloat16 (fp32 accumulation)
+        self.bf16_storage = False
         self.d_model = d_model
         self.n_levels = n_levels
         self.n_heads = n_heads
@@ -136,7 +138,7 @@ class MSDeformAttn(nn.Module):
             raise ValueError(
                 "Last dim of reference_points must be 2 or 4, but get {} instead.".format(ref_dim))
 
-        output = MSDeformAttnFunction.apply(
-            value, input_spatial_shapes, input_level_start_index, sampling_locations, attention_weights,
-            self.im2col_step)
-        return self.output_proj(output)
+        fn = MSDeformAttnBF16Function if self.bf16_storage else MSDeformAttnFunction
+        output = fn.apply(value, input_spatial_shapes, input_level_start_index, sampling_locations,
+                          attention_weights, self.im2col_step)
+        return self.output_proj(output.to(self.output_proj.weight.dtype) if self.bf16_storage else output)
