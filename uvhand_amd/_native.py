@@ -60,15 +60,23 @@ def _suffix(dtype):
 
 def _check_inputs(named):
     # order and wording follow ms_deform_attn_cuda.cu:28-38 / :93-105
-    if not named[0][1].is_cuda:
+    value = named[0][1]
+    if not value.is_cuda:
         raise RuntimeError("Not implemented on the CPU")          # ms_deform_attn.h:38,60
+    dev = value.device
+    ok = True
+    for _, t in named:
+        if not (t.is_contiguous() and t.is_cuda and t.device == dev):
+            ok = False
+            break
+    if ok:
+        return
     for name, t in named:
         if not t.is_contiguous():
             raise RuntimeError("%s tensor has to be contiguous" % name)
     for name, t in named:
         if not t.is_cuda:
             raise RuntimeError("%s must be a CUDA tensor" % name)
-    dev = named[0][1].device
     for name, t in named:
         if t.device != dev:
             raise RuntimeError("%s must be on the same device as value (%s vs %s)" % (name, t.device, dev))
@@ -113,25 +121,65 @@ def _raise(lib, rc, what):
     raise RuntimeError("%s failed (code %d): %s" % (what, rc, msg.decode() if msg else "?"))
 
 
-def _p(t):
-    return ctypes.c_void_p(t.data_ptr())
+_VP, _CI = ctypes.c_void_p, ctypes.c_int
+_FWD_ARGTYPES = [_VP] * 5 + [_CI] * 7 + [_VP, _VP]
+_BWD_ARGTYPES = [_VP] * 6 + [_CI] * 7 + [_VP] * 4
+_entry_cache = {}
+
+
+def _entry(lib, name, argtypes):
+    """ctypes function with declared argtypes (plain ints go straight through: the call costs a few us
+    of host time, which matters when a kernel takes 5)."""
+    fn = _entry_cache.get(name)
+    if fn is None:
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = _CI
+        _entry_cache[name] = fn
+    return fn
+
+
+def _raw_stream(device):
+    """hipStream_t of PyTorch's current stream on `device` (launch there: ms_deform_attn_cuda.cu:65,135)."""
+    try:
+        return torch._C._cuda_getCurrentRawStream(device.index)
+    except AttributeError:                                   # older/newer torch without the private hook
+        return torch.cuda.current_stream(device).cuda_stream
+
+
+class _DeviceGuard:
+    """No reference counterpart (it relies on torch.cuda.set_device(rank), util/misc.py:550): switch to
+    the tensors' device only when it is not already current."""
+    __slots__ = ("prev",)
+
+    def __init__(self, device):
+        cur = torch.cuda.current_device()
+        self.prev = cur if cur != device.index else None
+        if self.prev is not None:
+            torch.cuda.set_device(device.index)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            torch.cuda.set_device(self.prev)
+        return False
 
 
 def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
     """Replaces MSDA.ms_deform_attn_forward (vision.cpp:14). Returns out[N, Lq, M*D]."""
-    lib = load()
-    _check_inputs([("value", value), ("spatial_shapes", spatial_shapes),
+    lib = _lib or load()
+    _check_inputs((("value", value), ("spatial_shapes", spatial_shapes),
                    ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
-                   ("attn_weight", attn_weight)])
+                   ("attn_weight", attn_weight)))
     N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step)
     suf = _compute_dtypes(value, sampling_loc, attn_weight)
-    with torch.cuda.device_of(value):
+    with _DeviceGuard(value.device):
         out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
-        stream = ctypes.c_void_p(torch.cuda.current_stream(value.device).cuda_stream)
-        rc = getattr(lib, "msda_forward_" + suf)(
-            _p(value), _p(spatial_shapes), _p(level_start_index), _p(sampling_loc), _p(attn_weight),
-            ctypes.c_int(N), ctypes.c_int(S), ctypes.c_int(M), ctypes.c_int(D), ctypes.c_int(L),
-            ctypes.c_int(Lq), ctypes.c_int(P), _p(out), stream)
+        rc = _entry(lib, "msda_forward_" + suf, _FWD_ARGTYPES)(
+            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
+            attn_weight.data_ptr(), N, S, M, D, L, Lq, P, out.data_ptr(), _raw_stream(value.device))
     if rc != 0:
         _raise(lib, rc, "ms_deform_attn_forward")
     return out
@@ -141,25 +189,23 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
                             im2col_step):
     """Replaces MSDA.ms_deform_attn_backward (vision.cpp:15).
     Returns (grad_value, grad_sampling_loc, grad_attn_weight)."""
-    lib = load()
-    _check_inputs([("value", value), ("spatial_shapes", spatial_shapes),
+    lib = _lib or load()
+    _check_inputs((("value", value), ("spatial_shapes", spatial_shapes),
                    ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
-                   ("attn_weight", attn_weight), ("grad_output", grad_output)])
+                   ("attn_weight", attn_weight), ("grad_output", grad_output)))
     N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step)
     suf = _compute_dtypes(value, sampling_loc, attn_weight)
     if grad_output.dtype != value.dtype or grad_output.numel() != N * Lq * M * D:
         raise RuntimeError("ms_deform_attn_backward: grad_output must be %s[%d,%d,%d]"
                            % (value.dtype, N, Lq, M * D))
-    with torch.cuda.device_of(value):
+    with _DeviceGuard(value.device):
         grad_value = torch.empty_like(value)
         grad_loc = torch.empty_like(sampling_loc)
         grad_attn = torch.empty_like(attn_weight)
-        stream = ctypes.c_void_p(torch.cuda.current_stream(value.device).cuda_stream)
-        rc = getattr(lib, "msda_backward_" + suf)(
-            _p(grad_output), _p(value), _p(spatial_shapes), _p(level_start_index), _p(sampling_loc),
-            _p(attn_weight),
-            ctypes.c_int(N), ctypes.c_int(S), ctypes.c_int(M), ctypes.c_int(D), ctypes.c_int(L),
-            ctypes.c_int(Lq), ctypes.c_int(P), _p(grad_value), _p(grad_loc), _p(grad_attn), stream)
+        rc = _entry(lib, "msda_backward_" + suf, _BWD_ARGTYPES)(
+            grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+            sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P,
+            grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(), _raw_stream(value.device))
     if rc != 0:
         _raise(lib, rc, "ms_deform_attn_backward")
     return grad_value, grad_loc, grad_attn

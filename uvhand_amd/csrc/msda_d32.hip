@@ -209,12 +209,29 @@ __global__ __launch_bounds__(kBlock) void fwd_d32_kernel(
     const unsigned char *rb = recs + il * item_stride;
     const VT *vb = value + j * 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 4
-    for (int p = wave % SPLIT; p < LP; p += SPLIT) {
-        const int4 off = *reinterpret_cast<const int4 *>(rb + p * kRecBytes);
-        const float4 w = *reinterpret_cast<const float4 *>(rb + p * kRecBytes + 16);
-        const float4 v0 = ld4_tap(vb, off.x), v1 = ld4_tap(vb, off.y), v2 = ld4_tap(vb, off.z), v3 = ld4_tap(vb, off.w);
-        fma4(acc, w.x, v0); fma4(acc, w.y, v1); fma4(acc, w.z, v2); fma4(acc, w.w, v3);
+    // 4 points per trip: all records, then all 16 row loads, then the FMAs (one memory round trip
+    // per trip instead of one per point).
+    for (int p0 = wave % SPLIT; p0 < LP; p0 += 4 * SPLIT) {
+        int4 off[4]; float4 w[4]; float4 v[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = p0 + u * SPLIT;
+            off[u] = make_int4(-1, -1, -1, -1); w[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p < LP) {
+                off[u] = *reinterpret_cast<const int4 *>(rb + p * kRecBytes);
+                w[u] = *reinterpret_cast<const float4 *>(rb + p * kRecBytes + 16);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            v[u][0] = ld4_tap(vb, off[u].x); v[u][1] = ld4_tap(vb, off[u].y);
+            v[u][2] = ld4_tap(vb, off[u].z); v[u][3] = ld4_tap(vb, off[u].w);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            fma4(acc, w[u].x, v[u][0]); fma4(acc, w[u].y, v[u][1]);
+            fma4(acc, w[u].z, v[u][2]); fma4(acc, w[u].w, v[u][3]);
+        }
     }
     MSDA_STAMP_AT(2, 2);
 
@@ -394,17 +411,22 @@ __global__ __launch_bounds__(kBlock) void bwd_query_d32_kernel(
 // of points, so equal counts of workgroups per level balance the gather work even though a coarse
 // level has 4x fewer pixels.  W comes from the host (it only needs S and the batch size); the
 // ranges come from spatial_shapes on the device.
-// MULTIPASS (Lq*P too large for the record array): queries are processed in chunks and the rows
-// accumulate in an LDS tile owned by the same lanes in every pass, flushed once at the end.
+// ACC (accumulation mode when Lq*P exceeds one pass's record array and queries go in chunks):
+//   kAccNone  single pass: each row is stored once from registers;
+//   kAccRmw   fp32 storage: pass 0 stores the rows, later passes read-add-write them in global memory
+//             (the rows belong to this workgroup alone, passes are separated by __syncthreads, and
+//             they stay in L2) — no LDS tile, so several workgroups fit per CU;
+//   kAccTile  bf16 storage: rows accumulate in an fp32 LDS tile and are rounded ONCE at the flush.
 // ------------------------------------------------------------------------------------------
 constexpr int kSBlock = 512;
 constexpr int kSWaves = kSBlock / kWave;
+constexpr int kAccNone = 0, kAccRmw = 1, kAccTile = 2;
 struct alignas(8) SRec { float w; int q; };
 
 // role-B sizing: single pass while 4*Lq*P records (8 B) fit beside the histogram in 64 KB of LDS
 constexpr int kSinglePPT = 3;               // points per thread: 3*512 = 1536 points, 48 KB of records
 constexpr int kSingleMaxPoints = kSinglePPT * 512;
-constexpr int kSingleMaxRows = 1920;        // 15 KB of histogram + prefix
+constexpr int kSingleMaxRows = 1920;        // 15 KB of histogram + prefix (rows per workgroup)
 constexpr int kMultiRows = 256;             // 32 KB LDS tile
 constexpr int kMultiPPT = 6;                // 3072 points per pass, 96 KB of records
 
@@ -416,43 +438,67 @@ __device__ __forceinline__ float4 shfl_xor4(const float4 &v, int m)
 }
 __device__ __forceinline__ void add4(float4 &a, const float4 &b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
 
-// Step 4.  SLOTS lane-groups of 8 lanes share one row's segment; 8/SLOTS rows per wavefront trip.
-// A lane group takes its records four at a time: 4 record reads, then 4 independent 128-B row
-// loads in flight, then the FMAs — one memory round trip per 4*SLOTS records of a row.
-template <int SLOTS, bool MULTIPASS, typename VT>
+// Step 4.  SLOTS lane-groups of 8 lanes share one row's segment; 8/SLOTS rows per wavefront trip and
+// TWO trips' rows in flight (A and B).  A lane group takes CH records of each row at a time: the
+// record reads, then 2*CH independent 128-B row loads, then the FMAs — one memory round trip per
+// CH*SLOTS records of two rows.  (A balanced "linear" variant — the sorted records cut evenly over
+// the lane groups, partial row runs combined in a fix-up phase — was measured and is not faster:
+// its per-record run bookkeeping costs what the load imbalance costs here; profiles/r01_notes.md.)
+template <int SLOTS, int ACC, typename VT>
 __device__ __forceinline__ void gather_rows(const VT *__restrict__ go_base, VT *__restrict__ gv_base,
                                             const int *cnt, const int *start, const SRec *rec, float *tile,
                                             int npx, int row_stride, bool first_pass)
 {
     constexpr int DPW = 8 / SLOTS;
+    constexpr int CH = 4;
+    constexpr int RSTEP = kSWaves * DPW;                     // rows per workgroup trip
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int dsub = lane / (SLOTS * 8), slot = (lane >> 3) % SLOTS, j = lane & 7;
-    for (int d = wave * DPW + dsub; d < npx; d += kSWaves * DPW) {
-        const int n = cnt[d];
-        const SRec *r = rec + start[d];
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int i0 = slot; i0 < n; i0 += 4 * SLOTS) {
-            SRec rr[4]; float4 g[4];
+    for (int dA = wave * DPW + dsub; dA < npx; dA += 2 * RSTEP) {
+        const int dB = dA + RSTEP;
+        const bool hasB = dB < npx;
+        const int nA = cnt[dA], nB = hasB ? cnt[dB] : 0;
+        const SRec *rA = rec + start[dA], *rB = rec + (hasB ? start[dB] : 0);
+        float4 accA = make_float4(0.f, 0.f, 0.f, 0.f), accB = accA;
+        const int nmax = max(nA, nB);
+        for (int i0 = slot; i0 < nmax; i0 += CH * SLOTS) {
+            SRec ra[CH], rb[CH]; float4 ga[CH], gb[CH];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { rr[u].w = 0.f; rr[u].q = -1; if (i0 + u * SLOTS < n) rr[u] = r[i0 + u * SLOTS]; }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float4 t = Row<VT>::load(go_base + (long long)(rr[u].q >= 0 ? rr[u].q : 0) * row_stride);
-                const bool ok = rr[u].q >= 0;
-                g[u] = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
+            for (int u = 0; u < CH; ++u) {
+                ra[u].w = 0.f; ra[u].q = -1; rb[u] = ra[u];
+                if (i0 + u * SLOTS < nA) ra[u] = rA[i0 + u * SLOTS];
+                if (i0 + u * SLOTS < nB) rb[u] = rB[i0 + u * SLOTS];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) fma4(acc, rr[u].w, g[u]);
+            for (int u = 0; u < CH; ++u) {
+                const float4 ta = Row<VT>::load(go_base + (long long)(ra[u].q >= 0 ? ra[u].q : 0) * row_stride);
+                const float4 tb = Row<VT>::load(go_base + (long long)(rb[u].q >= 0 ? rb[u].q : 0) * row_stride);
+                const bool oa = ra[u].q >= 0, ob = rb[u].q >= 0;
+                ga[u] = make_float4(oa ? ta.x : 0.f, oa ? ta.y : 0.f, oa ? ta.z : 0.f, oa ? ta.w : 0.f);
+                gb[u] = make_float4(ob ? tb.x : 0.f, ob ? tb.y : 0.f, ob ? tb.z : 0.f, ob ? tb.w : 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < CH; ++u) { fma4(accA, ra[u].w, ga[u]); fma4(accB, rb[u].w, gb[u]); }
         }
-        if (SLOTS >= 2) add4(acc, shfl_xor4(acc, 8));
-        if (SLOTS >= 4) add4(acc, shfl_xor4(acc, 16));
-        if (SLOTS >= 8) add4(acc, shfl_xor4(acc, 32));
+        if (SLOTS >= 2) { add4(accA, shfl_xor4(accA, 8)); add4(accB, shfl_xor4(accB, 8)); }
+        if (SLOTS >= 4) { add4(accA, shfl_xor4(accA, 16)); add4(accB, shfl_xor4(accB, 16)); }
+        if (SLOTS >= 8) { add4(accA, shfl_xor4(accA, 32)); add4(accB, shfl_xor4(accB, 32)); }
         if (slot == 0) {
-            if (MULTIPASS) {
-                float4 *t = reinterpret_cast<float4 *>(tile) + d * 8 + j;   // same lane owns it in every pass
-                if (first_pass) *t = acc; else { float4 o = *t; add4(o, acc); *t = o; }
+            if (ACC == kAccTile) {
+                float4 *tA = reinterpret_cast<float4 *>(tile) + dA * 8 + j;
+                if (first_pass) *tA = accA; else { float4 o = *tA; add4(o, accA); *tA = o; }
+                if (hasB) {
+                    float4 *tB = reinterpret_cast<float4 *>(tile) + dB * 8 + j;
+                    if (first_pass) *tB = accB; else { float4 o = *tB; add4(o, accB); *tB = o; }
+                }
             } else {
-                Row<VT>::store(gv_base + (long long)d * row_stride, acc);
+                VT *pA = gv_base + (long long)dA * row_stride, *pB = gv_base + (long long)dB * row_stride;
+                if (ACC == kAccRmw && !first_pass) {
+                    add4(accA, Row<VT>::load(pA));
+                    if (hasB) add4(accB, Row<VT>::load(pB));
+                }
+                Row<VT>::store(pA, accA);
+                if (hasB) Row<VT>::store(pB, accB);
             }
         }
     }
@@ -461,7 +507,7 @@ __device__ __forceinline__ void gather_rows(const VT *__restrict__ go_base, VT *
 // PPT = sampling points per thread per pass: all of a thread's points are loaded up front (2*PPT
 // independent global loads in flight), their taps and histogram ranks stay in registers between
 // step 1 and step 3, so loc / attn are read exactly once and step 3 needs no atomics.
-template <bool MULTIPASS, int PPT, typename VT>
+template <int ACC, int PPT, typename VT>
 __device__ __forceinline__ void bwd_value_body(
     const VT *__restrict__ grad_out, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ level_start, const float *__restrict__ loc,
@@ -469,9 +515,9 @@ __device__ __forceinline__ void bwd_value_body(
     VT *__restrict__ grad_value, int ti, int W, int l, int pr, unsigned char *smem)
 {
     constexpr int NPC = PPT * kSBlock;                       // points per pass
-    // LDS: [tile: tp_cap*32 floats if MULTIPASS] [cnt tp_cap] [start tp_cap] [wsum 16] [rec 4*NPC]
+    // LDS: [tile: tp_cap*32 floats if kAccTile] [cnt tp_cap] [start tp_cap] [wsum 16] [rec]
     float *tile = reinterpret_cast<float *>(smem);
-    int *cnt = reinterpret_cast<int *>(smem + (MULTIPASS ? (size_t)tp_cap * kD * 4 : 0));
+    int *cnt = reinterpret_cast<int *>(smem + (ACC == kAccTile ? (size_t)tp_cap * kD * 4 : 0));
     int *start = cnt + tp_cap;
     int *wsum = start + tp_cap;
     SRec *rec = reinterpret_cast<SRec *>(wsum + 16);
@@ -561,15 +607,15 @@ __device__ __forceinline__ void bwd_value_body(
         // ---- 4. gather; lanes per row chosen from the mean segment length (uniform) ----
         const int mean2 = (2 * total) / npx;                                  // 2 x mean records per row
         const bool first = (c0 == 0);
-        if (mean2 <= 8)       gather_rows<1, MULTIPASS, VT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
-        else if (mean2 <= 16) gather_rows<2, MULTIPASS, VT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
-        else if (mean2 <= 32) gather_rows<4, MULTIPASS, VT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
-        else                  gather_rows<8, MULTIPASS, VT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
-        if (MULTIPASS) __syncthreads();
+        if (mean2 <= 8)       gather_rows<1, ACC, VT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
+        else if (mean2 <= 16) gather_rows<2, ACC, VT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
+        else if (mean2 <= 32) gather_rows<4, ACC, VT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
+        else                  gather_rows<8, ACC, VT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
+        if (ACC != kAccNone) __syncthreads();                // next pass reuses the LDS arrays / re-reads rows
         MSDA_STAMP(5);
     }
 
-    if (MULTIPASS) {
+    if (ACC == kAccTile) {
         // ---- flush the LDS tile: each row once, coalesced ----
         for (int i = tid; i < npx * 8; i += kSBlock) {
             const int d = i >> 3, jj = i & 7;
@@ -579,7 +625,7 @@ __device__ __forceinline__ void bwd_value_body(
     }
 }
 
-template <bool MULTIPASS, int PPT, typename VT>
+template <int ACC, int PPT, typename VT>
 __global__ __launch_bounds__(kSBlock) void bwd_value_d32_kernel(
     const VT *__restrict__ grad_out, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ level_start, const float *__restrict__ loc,
@@ -588,7 +634,7 @@ __global__ __launch_bounds__(kSBlock) void bwd_value_d32_kernel(
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // grid = (W ranges, L levels, N*M pairs)
-    bwd_value_body<MULTIPASS, PPT, VT>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, tp_cap,
+    bwd_value_body<ACC, PPT, VT>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, tp_cap,
                                    grad_value, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y, (int)blockIdx.z, smem);
 }
 
@@ -596,7 +642,7 @@ __global__ __launch_bounds__(kSBlock) void bwd_value_d32_kernel(
 // (grad_value), the rest role A (grad_sampling_loc / grad_attn_weight).  The two roles share no
 // data, so this is plain concurrency inside one grid — it removes a dependent kernel boundary
 // (~1.5 us) and lets role A's short workgroups fill the CUs around role B's longer ones.
-template <int SPLIT, typename VT>
+template <int SPLIT, int ACC, typename VT>
 __global__ __launch_bounds__(kSBlock) void bwd_fused_d32_kernel(
     const VT *__restrict__ grad_out, const VT *__restrict__ value,
     const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
@@ -608,7 +654,7 @@ __global__ __launch_bounds__(kSBlock) void bwd_fused_d32_kernel(
     const int bid = (int)blockIdx.x;
     if (bid < nB) {
         const int ti = bid % W, l = (bid / W) % L, pr = bid / (W * L);
-        bwd_value_body<false, kSinglePPT, VT>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, tp_cap,
+        bwd_value_body<ACC, kSinglePPT, VT>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, tp_cap,
                                           grad_value, ti, W, l, pr, smem);
     } else {
         bwd_query_body<SPLIT, false, kSBlock, VT>(grad_out, value, shapes, level_start, loc, attn, S, M, L, Lq, P, items,
@@ -672,6 +718,42 @@ static int launch_fwd_d32_t(const VT *value, const int64_t *shapes, const int64_
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// Role-B plan (host side; only S, the batch and Lq*P are known here — the level geometry lives on
+// the device): W ranges per level, PPT points per thread per pass, accumulation mode.
+struct ValuePlan { int W, tp_cap, ppt, acc; size_t lds; };
+
+template <typename VT>
+static ValuePlan plan_value(int N, int S, int M, int L, int Lq, int P, int target_wgs)
+{
+    ValuePlan pl;
+    const int NP = Lq * P, pairs_levels = N * M * L;
+    const bool multipass = NP > kSingleMaxPoints;
+    pl.acc = !multipass ? kAccNone : (sizeof(VT) == 4 ? kAccRmw : kAccTile);
+    if (pl.acc == kAccTile) {
+        pl.tp_cap = kMultiRows;
+        pl.W = ceil_div(S, pl.tp_cap);
+        pl.ppt = kMultiPPT;
+    } else {
+        pl.W = max(ceil_div(S, kSingleMaxRows), ceil_div(target_wgs, pairs_levels));
+        pl.W = max(1, min(pl.W, max(1, S / 16)));
+        pl.tp_cap = ceil_div(S, pl.W);
+        // few workgroups and many passes: take twice the points per pass (one workgroup per CU anyway)
+        pl.ppt = (multipass && (long long)pairs_levels * pl.W <= 512) ? kMultiPPT : kSinglePPT;
+    }
+    pl.tp_cap = (pl.tp_cap + 3) & ~3;                                 // keeps the LDS arrays 16-B aligned
+    const int pass_points = min(NP, pl.ppt * kSBlock);
+    pl.lds = (pl.acc == kAccTile ? (size_t)pl.tp_cap * kD * 4 : 0) + (2 * (size_t)pl.tp_cap + 16) * 4 +
+             (size_t)4 * pass_points * sizeof(SRec);
+    return pl;
+}
+
+static int allow_lds(const void *fn, size_t bytes)
+{
+    if (bytes <= 64 * 1024) return MSDA_OK;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    return e == hipSuccess ? MSDA_OK : set_error(MSDA_ERR_LAUNCH, hipGetErrorString(e));
+}
+
 template <typename VT>
 static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *shapes,
                             const int64_t *level_start, const float *loc, const float *attn, int N, int S,
@@ -687,62 +769,43 @@ static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *
         const char *v = getenv("MSDA_BWD_MODE");
         return (v && !strcmp(v, "atomic")) ? 2 : (v && !strcmp(v, "split")) ? 1 : 0; }();
     const int bwd_mode = (bwd_mode_env == 2 && sizeof(VT) != 4) ? 0 : bwd_mode_env;
-    const bool atomic_mode = bwd_mode == 2;
     static const int target_wgs = [] { int v = env_int("MSDA_BWD_WGS", 256); return v < 1 ? 1 : v; }();
     const int split = pick_split(items, LP);
     const int ps = pow2_shift(P), lps = pow2_shift(LP), ms = pow2_shift(M);
 
-    if (atomic_mode) {
+    if (bwd_mode == 2) {
         hipError_t e = hipMemsetAsync(grad_value, 0, sizeof(VT) * (size_t)N * S * M * kD, stream);
         if (e != hipSuccess) return set_error(MSDA_ERR_LAUNCH, hipGetErrorString(e));
     } else {
-        // role B: counting sort + gather, W pixel ranges per level (see the kernel's header)
-        const int NP = Lq * P;
-        const bool multipass = NP > kSingleMaxPoints;
-        const int pairs_levels = N * M * L;
-        int W, tp_cap;
-        if (!multipass) {
-            W = max(ceil_div(S, kSingleMaxRows), ceil_div(target_wgs, pairs_levels));
-            W = max(1, min(W, max(1, S / 16)));
-            tp_cap = ceil_div(S, W);
-        } else {
-            tp_cap = kMultiRows;
-            W = ceil_div(S, tp_cap);
-        }
-        tp_cap = (tp_cap + 3) & ~3;                                   // keeps the LDS arrays 16-B aligned
-        const dim3 grid((unsigned)W, (unsigned)L, (unsigned)(N * M));
-        const size_t lds = (multipass ? (size_t)tp_cap * kD * 4 : 0) + (2 * (size_t)tp_cap + 16) * 4 +
-                           (size_t)4 * (multipass ? kMultiPPT : kSinglePPT) * kSBlock * sizeof(SRec);
-        if (!multipass && bwd_mode == 0) {
-            // ---- whole backward in one launch: nB role-B workgroups, then the role-A ones ----
-            const int ipw = 64 / split;                                 // 512-thread role-A workgroups
-            const size_t lds_a = (size_t)ipw * item_stride + (size_t)ipw * LP * 16;
-            const long long nB = (long long)W * pairs_levels, nA = (items + ipw - 1) / ipw;
-            if (nB + nA > 0x7fffffffLL) return set_error(MSDA_ERR_ARGUMENT, "msda backward (d32): grid too large");
+        const ValuePlan pl = plan_value<VT>(N, S, M, L, Lq, P, target_wgs);
+        const long long nB = (long long)pl.W * N * M * L;
+        // ---- whole backward in one launch when role A's workgroups can share the CUs (LDS) ----
+        const int ipw_f = 64 / split;                                   // 512-thread role-A workgroups
+        const size_t lds_a = (size_t)ipw_f * item_stride + (size_t)ipw_f * LP * 16;
+        const long long nA = (items + ipw_f - 1) / ipw_f;
+        if (bwd_mode == 0 && pl.ppt == kSinglePPT && pl.acc != kAccTile && nB + nA <= 0x7fffffffLL) {
             const dim3 fgrid((unsigned)(nB + nA));
-            const size_t flds = lds > lds_a ? lds : lds_a;
-#define MSDA_LAUNCH_F(SP)                                                                              \
-            hipLaunchKernelGGL((bwd_fused_d32_kernel<SP, VT>), fgrid, dim3(kSBlock), flds, stream, grad_out, value,  \
-                               shapes, level_start, loc, attn, S, M, L, Lq, P, items, ps, lps, ms, tp_cap, W,    \
-                               (int)nB, grad_value, grad_loc, grad_attn)
-            if (split == 4) MSDA_LAUNCH_F(4); else if (split == 2) MSDA_LAUNCH_F(2); else MSDA_LAUNCH_F(1);
+            const size_t flds = pl.lds > lds_a ? pl.lds : lds_a;
+#define MSDA_LAUNCH_F(SP, AC)                                                                          \
+            hipLaunchKernelGGL((bwd_fused_d32_kernel<SP, AC, VT>), fgrid, dim3(kSBlock), flds, stream, grad_out,  \
+                               value, shapes, level_start, loc, attn, S, M, L, Lq, P, items, ps, lps, ms,        \
+                               pl.tp_cap, pl.W, (int)nB, grad_value, grad_loc, grad_attn)
+            if (pl.acc == kAccNone) { if (split == 4) MSDA_LAUNCH_F(4, kAccNone); else if (split == 2) MSDA_LAUNCH_F(2, kAccNone); else MSDA_LAUNCH_F(1, kAccNone); }
+            else                    { if (split == 4) MSDA_LAUNCH_F(4, kAccRmw); else if (split == 2) MSDA_LAUNCH_F(2, kAccRmw); else MSDA_LAUNCH_F(1, kAccRmw); }
 #undef MSDA_LAUNCH_F
             return check_launch("msda backward (d32, fused)");
         }
-        if (multipass) {
-            static thread_local size_t granted = 0;
-            if (lds > granted) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bwd_value_d32_kernel<true, kMultiPPT, VT>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                if (e != hipSuccess) return set_error(MSDA_ERR_LAUNCH, hipGetErrorString(e));
-                granted = lds;
-            }
-            hipLaunchKernelGGL((bwd_value_d32_kernel<true, kMultiPPT, VT>), grid, dim3(kSBlock), lds, stream,
-                               grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, ps, tp_cap, grad_value);
-        } else {
-            hipLaunchKernelGGL((bwd_value_d32_kernel<false, kSinglePPT, VT>), grid, dim3(kSBlock), lds, stream,
-                               grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, ps, tp_cap, grad_value);
-        }
+        // ---- role B as its own launch (large record arrays / bf16 tile / A-B knob) ----
+        const dim3 grid((unsigned)pl.W, (unsigned)L, (unsigned)(N * M));
+#define MSDA_LAUNCH_B(AC, PPT_)                                                                        \
+        do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_value_d32_kernel<AC, PPT_, VT>), pl.lds)) return rc; \
+             hipLaunchKernelGGL((bwd_value_d32_kernel<AC, PPT_, VT>), grid, dim3(kSBlock), pl.lds, stream, grad_out,    \
+                                shapes, level_start, loc, attn, S, M, L, Lq, P, ps, pl.tp_cap, grad_value); } while (0)
+        if (pl.acc == kAccNone) MSDA_LAUNCH_B(kAccNone, kSinglePPT);
+        else if (pl.acc == kAccTile) MSDA_LAUNCH_B(kAccTile, kMultiPPT);
+        else if (pl.ppt == kMultiPPT) MSDA_LAUNCH_B(kAccRmw, kMultiPPT);
+        else MSDA_LAUNCH_B(kAccRmw, kSinglePPT);
+#undef MSDA_LAUNCH_B
         if (int rc = check_launch("msda backward (d32, grad_value sort+gather)")) return rc;
     }
     {
@@ -752,8 +815,8 @@ static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *
 #define MSDA_LAUNCH_A(SP, AT)                                                                          \
         hipLaunchKernelGGL((bwd_query_d32_kernel<SP, AT, VT>), grid, block, lds, stream, grad_out, value, shapes, \
                            level_start, loc, attn, S, M, L, Lq, P, items, ps, lps, ms, grad_value, grad_loc, grad_attn)
-        if (atomic_mode) { if (split == 4) MSDA_LAUNCH_A(4, true); else if (split == 2) MSDA_LAUNCH_A(2, true); else MSDA_LAUNCH_A(1, true); }
-        else             { if (split == 4) MSDA_LAUNCH_A(4, false); else if (split == 2) MSDA_LAUNCH_A(2, false); else MSDA_LAUNCH_A(1, false); }
+        if (bwd_mode == 2) { if (split == 4) MSDA_LAUNCH_A(4, true); else if (split == 2) MSDA_LAUNCH_A(2, true); else MSDA_LAUNCH_A(1, true); }
+        else               { if (split == 4) MSDA_LAUNCH_A(4, false); else if (split == 2) MSDA_LAUNCH_A(2, false); else MSDA_LAUNCH_A(1, false); }
 #undef MSDA_LAUNCH_A
     }
     return check_launch("msda backward (d32, query-major)");
