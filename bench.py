@@ -147,9 +147,12 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
         args.gpus = world
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    harness.init_process_group("nccl", device)
+    # one rank per GPU; MSDA_BENCH_BACKEND=gloo lets several ranks rehearse the N>1 path on one card
+    backend = os.environ.get("MSDA_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    harness.init_process_group(backend, device)
 
     from uvhand_amd import _native
     from uvhand_amd.functions import MSDeformAttnBF16Function, MSDeformAttnFunction
