@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""Synthetic data-parallel TRAIN STEP around the op (SURVEY.md §8d config C4, §8b "harness counterpart").
+
+Not part of the product and not the bench line: a harness that exercises the drop-in module the way the
+reference's training loop does — engine.py:590-648: forward -> loss -> backward -> clip_grad_norm_(0.1)
+-> AdamW step — under DistributedDataParallel on RCCL (main.py:96-98 uses DDP the same way), so that
+the op's stream-ordered, sync-free behaviour under DDP's overlapped gradient all-reduce is covered.
+
+    python tools/ddp_step.py                                   # 1 GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+           tools/ddp_step.py --ballast-mb 900                 # 8 GPUs, Swin-L-sized gradient volume
+    MSDA_BENCH_BACKEND=gloo python -m torch.distributed.run --nproc-per-node 2 ... tools/ddp_step.py   # rehearsal on 1 GPU
+
+The model is the transformer part of the reference with the backbone replaced by synthetic feature
+pyramids: `--enc` encoder layers (MSDeformAttn self-attention over all S pixels + FFN,
+models/arctic_transformer.py:261-300) and `--dec` decoder layers (MSDeformAttn cross-attention of
+`--queries` queries + FFN, :334-391; the decoder's nn.MultiheadAttention self-attention is included).
+`--ballast-mb` adds a parameter block whose gradient volume stands for the Swin-L backbone (≈0.9 GB).
+Per rank: batch 1 x window `--window` frames folded into the batch (tempo_inference_dataset.py:112-161),
+224x224 crops -> levels 28/14/7/4 (S = 1045), i.e. BASELINE cfg-4.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+from torch import nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from uvhand_amd import harness                      # noqa: E402
+from uvhand_amd.modules import MSDeformAttn         # noqa: E402
+
+
+class EncoderLayer(nn.Module):
+    def __init__(self, d=256, ffn=1024, levels=4, heads=8, points=4):
+        super().__init__()
+        self.self_attn = MSDeformAttn(d, levels, heads, points)
+        self.norm1, self.norm2 = nn.LayerNorm(d), nn.LayerNorm(d)
+        self.linear1, self.linear2 = nn.Linear(d, ffn), nn.Linear(ffn, d)
+
+    def forward(self, src, pos, ref, shapes, lsi):
+        src = self.norm1(src + self.self_attn(src + pos, ref, src, shapes, lsi))
+        return self.norm2(src + self.linear2(torch.relu(self.linear1(src))))
+
+
+class DecoderLayer(nn.Module):
+    def __init__(self, d=256, ffn=1024, levels=4, heads=8, points=4):
+        super().__init__()
+        self.cross_attn = MSDeformAttn(d, levels, heads, points)
+        self.self_attn = nn.MultiheadAttention(d, heads, batch_first=True)
+        self.norm1, self.norm2, self.norm3 = nn.LayerNorm(d), nn.LayerNorm(d), nn.LayerNorm(d)
+        self.linear1, self.linear2 = nn.Linear(d, ffn), nn.Linear(ffn, d)
+
+    def forward(self, tgt, qpos, ref, memory, shapes, lsi):
+        q = tgt + qpos
+        tgt = self.norm2(tgt + self.self_attn(q, q, tgt, need_weights=False)[0])
+        tgt = self.norm1(tgt + self.cross_attn(tgt + qpos, ref, memory, shapes, lsi))
+        return self.norm3(tgt + self.linear2(torch.relu(self.linear1(tgt))))
+
+
+class SyntheticDeformableStack(nn.Module):
+    def __init__(self, enc, dec, queries, ballast_mb, d=256):
+        super().__init__()
+        self.enc = nn.ModuleList(EncoderLayer(d) for _ in range(enc))
+        self.dec = nn.ModuleList(DecoderLayer(d) for _ in range(dec))
+        self.query_embed = nn.Embedding(queries, 2 * d)
+        self.ref_head = nn.Linear(d, 2)
+        self.out_head = nn.Linear(d, 64)
+        n = int(ballast_mb * 1e6 / 4)
+        self.ballast = nn.Parameter(torch.zeros(n)) if n else None
+
+    def forward(self, src, pos, enc_ref, shapes, lsi):
+        for layer in self.enc:
+            src = layer(src, pos, enc_ref, shapes, lsi)
+        n = src.shape[0]
+        qpos, tgt = self.query_embed.weight.chunk(2, dim=-1)
+        qpos, tgt = qpos.expand(n, -1, -1), tgt.expand(n, -1, -1)
+        ref = self.ref_head(qpos).sigmoid()[:, :, None, :].expand(-1, -1, shapes.shape[0], -1)
+        for layer in self.dec:
+            tgt = layer(tgt, qpos, ref, src, shapes, lsi)
+        out = self.out_head(tgt)
+        loss = out.float().pow(2).mean()
+        if self.ballast is not None:
+            loss = loss + 0.0 * self.ballast.sum()          # gives the ballast a (zero) gradient to reduce
+        return loss
+
+
+def encoder_reference_points(shapes_list, device):
+    """Pixel-centre grid per level, normalised (models/arctic_transformer.py:310-323 with valid_ratio 1)."""
+    refs = []
+    for h, w in shapes_list:
+        ys, xs = torch.meshgrid(torch.linspace(0.5, h - 0.5, h, device=device) / h,
+                                torch.linspace(0.5, w - 0.5, w, device=device) / w, indexing="ij")
+        refs.append(torch.stack((xs.reshape(-1), ys.reshape(-1)), -1))
+    ref = torch.cat(refs, 0)                                   # [S, 2]
+    return ref[None, :, None, :].expand(1, -1, len(shapes_list), -1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--window", type=int, default=32, help="frames per rank folded into the batch")
+    ap.add_argument("--queries", type=int, default=300)
+    ap.add_argument("--enc", type=int, default=6)
+    ap.add_argument("--dec", type=int, default=6)
+    ap.add_argument("--ballast-mb", type=float, default=0.0)
+    ap.add_argument("--levels", default="28,14,7,4")
+    args = ap.parse_args()
+
+    rank, local_rank, world = harness.dist_env()
+    backend = os.environ.get("MSDA_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    distributed = harness.init_process_group(backend, device)
+
+    torch.manual_seed(harness.rank_seed(0, 0))                  # identical initial weights on every rank
+    model = SyntheticDeformableStack(args.enc, args.dec, args.queries, args.ballast_mb).to(device)
+    if distributed:
+        model = nn.parallel.DistributedDataParallel(model, device_ids=[dev_index] if backend == "nccl" else None,
+                                                    gradient_as_bucket_view=True)
+    opt = torch.optim.AdamW(model.parameters(), lr=2e-5, weight_decay=1e-4)
+
+    shapes_list = [(int(x), int(x)) for x in args.levels.split(",")]
+    shapes = torch.tensor(shapes_list, dtype=torch.long, device=device)
+    lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+    S = int(shapes.prod(1).sum())
+    g = torch.Generator(device="cpu").manual_seed(harness.rank_seed(100, rank))     # each rank: its own frames
+    src = torch.randn(args.window, S, 256, generator=g).to(device)
+    pos = torch.randn(args.window, S, 256, generator=g).to(device) * 0.1
+    enc_ref = encoder_reference_points(shapes_list, device).expand(args.window, -1, -1, -1).contiguous()
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = model(src, pos, enc_ref, shapes, lsi)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 0.1)
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        loss = step()
+    harness.barrier(device)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    harness.barrier(device)
+    elapsed = harness.max_over_ranks(time.perf_counter() - t0, device)
+    total = harness.sum_over_ranks(args.window * args.steps, device)
+    finite = bool(torch.isfinite(loss.detach()).item())
+    if rank == 0:
+        print(json.dumps({"harness": "ddp_step", "n_gpus": world, "frames_per_s": total / elapsed,
+                          "ms_per_step": 1e3 * elapsed / args.steps, "steps": args.steps,
+                          "per_rank": {"window": args.window, "S": S, "queries": args.queries, "enc": args.enc,
+                                       "dec": args.dec, "ballast_mb": args.ballast_mb},
+                          "backend": backend if distributed else None, "loss_finite": finite}))
+    if distributed:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
