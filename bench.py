@@ -51,8 +51,37 @@ def algorithmic_bytes(N, S, M, D, L, Lq, P, e=4, el=4):
     return fwd, bwd
 
 
-def make_inputs(workload, seed, device):
-    """Synthetic inputs, distributions of models/ops/test.py:33-36 (distribution A)."""
+def model_like_locations(N, shapes, M, Lq, P, g):
+    """SURVEY.md §8d distribution B: what the UVHand transformers actually feed the op.  Decoder regime
+    (Lq != S): reference points ~ U(-1, 1) per query (two-stage sigmoid()*2-1, arctic_transformer.py:230),
+    so many taps fall outside the maps; encoder regime (Lq == S): the pixel-centre grid (:314-322).  Offsets
+    follow the module's initial pattern (modules/ms_deform_attn.py:64-70): point k of head m sits k+1 pixels
+    along head m's direction, plus N(0, 0.5 px) jitter."""
+    import math
+    L = len(shapes)
+    S = sum(h * w for h, w in shapes)
+    if Lq == S:
+        refs = []
+        for h, w in shapes:
+            ys, xs = torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w, indexing="ij")
+            refs.append(torch.stack((xs.reshape(-1), ys.reshape(-1)), -1))
+        ref = torch.cat(refs, 0)[None].expand(N, -1, -1)
+    else:
+        ref = torch.rand(N, Lq, 2, generator=g) * 2 - 1
+    theta = torch.arange(M, dtype=torch.float32) * (2 * math.pi / M)
+    dirs = torch.stack((theta.cos(), theta.sin()), -1)
+    dirs = dirs / dirs.abs().max(-1, keepdim=True)[0]                                  # [M, 2]
+    k = torch.arange(1, P + 1, dtype=torch.float32)
+    off_px = dirs[:, None, None, :] * k[None, None, :, None]                           # [M, 1, P, 2]
+    off_px = off_px.expand(M, L, P, 2) + 0.0
+    wh = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float32)                # [L, 2]
+    jitter = torch.randn(N, Lq, M, L, P, 2, generator=g) * 0.5
+    return ref[:, :, None, None, None, :] + (off_px[None, None] + jitter) / wh[None, None, None, :, None, :]
+
+
+def make_inputs(workload, seed, device, dist_kind="uniform"):
+    """Synthetic inputs.  "uniform": the distributions of models/ops/test.py:33-36 (SURVEY.md §8d,
+    distribution A, the headline); "model": distribution B (model_like_locations)."""
     N, shapes, M, D, Lq, P = WORKLOADS[workload]
     g = torch.Generator(device="cpu").manual_seed(seed)
     shapes_t = torch.tensor(shapes, dtype=torch.long)
@@ -60,6 +89,8 @@ def make_inputs(workload, seed, device):
     S, L = int(shapes_t.prod(1).sum()), len(shapes)
     value = torch.rand(N, S, M, D, generator=g) * 0.01
     loc = torch.rand(N, Lq, M, L, P, 2, generator=g)
+    if dist_kind == "model":
+        loc = model_like_locations(N, shapes, M, Lq, P, g).contiguous()
     attn = torch.rand(N, Lq, M, L, P, generator=g) + 1e-5
     attn = attn / attn.sum((-1, -2), keepdim=True)
     go = torch.rand(N, Lq, M * D, generator=g)
@@ -73,6 +104,34 @@ def usable_cores():
         return len(os.sched_getaffinity(0))
     except AttributeError:
         return os.cpu_count() or 1
+
+
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def copy_bandwidth_gbs(device, nbytes=1 << 30, iters=10):
+    """Achieved device-to-device copy rate (read + write bytes / time): the practical HBM ceiling
+    on this box, next to the 8 TB/s spec the roofline fraction is quoted against."""
+    src = torch.empty(nbytes // 4, dtype=torch.float32, device=device).normal_()
+    dst = torch.empty_like(src)
+    for _ in range(2):
+        dst.copy_(src)
+    torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        dst.copy_(src)
+    e1.record()
+    e1.synchronize()
+    return 2.0 * nbytes * iters / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
 def time_cpu_baseline(workload, budget_s=8.0):
@@ -98,6 +157,7 @@ def time_cpu_baseline(workload, budget_s=8.0):
     best = max(runs, key=lambda r: r["samples_per_s"])
     return {"value": best["samples_per_s"], "unit": "samples/s", "cores": best["threads"], "kind": "port",
             "ms_per_step": best["ms_per_step"], "runs": runs, "host_cpus": os.cpu_count(),
+            "cpu_model": cpu_model_name(),
             "sample": "%d fwd+bwd calls of the %s batch (N=%d) through oracle/torch_fallback.py "
                       "(restatement of ms_deform_attn_core_pytorch, fp32, %d intra-op threads)"
                       % (best["calls"], workload, N, best["threads"])}
@@ -136,6 +196,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="time the eager autograd path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-iters", type=int, default=200)
+    ap.add_argument("--locations", default="uniform", choices=["uniform", "model"],
+                    help="sampling-location distribution: uniform in [0,1) (headline) or model-like (SURVEY §8d B)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="storage type of value/out/grad tensors (bf16 = BASELINE config 3, MSDeformAttnBF16Function)")
     args = ap.parse_args()
@@ -161,7 +223,7 @@ def main():
     esize = 2 if bf16 else 4
     fn_apply = MSDeformAttnBF16Function.apply if bf16 else MSDeformAttnFunction.apply
 
-    _, d, dims = make_inputs(args.workload, harness.rank_seed(1000, rank), device)
+    _, d, dims = make_inputs(args.workload, harness.rank_seed(1000, rank), device, args.locations)
     N, S, M, D, L, Lq, P = dims
     value = (d["value"].to(torch.bfloat16) if bf16 else d["value"]).requires_grad_(True)
     loc = d["loc"].requires_grad_(True)
@@ -243,6 +305,7 @@ def main():
             "config": {"workload": "%s: N=%d/GPU, levels %s (S=%d), Lq=%d, M=%d, D=%d, P=%d, %s"
                                    % (args.workload, N, "/".join(str(h) for h, _ in WORKLOADS[args.workload][1]),
                                       S, Lq, M, D, P, "fp32" if not bf16 else "bf16 storage / fp32 accumulate"),
+                       "locations": args.locations,
                        "step": "MSDeformAttnFunction.apply forward + backward (3 grads)",
                        "launch": "hipGraph replay" if graph is not None else "eager autograd",
                        "sharding": "batch-sharded, no collective"},
@@ -254,6 +317,8 @@ def main():
                                 "GBps": fwd_b / (kt["fwd"] * 1e-3) / 1e9},
                         "bwd": {"ms": kt["bwd"], "algorithmic_bytes": bwd_b, "GBps": ach}},
         }
+        if world == 1:
+            result["roofline"]["copy_GBps_measured"] = copy_bandwidth_gbs(device)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = time_cpu_baseline(args.workload)
             result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""One MSDeformAttn MODULE forward+backward loop (the op plus its four nn.Linear, softmax and location
+arithmetic) for profiling:  rocprofv3 --kernel-trace --stats -- python3 tools/module_step.py cfg4_encoder"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from bench import WORKLOADS
+from uvhand_amd.modules import MSDeformAttn
+
+name = sys.argv[1] if len(sys.argv) > 1 else "cfg4_encoder"
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+amp = os.environ.get("MODULE_AMP", "")            # "bf16": autocast + bf16 storage in the op
+N, shapes, M, D, Lq, P = WORKLOADS[name]
+dev = torch.device("cuda", 0)
+torch.manual_seed(0)
+mod = MSDeformAttn(M * D, len(shapes), M, P).to(dev)
+with torch.no_grad():
+    for p in mod.parameters():
+        p.add_(torch.randn_like(p) * 0.02)
+sh = torch.tensor(shapes, dtype=torch.long, device=dev)
+lsi = torch.cat((sh.new_zeros(1), sh.prod(1).cumsum(0)[:-1]))
+S = int(sh.prod(1).sum())
+q = torch.randn(N, Lq, M * D, device=dev, requires_grad=True)
+src = torch.randn(N, S, M * D, device=dev, requires_grad=True)
+ref = torch.rand(N, Lq, len(shapes), 2, device=dev)
+go = torch.randn(N, Lq, M * D, device=dev)
+for i in range(iters + 3):
+    if i == 3:
+        torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
+    mod.zero_grad(set_to_none=True); q.grad = src.grad = None
+    if amp == "bf16":
+        mod.bf16_storage = True
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = mod(q, ref, src, sh, lsi)
+        out.backward(go.to(out.dtype))
+    else:
+        out = mod(q, ref, src, sh, lsi)
+        out.backward(go)
+e1.record(); e1.synchronize()
+print("%s module fwd+bwd%s: %.1f us per step" % (name, " (autocast bf16 + bf16 storage)" if amp else "", e0.elapsed_time(e1) * 1e3 / iters))
