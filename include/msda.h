@@ -106,6 +106,18 @@ int msda_backward_bf16(const uint16_t *grad_out, const uint16_t *value, const in
                        uint16_t *grad_value, float *grad_sampling_loc, float *grad_attn_weight,
                        msda_stream_t stream);
 
+/* ---- Bracketing projections ----------------------------------------------------
+ * Weight and bias gradient of an fp32 nn.Linear  y[M,N] = x[M,K] . W[N,K]^T + b[N]:
+ *     grad_weight[N,K] = grad_out[M,N]^T . input[M,K]        grad_bias[N] = sum_m grad_out[m,:]
+ * i.e. the GEMM autograd issues for value_proj / sampling_offsets / attention_weights / output_proj
+ * (models/ops/modules/ms_deform_attn.py:96,100,101,139), as a split-M fp32-MFMA kernel with a
+ * fixed-order reduction (bitwise reproducible).  N and K must be multiples of 4; grad_bias may be
+ * NULL; `workspace` must hold msda_linear_wgrad_workspace_bytes(M, N, K) bytes (may be 0 -> NULL ok).
+ * The forward GEMM and the input gradient stay on the vendor BLAS. */
+unsigned long long msda_linear_wgrad_workspace_bytes(int M, int N, int K);
+int msda_linear_wgrad_f32(const float *grad_out, const float *input, int M, int N, int K,
+                          float *grad_weight, float *grad_bias, void *workspace, msda_stream_t stream);
+
 /* Thread-local description of the last failure on the calling thread ("" if none). */
 const char *msda_last_error(void);
 

@@ -1,0 +1,63 @@
+"""Weight / bias gradient kernel of the bracketing nn.Linear layers (msda_linear_wgrad_f32) against
+PyTorch's own fp64 result, and the autograd wrapper against nn.Linear."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("M,N,K", [(600, 256, 256), (600, 128, 256), (6120, 256, 256), (33440, 128, 256),
+                                    (37, 12, 20), (1, 4, 4), (70, 68, 132), (2400, 384, 256), (64, 64, 64)])
+def test_wgrad_matches_fp64(M, N, K):
+    from uvhand_amd import _native
+    g = torch.Generator().manual_seed(M + N + K)
+    dy = torch.randn(M, N, generator=g).cuda()
+    x = torch.randn(M, K, generator=g).cuda()
+    gw, gb = _native.linear_wgrad(dy, x)
+    ref_w = (dy.double().t() @ x.double()).cpu().numpy()
+    ref_b = dy.double().sum(0).cpu().numpy()
+    # fp32 MFMA = fp32 fma chain over M terms: error ~ sqrt(M) * 2^-24 of the sum of magnitudes
+    assert rel_err(gw.cpu().numpy(), ref_w) < 2e-6
+    assert rel_err(gb.cpu().numpy(), ref_b) < 2e-6
+    gw2, gb2 = _native.linear_wgrad(dy, x)
+    assert torch.equal(gw, gw2) and torch.equal(gb, gb2)            # fixed-order reduction: reproducible
+    gw3, none = _native.linear_wgrad(dy, x, want_bias=False)
+    assert none is None and torch.equal(gw, gw3)
+
+
+def test_wgrad_rejects_what_it_cannot_do():
+    from uvhand_amd import _native
+    with pytest.raises(RuntimeError):
+        _native.linear_wgrad(torch.randn(8, 6).cuda(), torch.randn(8, 8).cuda())     # N % 4 != 0
+    with pytest.raises(RuntimeError):
+        _native.linear_wgrad(torch.randn(8, 8).cuda().double(), torch.randn(8, 8).cuda().double())
+    gw, gb = _native.linear_wgrad(torch.empty(0, 8).cuda(), torch.empty(0, 12).cuda())
+    assert not gw.any() and not gb.any() and tuple(gw.shape) == (8, 12)
+
+
+def test_bracket_linear_equals_nn_linear():
+    from uvhand_amd.functions.linear_func import bracket_linear
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(256, 128).cuda()
+    x = torch.randn(2, 300, 256).cuda().requires_grad_(True)
+    go = torch.randn(2, 300, 128).cuda()
+    y = bracket_linear(x, lin)
+    y.backward(go)
+    got = (x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone())
+    x.grad = None; lin.zero_grad()
+    y_ref = lin(x)
+    y_ref.backward(go)
+    assert torch.equal(y, y_ref)                                       # same forward GEMM
+    assert torch.allclose(got[0], x.grad, rtol=1e-5, atol=1e-5)
+    assert rel_err(got[1].cpu().numpy(), lin.weight.grad.cpu().numpy()) < 2e-6
+    assert rel_err(got[2].cpu().numpy(), lin.bias.grad.cpu().numpy()) < 2e-6
+    # preconditions not met -> the layer itself
+    with torch.no_grad():
+        assert torch.equal(bracket_linear(x, lin), lin(x))
+    odd = torch.nn.Linear(10, 6).cuda()
+    z = torch.randn(5, 10).cuda().requires_grad_(True)
+    bracket_linear(z, odd).sum().backward()
+    assert z.grad is not None

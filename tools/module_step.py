@@ -25,9 +25,7 @@ q = torch.randn(N, Lq, M * D, device=dev, requires_grad=True)
 src = torch.randn(N, S, M * D, device=dev, requires_grad=True)
 ref = torch.rand(N, Lq, len(shapes), 2, device=dev)
 go = torch.randn(N, Lq, M * D, device=dev)
-for i in range(iters + 3):
-    if i == 3:
-        torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
+def step():
     mod.zero_grad(set_to_none=True); q.grad = src.grad = None
     if amp == "bf16":
         mod.bf16_storage = True
@@ -37,5 +35,25 @@ for i in range(iters + 3):
     else:
         out = mod(q, ref, src, sh, lsi)
         out.backward(go)
-e1.record(); e1.synchronize()
-print("%s module fwd+bwd%s: %.1f us per step" % (name, " (autocast bf16 + bf16 storage)" if amp else "", e0.elapsed_time(e1) * 1e3 / iters))
+
+use_graph = os.environ.get("MODULE_GRAPH", "") == "1"              # replay a HIP graph: GPU-bound time
+st = torch.cuda.Stream(dev)
+with torch.cuda.stream(st):
+    for _ in range(3):
+        step()
+    st.synchronize()
+    run = step
+    if use_graph:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            step()
+        run = g.replay
+    for _ in range(3):
+        run()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(iters):
+        run()
+    e1.record(st); e1.synchronize()
+print("%s module fwd+bwd%s%s: %.1f us per step" % (name, " (autocast bf16 + bf16 storage)" if amp else "",
+      " [HIP graph]" if use_graph else " [eager]", e0.elapsed_time(e1) * 1e3 / iters))

@@ -23,6 +23,7 @@ _lib = None
 _SYMBOLS = (
     "msda_forward_f32", "msda_backward_f32", "msda_forward_f64", "msda_backward_f64",
     "msda_forward_bf16", "msda_backward_bf16",
+    "msda_linear_wgrad_f32", "msda_linear_wgrad_workspace_bytes",
     "msda_last_error", "msda_version", "msda_path_for", "msda_force_path",
 )
 
@@ -44,6 +45,8 @@ def load():
     lib.msda_version.restype = ctypes.c_int
     lib.msda_path_for.restype = ctypes.c_int
     lib.msda_force_path.restype = None
+    lib.msda_linear_wgrad_workspace_bytes.restype = ctypes.c_ulonglong
+    lib.msda_linear_wgrad_workspace_bytes.argtypes = [ctypes.c_int] * 3
     _lib = lib
     return lib
 
@@ -209,6 +212,37 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     if rc != 0:
         _raise(lib, rc, "ms_deform_attn_backward")
     return grad_value, grad_loc, grad_attn
+
+
+_WGRAD_ARGTYPES = [_VP, _VP, _CI, _CI, _CI, _VP, _VP, _VP, _VP]
+
+
+def linear_wgrad_supported(grad_out, inp):
+    """fp32, contiguous 2-D views [M, N] / [M, K] on one GPU, N and K multiples of 4."""
+    return (grad_out.is_cuda and inp.is_cuda and grad_out.dtype == torch.float32 and inp.dtype == torch.float32
+            and grad_out.dim() == 2 and inp.dim() == 2 and grad_out.shape[0] == inp.shape[0]
+            and grad_out.is_contiguous() and inp.is_contiguous() and grad_out.device == inp.device
+            and grad_out.shape[1] % 4 == 0 and inp.shape[1] % 4 == 0 and inp.shape[0] < (1 << 30))
+
+
+def linear_wgrad(grad_out, inp, want_bias=True):
+    """(grad_weight[N,K], grad_bias[N] or None) = (grad_out^T @ inp, grad_out.sum(0)) — include/msda.h."""
+    lib = _lib or load()
+    if not linear_wgrad_supported(grad_out, inp):
+        raise RuntimeError("linear_wgrad: expected contiguous fp32 CUDA matrices [M,N] and [M,K] with N, K % 4 == 0")
+    M, N = grad_out.shape
+    K = inp.shape[1]
+    with _DeviceGuard(inp.device):
+        gw = torch.empty((N, K), dtype=torch.float32, device=inp.device)
+        gb = torch.empty((N,), dtype=torch.float32, device=inp.device) if want_bias else None
+        nbytes = lib.msda_linear_wgrad_workspace_bytes(M, N, K)
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=inp.device) if nbytes else None
+        rc = _entry(lib, "msda_linear_wgrad_f32", _WGRAD_ARGTYPES)(
+            grad_out.data_ptr(), inp.data_ptr(), M, N, K, gw.data_ptr(), gb.data_ptr() if want_bias else None,
+            ws.data_ptr() if ws is not None else None, _raw_stream(inp.device))
+    if rc != 0:
+        _raise(lib, rc, "linear_wgrad")
+    return gw, gb
 
 
 def path_for(elem_bytes, M, D, L, P):

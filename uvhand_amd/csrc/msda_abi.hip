@@ -179,6 +179,29 @@ int msda_backward_bf16(const uint16_t *grad_out, const uint16_t *value, const in
                                      L, Lq, P, grad_value, grad_sampling_loc, grad_attn_weight, (hipStream_t)stream);
 }
 
+unsigned long long msda_linear_wgrad_workspace_bytes(int M, int N, int K)
+{
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    return (unsigned long long)msda::linear_wgrad_workspace_bytes(M, N, K);
+}
+
+int msda_linear_wgrad_f32(const float *grad_out, const float *input, int M, int N, int K, float *grad_weight,
+                          float *grad_bias, void *workspace, msda_stream_t stream)
+{
+    if (M < 0 || N <= 0 || K <= 0 || (N & 3) || (K & 3))
+        return msda::set_error(MSDA_ERR_ARGUMENT, "msda_linear_wgrad_f32: need N, K > 0 and multiples of 4");
+    if (grad_weight == nullptr || (M > 0 && (grad_out == nullptr || input == nullptr)))
+        return msda::set_error(MSDA_ERR_ARGUMENT, "msda_linear_wgrad_f32: null device pointer");
+    msda::g_err[0] = 0;
+    if (M == 0) {
+        hipError_t e = hipMemsetAsync(grad_weight, 0, sizeof(float) * (size_t)N * K, (hipStream_t)stream);
+        if (e == hipSuccess && grad_bias) e = hipMemsetAsync(grad_bias, 0, sizeof(float) * (size_t)N, (hipStream_t)stream);
+        return e == hipSuccess ? MSDA_OK : msda::set_error(MSDA_ERR_LAUNCH, hipGetErrorString(e));
+    }
+    return msda::launch_linear_wgrad(grad_out, input, M, N, K, grad_weight, grad_bias, static_cast<float *>(workspace),
+                                     (hipStream_t)stream);
+}
+
 const char *msda_last_error(void) { return msda::g_err; }
 
 int msda_version(void) { return 100; }

@@ -43,4 +43,9 @@ int launch_bwd_d32_bf16(const uint16_t *grad_out, const uint16_t *value, const i
                         int M, int L, int Lq, int P, uint16_t *grad_value, float *grad_loc, float *grad_attn,
                         hipStream_t stream);
 
+// ---- weight / bias gradient of the bracketing nn.Linear layers (msda_linear.hip) -----------------
+size_t linear_wgrad_workspace_bytes(int M, int N, int K);
+int launch_linear_wgrad(const float *dY, const float *X, int M, int N, int K, float *dW, float *db, float *workspace,
+                        hipStream_t stream);
+
 }  // namespace msda

@@ -1,0 +1,63 @@
+"""``bracket_linear`` — ``F.linear`` for the four projections around the sampling kernel
+(UVHand models/ops/modules/ms_deform_attn.py:96,100,101,139) with the weight / bias gradient on the
+hand-written split-M MFMA kernel (``msda_linear_wgrad_f32``, include/msda.h).
+
+Why only that GEMM: the forward ``x @ W^T + b`` and the input gradient ``dy @ W`` run at 38-97 TFLOP/s
+on the vendor BLAS at these shapes, while the weight gradient ``dy^T @ x`` with few rows (600 at the
+300-query decoder shape) is run by hipBLASLt as one 256x256 tile on one CU — 141 us, 0.6 TFLOP/s
+(tools/gemm_baseline.py).  Numerics: fp32 MFMA is an exact fp32 fma chain; the split-M partial sums
+are combined in a fixed order, so the result is reproducible run to run.
+
+Falls back to ``F.linear`` — PyTorch's own implementation of the same layer, not an alternative
+implementation of the op — whenever the kernel's preconditions do not hold (CPU tensors, non-fp32,
+autocast, feature counts not multiples of 4), so the module keeps working everywhere nn.Linear does.
+"""
+import os
+
+import torch
+import torch.nn.functional as F
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .. import _native as MSDA
+
+
+class _BracketLinearFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        x, weight = ctx.saved_tensors
+        need_x, need_w, need_b = ctx.needs_input_grad
+        go2 = grad_out.reshape(-1, grad_out.shape[-1])
+        grad_x = grad_w = grad_b = None
+        if need_x:
+            grad_x = (go2 @ weight).view_as(x)
+        if need_w or (need_b and ctx.has_bias):
+            x2 = x.reshape(-1, x.shape[-1])
+            go2c, x2c = go2.contiguous(), x2.contiguous()
+            if MSDA.linear_wgrad_supported(go2c, x2c):
+                grad_w, grad_b = MSDA.linear_wgrad(go2c, x2c, want_bias=ctx.has_bias and need_b)
+            else:
+                grad_w = go2c.t() @ x2c
+                grad_b = go2c.sum(0) if (ctx.has_bias and need_b) else None
+            if not need_w:
+                grad_w = None
+        return grad_x, grad_w, grad_b
+
+
+_ENABLED = os.environ.get("MSDA_BRACKET_LINEAR", "1") != "0"       # A/B knob: 0 = always the plain layer
+
+
+def bracket_linear(x, layer):
+    """``layer(x)`` for an ``nn.Linear`` ``layer``; custom weight-gradient kernel when applicable."""
+    if (_ENABLED and x.is_cuda and x.dtype == torch.float32 and layer.weight.dtype == torch.float32
+            and not torch.is_autocast_enabled() and torch.is_grad_enabled()
+            and layer.in_features % 4 == 0 and layer.out_features % 4 == 0):
+        return _BracketLinearFn.apply(x, layer.weight, layer.bias)
+    return layer(x)

@@ -26,6 +26,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..functions import MSDeformAttnBF16Function, MSDeformAttnFunction
+from ..functions.linear_func import bracket_linear
 
 
 # (data_ptr, version, Len_in) of spatial_shapes tensors whose H*W sum was already verified: the
@@ -109,13 +110,15 @@ class MSDeformAttn(nn.Module):
         N, Len_in, _ = input_flatten.shape
         _check_shapes_sum(input_spatial_shapes, Len_in)
 
-        value = self.value_proj(input_flatten)
+        # the four projections are nn.Linear (same parameters, same forward GEMM as the reference);
+        # bracket_linear only swaps the weight-gradient GEMM of their backward (functions/linear_func.py)
+        value = bracket_linear(input_flatten, self.value_proj)
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], float(0))
         value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
-        sampling_offsets = self.sampling_offsets(query).view(
+        sampling_offsets = bracket_linear(query, self.sampling_offsets).view(
             N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
-        attention_weights = self.attention_weights(query).view(
+        attention_weights = bracket_linear(query, self.attention_weights).view(
             N, Len_q, self.n_heads, self.n_levels * self.n_points)
         attention_weights = F.softmax(attention_weights, -1).view(
             N, Len_q, self.n_heads, self.n_levels, self.n_points)
@@ -141,4 +144,5 @@ class MSDeformAttn(nn.Module):
         fn = MSDeformAttnBF16Function if self.bf16_storage else MSDeformAttnFunction
         output = fn.apply(value, input_spatial_shapes, input_level_start_index, sampling_locations,
                           attention_weights, self.im2col_step)
-        return self.output_proj(output.to(self.output_proj.weight.dtype) if self.bf16_storage else output)
+        return bracket_linear(output.to(self.output_proj.weight.dtype) if self.bf16_storage else output,
+                              self.output_proj)
