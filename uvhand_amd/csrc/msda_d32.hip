@@ -734,11 +734,14 @@ static ValuePlan plan_value(int N, int S, int M, int L, int Lq, int P, int targe
         pl.W = ceil_div(S, pl.tp_cap);
         pl.ppt = kMultiPPT;
     } else {
-        pl.W = max(ceil_div(S, kSingleMaxRows), ceil_div(target_wgs, pairs_levels));
+        // multi-pass problems: twice the workgroups (each pass is a latency chain; more, smaller
+        // workgroups overlap better) and the smaller record array, so role A still shares the launch
+        // (measured: cfg-2 encoder 108 vs 120 us; cfg-4 encoder unchanged)
+        pl.W = max(ceil_div(S, kSingleMaxRows), ceil_div(multipass ? 2 * target_wgs : target_wgs, pairs_levels));
         pl.W = max(1, min(pl.W, max(1, S / 16)));
         pl.tp_cap = ceil_div(S, pl.W);
-        // few workgroups and many passes: take twice the points per pass (one workgroup per CU anyway)
-        pl.ppt = (multipass && (long long)pairs_levels * pl.W <= 512) ? kMultiPPT : kSinglePPT;
+        static const int force_ppt = env_int("MSDA_BWD_PPT", 0);         // tuning knob: kSinglePPT or kMultiPPT
+        pl.ppt = (multipass && force_ppt == kMultiPPT) ? kMultiPPT : kSinglePPT;
     }
     pl.tp_cap = (pl.tp_cap + 3) & ~3;                                 // keeps the LDS arrays 16-B aligned
     const int pass_points = min(NP, pl.ppt * kSBlock);
