@@ -106,6 +106,30 @@ int msda_backward_bf16(const uint16_t *grad_out, const uint16_t *value, const in
                        uint16_t *grad_value, float *grad_sampling_loc, float *grad_attn_weight,
                        msda_stream_t stream);
 
+/* ---- Fused module prologue (fp32, D = 32 family) ---------------------------------
+ * The module computes  attn = softmax(logits) over the L*P points of a (query, head)  and
+ * sampling_loc = reference_point + offset / (W_l, H_l)  (models/ops/modules/ms_deform_attn.py:101-108,
+ * :110-128 after the 21-keypoint mean) with elementwise PyTorch kernels before calling the op.  These
+ * entry points take the RAW tensors instead and do that arithmetic in the kernels' point lanes:
+ *   forward : reference_points[N,Lq,L,2], sampling_offsets[N,Lq,M,L,P,2] (pixels), attn_logits[N,Lq,M,L*P]
+ *             -> out, plus sampling_loc_out / attn_weight_out (what the unfused path would have been
+ *             given; saved for the backward)
+ *   backward: takes those saved tensors; returns grad_value and the gradients of the RAW tensors
+ *             (offsets, logits — softmax backward included — and reference points, summed over heads
+ *             and points).
+ * msda_prologue_supported() != 0 iff the geometry qualifies (D = 32 family, L*P and P powers of two,
+ * whole queries per workgroup); otherwise callers compose the plain entry points as the reference does. */
+int msda_prologue_supported(int N, int S, int M, int D, int L, int Lq, int P);
+int msda_forward_prologue_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                              const float *reference_points, const float *sampling_offsets, const float *attn_logits,
+                              int N, int S, int M, int D, int L, int Lq, int P,
+                              float *out, float *sampling_loc_out, float *attn_weight_out, msda_stream_t stream);
+int msda_backward_prologue_f32(const float *grad_out, const float *value, const int64_t *spatial_shapes,
+                               const int64_t *level_start, const float *sampling_loc, const float *attn_weight,
+                               int N, int S, int M, int D, int L, int Lq, int P,
+                               float *grad_value, float *grad_sampling_offsets, float *grad_attn_logits,
+                               float *grad_reference_points, msda_stream_t stream);
+
 /* ---- Bracketing projections ----------------------------------------------------
  * Weight and bias gradient of an fp32 nn.Linear  y[M,N] = x[M,K] . W[N,K]^T + b[N]:
  *     grad_weight[N,K] = grad_out[M,N]^T . input[M,K]        grad_bias[N] = sum_m grad_out[m,:]

@@ -80,3 +80,68 @@ def test_module_bf16_storage_option():
     out.sum().backward()
     assert out.dtype == torch.float32 and torch.isfinite(q.grad).all()
     assert rel_err(out.detach().cpu().numpy(), ref.detach().cpu().numpy()) < 1e-2
+
+
+# ---------------------------------------------------------------------------------------------
+# fused prologue (softmax + location arithmetic inside the kernels) vs the unfused composition
+# ---------------------------------------------------------------------------------------------
+def _prologue_case(seed, N, Lq, shapes, M=8, P=4):
+    g = torch.Generator().manual_seed(seed)
+    L = len(shapes)
+    S = sum(h * w for h, w in shapes)
+    sh = torch.tensor(shapes, dtype=torch.long).cuda()
+    lsi = torch.cat((sh.new_zeros(1), sh.prod(1).cumsum(0)[:-1]))
+    value = (torch.rand(N, S, M, 32, generator=g) - 0.5).cuda().requires_grad_(True)
+    ref = (torch.rand(N, Lq, L, 2, generator=g) * 1.4 - 0.2).cuda().requires_grad_(True)
+    off = (torch.randn(N, Lq, M, L, P, 2, generator=g) * 2.0).cuda().requires_grad_(True)
+    logits = torch.randn(N, Lq, M, L * P, generator=g).cuda().requires_grad_(True)
+    go = torch.randn(N, Lq, M * 32, generator=g).cuda()
+    return sh, lsi, value, ref, off, logits, go
+
+
+@pytest.mark.parametrize("N,Lq,shapes", [(2, 37, [(12, 12), (6, 6), (3, 3), (2, 2)]),
+                                          (2, 300, [(48, 48), (24, 24), (12, 12), (6, 6)]),
+                                          (1, 2100, [(16, 16), (8, 8), (4, 4), (2, 2)]),       # multi-pass role B
+                                          (3, 5, [(5, 7), (3, 4)])])
+def test_prologue_function_matches_unfused_composition(N, Lq, shapes):
+    from uvhand_amd import _native
+    from uvhand_amd.functions import MSDeformAttnFunction, MSDeformAttnPrologueFunction
+    sh, lsi, value, ref, off, logits, go = _prologue_case(N + Lq, N, Lq, shapes)
+    L, P = len(shapes), 4
+    assert _native.prologue_supported(value, ref, off, logits)
+    out = MSDeformAttnPrologueFunction.apply(value, sh, lsi, ref, off, logits, 64)
+    out.backward(go)
+    got = [t.grad.clone() for t in (value, ref, off, logits)]
+    for t in (value, ref, off, logits):
+        t.grad = None
+    # the reference's own arithmetic (modules/ms_deform_attn.py:101-108) in fp64 on the plain function
+    wh = torch.stack([sh[:, 1], sh[:, 0]], -1).double()
+    vd, rd, od, ld = (t.detach().double().requires_grad_(True) for t in (value, ref, off, logits))
+    attn = torch.softmax(ld, -1).view(N, Lq, 8, L, P)
+    loc = rd[:, :, None, :, None, :] + od / wh[None, None, None, :, None, :]
+    out_ref = MSDeformAttnFunction.apply(vd, sh, lsi, loc, attn, 64)
+    out_ref.backward(go.double())
+    # fp32 kernels vs the same arithmetic in fp64: forward 2e-5 of max (locations are formed in fp32, so a
+    # sample moves by up to 1e-5 px), gradients 1e-4 of max
+    e_out = rel_err(out.detach().cpu().numpy(), out_ref.detach().cpu().numpy())
+    assert e_out < 2e-5, e_out
+    for name, g32, t64 in zip(("value", "ref", "offsets", "logits"), got, (vd, rd, od, ld)):
+        e = rel_err(g32.cpu().numpy(), t64.grad.cpu().numpy())
+        assert e < 1e-4, (name, e)
+
+
+def test_module_fused_and_unfused_prologue_agree():
+    z = load_golden("module_42d")
+    mod = _module()
+    args = lambda: [torch.from_numpy(z[k]).cuda() for k in ("query", "refp", "src", "shapes", "level_start", "mask")]
+    res = {}
+    for fused in (True, False):
+        mod.fused_prologue = fused
+        mod.zero_grad()
+        a = args()
+        a[0].requires_grad_(True); a[1].requires_grad_(True); a[2].requires_grad_(True)
+        out = mod(*a)
+        out.backward(torch.from_numpy(z["gout"]).cuda())
+        res[fused] = [out.detach()] + [t.grad for t in a[:3]] + [p.grad.clone() for p in mod.parameters()]
+    for x, y in zip(res[True], res[False]):
+        assert rel_err(x.cpu().numpy(), y.cpu().numpy()) < 2e-5

@@ -11,10 +11,12 @@ from uvhand_amd.modules import MSDeformAttn
 name = sys.argv[1] if len(sys.argv) > 1 else "cfg4_encoder"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 amp = os.environ.get("MODULE_AMP", "")            # "bf16": autocast + bf16 storage in the op
+fused = os.environ.get("MODULE_FUSED_PROLOGUE", "1") != "0"
 N, shapes, M, D, Lq, P = WORKLOADS[name]
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 mod = MSDeformAttn(M * D, len(shapes), M, P).to(dev)
+mod.fused_prologue = fused
 with torch.no_grad():
     for p in mod.parameters():
         p.add_(torch.randn_like(p) * 0.02)
@@ -22,11 +24,12 @@ sh = torch.tensor(shapes, dtype=torch.long, device=dev)
 lsi = torch.cat((sh.new_zeros(1), sh.prod(1).cumsum(0)[:-1]))
 S = int(sh.prod(1).sum())
 q = torch.randn(N, Lq, M * D, device=dev, requires_grad=True)
+ref_requires_grad = True
 src = torch.randn(N, S, M * D, device=dev, requires_grad=True)
-ref = torch.rand(N, Lq, len(shapes), 2, device=dev)
+ref = torch.rand(N, Lq, len(shapes), 2, device=dev, requires_grad=True)
 go = torch.randn(N, Lq, M * D, device=dev)
 def step():
-    mod.zero_grad(set_to_none=True); q.grad = src.grad = None
+    mod.zero_grad(set_to_none=True); q.grad = src.grad = ref.grad = None
     if amp == "bf16":
         mod.bf16_storage = True
         with torch.autocast("cuda", dtype=torch.bfloat16):

@@ -24,6 +24,7 @@ _SYMBOLS = (
     "msda_forward_f32", "msda_backward_f32", "msda_forward_f64", "msda_backward_f64",
     "msda_forward_bf16", "msda_backward_bf16",
     "msda_linear_wgrad_f32", "msda_linear_wgrad_workspace_bytes",
+    "msda_prologue_supported", "msda_forward_prologue_f32", "msda_backward_prologue_f32",
     "msda_last_error", "msda_version", "msda_path_for", "msda_force_path",
 )
 
@@ -45,6 +46,8 @@ def load():
     lib.msda_version.restype = ctypes.c_int
     lib.msda_path_for.restype = ctypes.c_int
     lib.msda_force_path.restype = None
+    lib.msda_prologue_supported.restype = ctypes.c_int
+    lib.msda_prologue_supported.argtypes = [ctypes.c_int] * 7
     lib.msda_linear_wgrad_workspace_bytes.restype = ctypes.c_ulonglong
     lib.msda_linear_wgrad_workspace_bytes.argtypes = [ctypes.c_int] * 3
     _lib = lib
@@ -243,6 +246,69 @@ def linear_wgrad(grad_out, inp, want_bias=True):
     if rc != 0:
         _raise(lib, rc, "linear_wgrad")
     return gw, gb
+
+
+def prologue_supported(value, reference_points, sampling_offsets, attn_logits):
+    """True when the fused-prologue entry points (include/msda.h) can take these tensors."""
+    if not (value.is_cuda and value.dtype == torch.float32 and sampling_offsets.dtype == torch.float32
+            and attn_logits.dtype == torch.float32 and reference_points.dtype == torch.float32):
+        return False
+    if value.dim() != 4 or sampling_offsets.dim() != 6 or reference_points.dim() != 4 or reference_points.shape[-1] != 2:
+        return False
+    N, S, M, D = value.shape
+    Lq, L, P = sampling_offsets.shape[1], sampling_offsets.shape[3], sampling_offsets.shape[4]
+    lib = _lib or load()
+    return bool(lib.msda_prologue_supported(N, S, M, D, L, Lq, P))
+
+
+def ms_deform_attn_forward_prologue(value, spatial_shapes, level_start_index, reference_points, sampling_offsets,
+                                    attn_logits, im2col_step):
+    """Fused-prologue forward (include/msda.h).  Returns (out, sampling_loc, attn_weight); the last two are
+    what the reference's Python would have computed and are what the backward consumes."""
+    lib = _lib or load()
+    _check_inputs((("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
+                   ("reference_points", reference_points), ("sampling_offsets", sampling_offsets),
+                   ("attn_logits", attn_logits)))
+    N, S, M, D = value.shape
+    Lq, L, P = sampling_offsets.shape[1], sampling_offsets.shape[3], sampling_offsets.shape[4]
+    if (tuple(sampling_offsets.shape) != (N, Lq, M, L, P, 2) or attn_logits.numel() != N * Lq * M * L * P
+            or tuple(reference_points.shape) != (N, Lq, L, 2) or tuple(spatial_shapes.shape) != (L, 2)):
+        raise RuntimeError("ms_deform_attn_forward_prologue: inconsistent shapes")
+    step = min(N, int(im2col_step))
+    if N > 0 and (step <= 0 or N % step != 0):
+        raise RuntimeError("batch(%d) must divide im2col_step(%d)" % (N, step))
+    with _DeviceGuard(value.device):
+        out = torch.empty((N, Lq, M * D), dtype=torch.float32, device=value.device)
+        loc = torch.empty_like(sampling_offsets)
+        attn = torch.empty((N, Lq, M, L, P), dtype=torch.float32, device=value.device)
+        rc = _entry(lib, "msda_forward_prologue_f32", [_VP] * 6 + [_CI] * 7 + [_VP] * 4)(
+            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), reference_points.data_ptr(),
+            sampling_offsets.data_ptr(), attn_logits.data_ptr(), N, S, M, D, L, Lq, P, out.data_ptr(), loc.data_ptr(),
+            attn.data_ptr(), _raw_stream(value.device))
+    if rc != 0:
+        _raise(lib, rc, "ms_deform_attn_forward_prologue")
+    return out, loc, attn
+
+
+def ms_deform_attn_backward_prologue(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output):
+    """Returns (grad_value, grad_sampling_offsets, grad_attn_logits[N,Lq,M,L*P], grad_reference_points[N,Lq,L,2])."""
+    lib = _lib or load()
+    _check_inputs((("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
+                   ("sampling_loc", sampling_loc), ("attn_weight", attn_weight), ("grad_output", grad_output)))
+    N, S, M, D = value.shape
+    Lq, L, P = sampling_loc.shape[1], sampling_loc.shape[3], sampling_loc.shape[4]
+    with _DeviceGuard(value.device):
+        gv = torch.empty_like(value)
+        goff = torch.empty_like(sampling_loc)
+        glog = torch.empty((N, Lq, M, L * P), dtype=torch.float32, device=value.device)
+        gref = torch.empty((N, Lq, L, 2), dtype=torch.float32, device=value.device)
+        rc = _entry(lib, "msda_backward_prologue_f32", [_VP] * 6 + [_CI] * 7 + [_VP] * 5)(
+            grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+            sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P, gv.data_ptr(), goff.data_ptr(),
+            glog.data_ptr(), gref.data_ptr(), _raw_stream(value.device))
+    if rc != 0:
+        _raise(lib, rc, "ms_deform_attn_backward_prologue")
+    return gv, goff, glog, gref
 
 
 def path_for(elem_bytes, M, D, L, P):

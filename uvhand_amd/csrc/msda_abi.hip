@@ -179,6 +179,44 @@ int msda_backward_bf16(const uint16_t *grad_out, const uint16_t *value, const in
                                      L, Lq, P, grad_value, grad_sampling_loc, grad_attn_weight, (hipStream_t)stream);
 }
 
+int msda_prologue_supported(int N, int S, int M, int D, int L, int Lq, int P)
+{
+    if (N <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Lq <= 0 || P <= 0) return 0;
+    if (msda::g_force_path.load(std::memory_order_relaxed) == MSDA_PATH_GENERIC) return 0;
+    return msda::prologue_supported(N, S, M, D, L, Lq, P) ? 1 : 0;
+}
+
+int msda_forward_prologue_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                              const float *reference_points, const float *sampling_offsets, const float *attn_logits,
+                              int N, int S, int M, int D, int L, int Lq, int P, float *out, float *sampling_loc_out,
+                              float *attn_weight_out, msda_stream_t stream)
+{
+    const void *ptrs[] = {value, spatial_shapes, level_start, reference_points, sampling_offsets, attn_logits, out,
+                          sampling_loc_out, attn_weight_out};
+    if (int rc = msda::check_args(ptrs, 9, N, S, M, D, L, Lq, P)) return rc;
+    if (!msda_prologue_supported(N, S, M, D, L, Lq, P))
+        return msda::set_error(MSDA_ERR_ARGUMENT, "msda_forward_prologue_f32: geometry not supported (msda_prologue_supported)");
+    msda::g_err[0] = 0;
+    return msda::launch_fwd_prologue(value, spatial_shapes, level_start, reference_points, sampling_offsets, attn_logits, N,
+                                     S, M, L, Lq, P, out, sampling_loc_out, attn_weight_out, (hipStream_t)stream);
+}
+
+int msda_backward_prologue_f32(const float *grad_out, const float *value, const int64_t *spatial_shapes,
+                               const int64_t *level_start, const float *sampling_loc, const float *attn_weight, int N,
+                               int S, int M, int D, int L, int Lq, int P, float *grad_value, float *grad_sampling_offsets,
+                               float *grad_attn_logits, float *grad_reference_points, msda_stream_t stream)
+{
+    const void *ptrs[] = {grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, grad_value,
+                          grad_sampling_offsets, grad_attn_logits, grad_reference_points};
+    if (int rc = msda::check_args(ptrs, 10, N, S, M, D, L, Lq, P)) return rc;
+    if (!msda_prologue_supported(N, S, M, D, L, Lq, P))
+        return msda::set_error(MSDA_ERR_ARGUMENT, "msda_backward_prologue_f32: geometry not supported (msda_prologue_supported)");
+    msda::g_err[0] = 0;
+    return msda::launch_bwd_prologue(grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M, L,
+                                     Lq, P, grad_value, grad_sampling_offsets, grad_attn_logits, grad_reference_points,
+                                     (hipStream_t)stream);
+}
+
 unsigned long long msda_linear_wgrad_workspace_bytes(int M, int N, int K)
 {
     if (M <= 0 || N <= 0 || K <= 0) return 0;

@@ -151,15 +151,42 @@ __device__ __forceinline__ void item_bm(int il, int b0, int r0, int m0, int LqM,
     m = m_shift >= 0 ? ((m0 + il) & (M - 1)) : (m0 + il) % M;
 }
 
+// ---- fused prologue: the module's softmax over the L*P logits of an item and its
+// location arithmetic  loc = reference_point + offset / (W_l, H_l)  (models/ops/modules/
+// ms_deform_attn.py:101-108) done by the point lanes of the prepass instead of 3 elementwise launches
+// over the [N,Lq,M,L,P,*] tensors.  The L*P points of an item sit on L*P consecutive lanes (L*P a power
+// of two <= 64), so max and sum are xor-shuffles inside that lane group.
+struct PrologueIn  { const float *ref; float *loc_out; float *attn_out; };      // ref[N,Lq,L,2]; saved for backward
+struct PrologueOut { float *grad_ref; };                                        // grad_ref[N,Lq,L,2]
+
+__device__ __forceinline__ float group_max(float x, int width)
+{
+    for (int m = 1; m < width; m <<= 1) x = fmaxf(x, __shfl_xor(x, m, kWave));
+    return x;
+}
+__device__ __forceinline__ float group_sum(float x, int width)
+{
+    for (int m = 1; m < width; m <<= 1) x += __shfl_xor(x, m, kWave);
+    return x;
+}
+// query index of the il-th item after item0 (r0 = item0 % (Lq*M))
+__device__ __forceinline__ int item_query(int il, int r0, int LqM, int M, int m_shift)
+{
+    int t = r0 + il;
+    if (t >= LqM) t -= LqM * (t / LqM);
+    return fdiv(t, M, m_shift);
+}
+
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
-template <int SPLIT, typename VT>
+// FUSED: `loc` holds the raw sampling offsets and `attn` the attention logits; see PrologueIn.
+template <int SPLIT, typename VT, bool FUSED = false>
 __global__ __launch_bounds__(kBlock) void fwd_d32_kernel(
     const VT *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ level_start, const float *__restrict__ loc,
     const float *__restrict__ attn, int S, int M, int L, int Lq, int P, int items, int p_shift,
-    int lp_shift, int m_shift, VT *__restrict__ out)
+    int lp_shift, int m_shift, VT *__restrict__ out, const PrologueIn pro = PrologueIn{nullptr, nullptr, nullptr})
 {
     constexpr int IPW = 32 / SPLIT;                       // items per workgroup
     constexpr int OPW = 4 / SPLIT;                        // octets per workgroup
@@ -184,14 +211,23 @@ __global__ __launch_bounds__(kBlock) void fwd_d32_kernel(
         r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0.f;
         if (item < items) {
             const int l = fdiv(pt, P, p_shift);
-            const float2 xy = reinterpret_cast<const float2 *>(loc)[(long long)item0 * LP + idx];
-            const float a = attn[(long long)item0 * LP + idx];
+            float2 xy = reinterpret_cast<const float2 *>(loc)[(long long)item0 * LP + idx];
+            float a = attn[(long long)item0 * LP + idx];
             LevelInfo li;
             li.H = (int)shapes[2 * l]; li.W = (int)shapes[2 * l + 1]; li.start = (int)level_start[l]; li.pad = 0;
+            int b, m;
+            item_bm(il, b0, r0, m0, LqM, M, m_shift, b, m);
+            if (FUSED) {
+                const int q = item_query(il, r0, LqM, M, m_shift);
+                const float2 rp = reinterpret_cast<const float2 *>(pro.ref)[((long long)b * Lq + q) * L + l];
+                xy = make_float2(rp.x + xy.x / (float)li.W, rp.y + xy.y / (float)li.H);
+                const float e = expf(a - group_max(a, LP));
+                a = e / group_sum(e, LP);
+                reinterpret_cast<float2 *>(pro.loc_out)[(long long)item0 * LP + idx] = xy;
+                pro.attn_out[(long long)item0 * LP + idx] = a;
+            }
             const PointGeom<float> g = point_geom<float>(xy.x, xy.y, li.H, li.W);
             if (g.inside) {
-                int b, m;
-                item_bm(il, b0, r0, m0, LqM, M, m_shift, b, m);
                 tap_offsets(g, li, b, m, S, M, r.off);
                 const float hh = 1.f - g.lh, hw = 1.f - g.lw;
                 r.w[0] = hh * hw * a; r.w[1] = hh * g.lw * a;
@@ -263,13 +299,18 @@ __global__ __launch_bounds__(kBlock) void fwd_d32_kernel(
 // ATOMIC = true additionally scatters grad_value with global float atomics (the v1 scheme, kept
 // for A/B measurements: MSDA_BWD_MODE=atomic); the default leaves grad_value to role B.
 // ------------------------------------------------------------------------------------------
-template <int SPLIT, bool ATOMIC, int THREADS, typename VT>
+// FUSED: the write-out applies the chain rule of the fused prologue — grad_loc becomes the gradient of
+// the raw offsets (grad_loc / (W,H)), grad_attn the gradient of the logits (softmax backward over the
+// item's L*P lanes), and the location gradients summed over heads and points go to pro.grad_ref.
+// Needs L*P and P powers of two and whole queries per workgroup (M | IPW): the host checks.
+template <int SPLIT, bool ATOMIC, int THREADS, typename VT, bool FUSED = false>
 __device__ __forceinline__ void bwd_query_body(
     const VT *__restrict__ grad_out, const VT *__restrict__ value,
     const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
     const float *__restrict__ loc, const float *__restrict__ attn, int S, int M, int L, int Lq,
     int P, int items, int p_shift, int lp_shift, int m_shift, VT *__restrict__ grad_value,
-    float *__restrict__ grad_loc, float *__restrict__ grad_attn, int block, unsigned char *smem)
+    float *__restrict__ grad_loc, float *__restrict__ grad_attn, int block, unsigned char *smem,
+    const PrologueOut pro = PrologueOut{nullptr})
 {
     constexpr int IPW = (THREADS / kWave) * 8 / SPLIT;      // items per workgroup
     unsigned char *recs = smem;
@@ -358,14 +399,39 @@ __device__ __forceinline__ void bwd_query_body(
     MSDA_STAMP_AT(1, 2);
 
     // ---- coalesced write-out of grad_sampling_loc / grad_attn_weight for the workgroup's items ----
+    float2 *refpart = reinterpret_cast<float2 *>(recs);                 // [IPW][L]: the records are no longer needed
     for (int idx = tid; idx < IPW * LP; idx += THREADS) {
         const int il2 = fdiv(idx, LP, lp_shift), pt = idx - il2 * LP;
         if (item0 + il2 < items) {
             const int l = fdiv(pt, P, p_shift);
             const float4 r = res[idx];
-            reinterpret_cast<float2 *>(grad_loc)[(long long)item0 * LP + idx] =
-                make_float2(r.x * (float)(int)shapes[2 * l + 1], r.y * (float)(int)shapes[2 * l]);
-            grad_attn[(long long)item0 * LP + idx] = r.z;
+            const float gx = r.x * (float)(int)shapes[2 * l + 1], gy = r.y * (float)(int)shapes[2 * l];
+            if (FUSED) {
+                // d loc / d offset = 1 / (W, H): the pixel-space sums are the offset gradients
+                reinterpret_cast<float2 *>(grad_loc)[(long long)item0 * LP + idx] = make_float2(r.x, r.y);
+                // softmax backward over the item's L*P lanes
+                const float a = attn[(long long)item0 * LP + idx];
+                const float dot = group_sum(a * r.z, LP);
+                grad_attn[(long long)item0 * LP + idx] = a * (r.z - dot);
+                // reference point: sum over the level's P points here, over the heads below
+                const float sx = group_sum(gx, P), sy = group_sum(gy, P);
+                if ((pt & (P - 1)) == 0) refpart[il2 * L + l] = make_float2(sx, sy);
+            } else {
+                reinterpret_cast<float2 *>(grad_loc)[(long long)item0 * LP + idx] = make_float2(gx, gy);
+                grad_attn[(long long)item0 * LP + idx] = r.z;
+            }
+        }
+    }
+    if (FUSED) {
+        __syncthreads();
+        for (int i = tid; i < (IPW / M) * L; i += THREADS) {           // one thread per (query of this workgroup, level)
+            const int qi = i / L, l = i - qi * L;
+            const int first = item0 + qi * M;
+            if (first < items) {
+                float2 acc = make_float2(0.f, 0.f);
+                for (int mm = 0; mm < M; ++mm) { const float2 v = refpart[(qi * M + mm) * L + l]; acc.x += v.x; acc.y += v.y; }
+                reinterpret_cast<float2 *>(pro.grad_ref)[(long long)(first / M) * L + l] = acc;   // first / M = b*Lq + q
+            }
         }
     }
     MSDA_STAMP_AT(1, 3);
@@ -642,13 +708,14 @@ __global__ __launch_bounds__(kSBlock) void bwd_value_d32_kernel(
 // (grad_value), the rest role A (grad_sampling_loc / grad_attn_weight).  The two roles share no
 // data, so this is plain concurrency inside one grid — it removes a dependent kernel boundary
 // (~1.5 us) and lets role A's short workgroups fill the CUs around role B's longer ones.
-template <int SPLIT, int ACC, typename VT>
+template <int SPLIT, int ACC, typename VT, bool FUSED = false>
 __global__ __launch_bounds__(kSBlock) void bwd_fused_d32_kernel(
     const VT *__restrict__ grad_out, const VT *__restrict__ value,
     const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
     const float *__restrict__ loc, const float *__restrict__ attn, int S, int M, int L, int Lq,
     int P, int items, int p_shift, int lp_shift, int m_shift, int tp_cap, int W, int nB,
-    VT *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attn)
+    VT *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attn,
+    const PrologueOut pro = PrologueOut{nullptr})
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int bid = (int)blockIdx.x;
@@ -657,9 +724,9 @@ __global__ __launch_bounds__(kSBlock) void bwd_fused_d32_kernel(
         bwd_value_body<ACC, kSinglePPT, VT>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, tp_cap,
                                           grad_value, ti, W, l, pr, smem);
     } else {
-        bwd_query_body<SPLIT, false, kSBlock, VT>(grad_out, value, shapes, level_start, loc, attn, S, M, L, Lq, P, items,
-                                              p_shift, lp_shift, m_shift, grad_value, grad_loc, grad_attn,
-                                              bid - nB, smem);
+        bwd_query_body<SPLIT, false, kSBlock, VT, FUSED>(grad_out, value, shapes, level_start, loc, attn, S, M, L, Lq, P,
+                                                     items, p_shift, lp_shift, m_shift, grad_value, grad_loc, grad_attn,
+                                                     bid - nB, smem, pro);
     }
 }
 
@@ -680,6 +747,12 @@ static int env_int(const char *name, int dflt)
 {
     const char *v = getenv(name);
     return (v && *v) ? atoi(v) : dflt;
+}
+
+static int bwd_target_wgs()
+{
+    static const int v = [] { int t = env_int("MSDA_BWD_WGS", 256); return t < 1 ? 1 : t; }();
+    return v;
 }
 
 static int pow2_shift(int x) { return (x > 0 && (x & (x - 1)) == 0) ? __builtin_ctz((unsigned)x) : -1; }
@@ -772,7 +845,7 @@ static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *
         const char *v = getenv("MSDA_BWD_MODE");
         return (v && !strcmp(v, "atomic")) ? 2 : (v && !strcmp(v, "split")) ? 1 : 0; }();
     const int bwd_mode = (bwd_mode_env == 2 && sizeof(VT) != 4) ? 0 : bwd_mode_env;
-    static const int target_wgs = [] { int v = env_int("MSDA_BWD_WGS", 256); return v < 1 ? 1 : v; }();
+    const int target_wgs = bwd_target_wgs();
     const int split = pick_split(items, LP);
     const int ps = pow2_shift(P), lps = pow2_shift(LP), ms = pow2_shift(M);
 
@@ -823,6 +896,65 @@ static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *
 #undef MSDA_LAUNCH_A
     }
     return check_launch("msda backward (d32, query-major)");
+}
+
+// ---- fused prologue (fp32 only): see PrologueIn / PrologueOut ----
+bool prologue_supported(int N, int S, int M, int D, int L, int Lq, int P)
+{
+    if (!d32_supported(N, S, M, D, L, Lq, P)) return false;
+    const int LP = L * P;
+    if (pow2_shift(LP) < 0 || pow2_shift(P) < 0 || LP > 64) return false;     // lane-group reductions
+    const int split = pick_split(N * Lq * M, LP);
+    if ((kSWaves * 8 / split) % M != 0) return false;                           // whole queries per role-A workgroup
+    static const bool plain_modes = [] { const char *v = getenv("MSDA_BWD_MODE"); return v && *v; }();
+    return !plain_modes;                                                        // A/B knobs select the unfused kernels
+}
+
+int launch_fwd_prologue(const float *value, const int64_t *shapes, const int64_t *level_start, const float *ref,
+                        const float *offsets, const float *logits, int N, int S, int M, int L, int Lq, int P, float *out,
+                        float *loc_out, float *attn_out, hipStream_t stream)
+{
+    const int items = N * Lq * M, LP = L * P;
+    const int item_stride = LP * kRecBytes + kItemPad;
+    const int split = pick_split(items, LP);
+    const int ipw = 32 / split;
+    const size_t lds = (size_t)ipw * item_stride + (split > 1 ? 4096 : 0);
+    const dim3 grid((items + ipw - 1) / ipw), block(kBlock);
+    const PrologueIn pro{ref, loc_out, attn_out};
+#define MSDA_LAUNCH_FP(SP)                                                                             \
+    hipLaunchKernelGGL((fwd_d32_kernel<SP, float, true>), grid, block, lds, stream, value, shapes, level_start, offsets, \
+                       logits, S, M, L, Lq, P, items, pow2_shift(P), pow2_shift(LP), pow2_shift(M), out, pro)
+    if (split == 4) MSDA_LAUNCH_FP(4); else if (split == 2) MSDA_LAUNCH_FP(2); else MSDA_LAUNCH_FP(1);
+#undef MSDA_LAUNCH_FP
+    return check_launch("msda forward (d32, fused prologue)");
+}
+
+int launch_bwd_prologue(const float *grad_out, const float *value, const int64_t *shapes, const int64_t *level_start,
+                        const float *loc, const float *attn, int N, int S, int M, int L, int Lq, int P, float *grad_value,
+                        float *grad_offsets, float *grad_logits, float *grad_ref, hipStream_t stream)
+{
+    const int items = N * Lq * M, LP = L * P;
+    const int item_stride = LP * kRecBytes + kItemPad;
+    const int split = pick_split(items, LP);
+    const int ps = pow2_shift(P), lps = pow2_shift(LP), ms = pow2_shift(M);
+    const ValuePlan pl = plan_value<float>(N, S, M, L, Lq, P, bwd_target_wgs());
+    const long long nB = (long long)pl.W * N * M * L;
+    const int ipw_f = kSWaves * 8 / split;
+    const size_t lds_a = (size_t)ipw_f * item_stride + (size_t)ipw_f * LP * 16;
+    const long long nA = (items + ipw_f - 1) / ipw_f;
+    if (pl.ppt != kSinglePPT || pl.acc == kAccTile || nB + nA > 0x7fffffffLL)
+        return set_error(MSDA_ERR_ARGUMENT, "msda backward (fused prologue): geometry not supported");
+    const dim3 fgrid((unsigned)(nB + nA));
+    const size_t flds = pl.lds > lds_a ? pl.lds : lds_a;
+    const PrologueOut pro{grad_ref};
+#define MSDA_LAUNCH_BP(SP, AC)                                                                         \
+    hipLaunchKernelGGL((bwd_fused_d32_kernel<SP, AC, float, true>), fgrid, dim3(kSBlock), flds, stream, grad_out, value,  \
+                       shapes, level_start, loc, attn, S, M, L, Lq, P, items, ps, lps, ms, pl.tp_cap, pl.W, (int)nB,    \
+                       grad_value, grad_offsets, grad_logits, pro)
+    if (pl.acc == kAccNone) { if (split == 4) MSDA_LAUNCH_BP(4, kAccNone); else if (split == 2) MSDA_LAUNCH_BP(2, kAccNone); else MSDA_LAUNCH_BP(1, kAccNone); }
+    else                    { if (split == 4) MSDA_LAUNCH_BP(4, kAccRmw); else if (split == 2) MSDA_LAUNCH_BP(2, kAccRmw); else MSDA_LAUNCH_BP(1, kAccRmw); }
+#undef MSDA_LAUNCH_BP
+    return check_launch("msda backward (d32, fused prologue)");
 }
 
 int launch_fwd_d32(const float *value, const int64_t *shapes, const int64_t *level_start, const float *loc,

@@ -43,6 +43,15 @@ int launch_bwd_d32_bf16(const uint16_t *grad_out, const uint16_t *value, const i
                         int M, int L, int Lq, int P, uint16_t *grad_value, float *grad_loc, float *grad_attn,
                         hipStream_t stream);
 
+// ---- fused prologue (fp32, D = 32 family): softmax over L*P and loc = ref + offset/(W,H) inside the kernels
+bool prologue_supported(int N, int S, int M, int D, int L, int Lq, int P);
+int launch_fwd_prologue(const float *value, const int64_t *shapes, const int64_t *level_start, const float *ref,
+                        const float *offsets, const float *logits, int N, int S, int M, int L, int Lq, int P, float *out,
+                        float *loc_out, float *attn_out, hipStream_t stream);
+int launch_bwd_prologue(const float *grad_out, const float *value, const int64_t *shapes, const int64_t *level_start,
+                        const float *loc, const float *attn, int N, int S, int M, int L, int Lq, int P, float *grad_value,
+                        float *grad_offsets, float *grad_logits, float *grad_ref, hipStream_t stream);
+
 // ---- weight / bias gradient of the bracketing nn.Linear layers (msda_linear.hip) -----------------
 size_t linear_wgrad_workspace_bytes(int M, int N, int K);
 int launch_linear_wgrad(const float *dY, const float *X, int M, int N, int K, float *dW, float *db, float *workspace,

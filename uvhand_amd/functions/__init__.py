@@ -1,3 +1,3 @@
-from .ms_deform_attn_func import MSDeformAttnBF16Function, MSDeformAttnFunction
+from .ms_deform_attn_func import MSDeformAttnBF16Function, MSDeformAttnFunction, MSDeformAttnPrologueFunction
 
-__all__ = ["MSDeformAttnFunction", "MSDeformAttnBF16Function"]
+__all__ = ["MSDeformAttnFunction", "MSDeformAttnBF16Function", "MSDeformAttnPrologueFunction"]

@@ -83,3 +83,34 @@ class MSDeformAttnBF16Function(Function):
             grad_output.to(torch.bfloat16).contiguous(), ctx.im2col_step)
         return (grad_value.to(value.dtype), None, None, grad_sampling_loc.to(sampling_locations.dtype),
                 grad_attn_weight.to(attention_weights.dtype), None)
+
+
+class MSDeformAttnPrologueFunction(Function):
+    """The op with the module's prologue folded in (no reference counterpart as a function —
+    it computes what models/ops/modules/ms_deform_attn.py:101-108 + MSDeformAttnFunction compute):
+
+        out = apply(value[N,S,M,D], spatial_shapes, level_start_index, reference_points[N,Lq,L,2],
+                    sampling_offsets[N,Lq,M,L,P,2] (pixels), attn_logits[N,Lq,M,L*P], im2col_step)
+
+    softmax over the L*P logits and ``loc = reference_point + offset / (W_l, H_l)`` run in the forward
+    kernel's point lanes; the backward kernel returns the gradients of the RAW tensors (softmax backward,
+    offset scaling and the reduction over heads / points for the reference points included).  fp32 only;
+    callers check ``_native.prologue_supported`` first (the module does)."""
+
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, reference_points, sampling_offsets,
+                attn_logits, im2col_step):
+        out, loc, attn = MSDA.ms_deform_attn_forward_prologue(
+            value, value_spatial_shapes, value_level_start_index, reference_points.contiguous(),
+            sampling_offsets.contiguous(), attn_logits.contiguous(), im2col_step)
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, loc, attn)
+        ctx.logits_shape = attn_logits.shape
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, value_spatial_shapes, value_level_start_index, loc, attn = ctx.saved_tensors
+        gv, goff, glog, gref = MSDA.ms_deform_attn_backward_prologue(
+            value, value_spatial_shapes, value_level_start_index, loc, attn, grad_output.contiguous())
+        return gv, None, None, gref, goff, glog.view(ctx.logits_shape), None

@@ -25,7 +25,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..functions import MSDeformAttnBF16Function, MSDeformAttnFunction
+from .. import _native
+from ..functions import MSDeformAttnBF16Function, MSDeformAttnFunction, MSDeformAttnPrologueFunction
 from ..functions.linear_func import bracket_linear
 
 
@@ -63,6 +64,9 @@ class MSDeformAttn(nn.Module):
         self.im2col_step = 64
         # opt-in, not in the reference: keep value / sampled output in bfloat16 (fp32 accumulation)
         self.bf16_storage = False
+        # softmax + location arithmetic inside the kernels where the geometry allows (fp32, 2-d / 42-d
+        # reference points); False = compose them in PyTorch exactly like the reference
+        self.fused_prologue = True
         self.d_model = d_model
         self.n_levels = n_levels
         self.n_heads = n_heads
@@ -120,10 +124,21 @@ class MSDeformAttn(nn.Module):
             N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
         attention_weights = bracket_linear(query, self.attention_weights).view(
             N, Len_q, self.n_heads, self.n_levels * self.n_points)
+
+        ref_dim = reference_points.shape[-1]
+        if self.fused_prologue and not self.bf16_storage and ref_dim in (2, 42):
+            # reference point per level: given (2-d) or the mean of the 21 keypoints (42-d, :121-122)
+            centre = reference_points if ref_dim == 2 else torch.stack(
+                [reference_points[..., 0::2].mean(-1), reference_points[..., 1::2].mean(-1)], -1)
+            if _native.prologue_supported(value, centre, sampling_offsets, attention_weights):
+                output = MSDeformAttnPrologueFunction.apply(
+                    value, input_spatial_shapes, input_level_start_index, centre, sampling_offsets,
+                    attention_weights, self.im2col_step)
+                return bracket_linear(output, self.output_proj)
+
         attention_weights = F.softmax(attention_weights, -1).view(
             N, Len_q, self.n_heads, self.n_levels, self.n_points)
 
-        ref_dim = reference_points.shape[-1]
         if ref_dim == 2 or ref_dim == 42:
             # offsets are in pixels of each level: normalise by (W_l, H_l)
             wh = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)
