@@ -392,3 +392,28 @@ def test_bf16_storage_vs_fp32_path_and_errors(native):
     with pytest.raises(RuntimeError, match="bf16"):
         MSDeformAttnBF16Function.apply(dev(zz["value"]), dev(zz["shapes"]), dev(zz["level_start"]),
                                        dev(zz["loc"]), dev(zz["attn"]), 64)
+
+
+def test_beyond_int32_element_offsets_uses_the_generic_kernels(native):
+    """N*S*M*D = 2^31 elements: the D=32 kernels' 32-bit row offsets no longer cover the tensor, the
+    dispatcher must route to the generic family (64-bit offsets) and the far end of the map must work."""
+    from uvhand_amd.functions import MSDeformAttnFunction
+    H, W, M, D = 2048, 4096, 8, 32                                     # S = 2^23 pixels, 8 GiB of fp32 value
+    shapes = torch.tensor([[H, W]], dtype=torch.long).cuda()
+    lsi = torch.zeros(1, dtype=torch.long).cuda()
+    value = torch.zeros(1, H * W, M, D, device="cuda")
+    y, x = H - 2, W - 3                                                  # a pixel near the end of the tensor
+    value[0, y * W + x] = torch.arange(M * D, dtype=torch.float32, device="cuda").view(M, D)
+    value.requires_grad_(True)
+    loc = torch.empty(1, 2, M, 1, 1, 2, device="cuda")
+    loc[..., 0] = (x + 0.5) / W                                          # exactly the pixel centre
+    loc[..., 1] = (y + 0.5) / H
+    attn = torch.ones(1, 2, M, 1, 1, device="cuda")
+    out = MSDeformAttnFunction.apply(value, shapes, lsi, loc, attn, 64)
+    assert torch.equal(out[0, 0], torch.arange(M * D, dtype=torch.float32, device="cuda"))
+    out.sum().backward()
+    torch.cuda.synchronize()
+    g = value.grad[0, y * W + x]
+    assert torch.all(g == 2.0) and value.grad.sum().item() == 2.0 * M * D     # two queries hit that pixel, nothing else
+    del value, out
+    torch.cuda.empty_cache()
