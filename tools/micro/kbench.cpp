@@ -7,6 +7,7 @@
 #include "../../uvhand_amd/csrc/msda_abi.hip"
 #include "../../uvhand_amd/csrc/msda_generic.hip"
 #include "../../uvhand_amd/csrc/msda_d32.hip"
+#include "../../uvhand_amd/csrc/msda_linear.hip"
 
 #include <algorithm>
 #include <cstdio>

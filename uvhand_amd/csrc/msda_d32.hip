@@ -1,5 +1,6 @@
-// D = 32, fp32 multi-scale deformable attention for MI355X (gfx950) — the shape the
-// UVHand transformers use (d_model 256 / 8 heads; util/settings.py:102-120).
+// D = 32 multi-scale deformable attention for MI355X (gfx950) — the shape the UVHand transformers
+// use (d_model 256 / 8 heads; util/settings.py:102-120): fp32 or bf16 rows, fp32 arithmetic; forward,
+// backward (role A + role B in one launch), and the fused-prologue variants of both.
 //
 // Work decomposition (not the reference's one-thread-per-channel / 32-thread blocks,
 // ms_deform_im2col_cuda.cuh:237-299, :301-403):
