@@ -117,18 +117,23 @@ int msda_backward_bf16(const uint16_t *grad_out, const uint16_t *value, const in
  *   backward: takes those saved tensors; returns grad_value and the gradients of the RAW tensors
  *             (offsets, logits — softmax backward included — and reference points, summed over heads
  *             and points).
+ * The module produces offsets and logits with two nn.Linear layers on the same input (:100-101); run as
+ * ONE GEMM their outputs are column blocks of a [N*Lq, ld] matrix.  ld_offsets / ld_logits are the floats
+ * between consecutive (batch, query) rows of those two tensors (0 = dense: 2*M*L*P and M*L*P); the raw
+ * gradients are written with ld_grad_offsets / ld_grad_logits the same way, so the backward of that one
+ * GEMM reads them in place.  Offsets need an even stride and an 8-byte aligned base.
  * msda_prologue_supported() != 0 iff the geometry qualifies (D = 32 family, L*P and P powers of two,
  * whole queries per workgroup); otherwise callers compose the plain entry points as the reference does. */
 int msda_prologue_supported(int N, int S, int M, int D, int L, int Lq, int P);
 int msda_forward_prologue_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
                               const float *reference_points, const float *sampling_offsets, const float *attn_logits,
-                              int N, int S, int M, int D, int L, int Lq, int P,
+                              int N, int S, int M, int D, int L, int Lq, int P, long long ld_offsets, long long ld_logits,
                               float *out, float *sampling_loc_out, float *attn_weight_out, msda_stream_t stream);
 int msda_backward_prologue_f32(const float *grad_out, const float *value, const int64_t *spatial_shapes,
                                const int64_t *level_start, const float *sampling_loc, const float *attn_weight,
-                               int N, int S, int M, int D, int L, int Lq, int P,
-                               float *grad_value, float *grad_sampling_offsets, float *grad_attn_logits,
-                               float *grad_reference_points, msda_stream_t stream);
+                               int N, int S, int M, int D, int L, int Lq, int P, long long ld_grad_offsets,
+                               long long ld_grad_logits, float *grad_value, float *grad_sampling_offsets,
+                               float *grad_attn_logits, float *grad_reference_points, msda_stream_t stream);
 
 /* ---- Bracketing projections ----------------------------------------------------
  * Weight and bias gradient of an fp32 nn.Linear  y[M,N] = x[M,K] . W[N,K]^T + b[N]:

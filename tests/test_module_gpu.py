@@ -145,3 +145,60 @@ def test_module_fused_and_unfused_prologue_agree():
         res[fused] = [out.detach()] + [t.grad for t in a[:3]] + [p.grad.clone() for p in mod.parameters()]
     for x, y in zip(res[True], res[False]):
         assert rel_err(x.cpu().numpy(), y.cpu().numpy()) < 2e-5
+
+
+@pytest.mark.parametrize("N,Lq,shapes", [(2, 300, [(48, 48), (24, 24), (12, 12), (6, 6)]),
+                                          (3, 5, [(5, 7), (3, 4)])])
+def test_merged_projection_function_equals_separate_tensors(N, Lq, shapes):
+    """Offsets and logits read in place from one [N, Lq, 3*M*L*P] projection output (row stride != dense
+    width), gradients written back into one tensor of that layout: bit-identical to the dense-tensor path
+    (grad_value up to summation order — the order of a row's records after the counting sort's LDS atomics
+    is not fixed run to run, as with the reference's atomicAdd scatter)."""
+    from uvhand_amd.functions import MSDeformAttnMergedPrologueFunction, MSDeformAttnPrologueFunction
+    sh, lsi, value, ref, off, logits, go = _prologue_case(7 * N + Lq, N, Lq, shapes)
+    M, L, P = 8, len(shapes), 4
+    out = MSDeformAttnPrologueFunction.apply(value, sh, lsi, ref, off, logits, 64)
+    out.backward(go)
+    want = [out.detach().clone()] + [t.grad.clone() for t in (value, ref, off, logits)]
+    for t in (value, ref, off, logits):
+        t.grad = None
+    proj = torch.cat([off.detach().reshape(N, Lq, -1), logits.detach().reshape(N, Lq, -1)], -1).requires_grad_(True)
+    out2 = MSDeformAttnMergedPrologueFunction.apply(value, sh, lsi, ref, proj, 64, M, L, P)
+    out2.backward(go)
+    mlp = M * L * P
+    got = [out2.detach(), value.grad, ref.grad, proj.grad[..., :2 * mlp].reshape(off.shape),
+           proj.grad[..., 2 * mlp:].reshape(logits.shape)]
+    for name, a, b in zip(("out", "value", "ref", "offsets", "logits"), got, want):
+        if name == "value":
+            assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-6
+        else:
+            assert torch.equal(a, b), name
+
+
+def test_prologue_rejects_bad_row_layouts():
+    from uvhand_amd import _native
+    sh, lsi, value, ref, off, logits, _ = _prologue_case(5, 2, 6, [(5, 7), (3, 4)])
+    with pytest.raises(RuntimeError, match="contiguous within a query row"):
+        _native.ms_deform_attn_forward_prologue(value, sh, lsi, ref, off.detach().transpose(3, 4).contiguous().transpose(3, 4),
+                                                logits.detach(), 64)
+    wide = torch.zeros(2, 6, 8 * 2 * 4 * 2 + 1, device="cuda")           # odd row stride for the (x, y) pairs
+    with pytest.raises(RuntimeError, match="row strides"):
+        _native.ms_deform_attn_forward_prologue(value, sh, lsi, ref, wide[..., :128].view(2, 6, 8, 2, 4, 2),
+                                                logits.detach(), 64)
+
+
+def test_module_merged_and_separate_projections_agree():
+    z = load_golden("module_2d")
+    mod = _module()
+    args = lambda: [torch.from_numpy(z[k]).cuda() for k in ("query", "refp", "src", "shapes", "level_start", "mask")]
+    res = {}
+    for merged in (True, False):
+        mod.merged_projection = merged
+        mod.zero_grad()
+        a = args()
+        a[0].requires_grad_(True); a[1].requires_grad_(True); a[2].requires_grad_(True)
+        out = mod(*a)
+        out.backward(torch.from_numpy(z["gout"]).cuda())
+        res[merged] = [out.detach()] + [t.grad for t in a[:3]] + [p.grad.clone() for p in mod.parameters()]
+    for x, y in zip(res[True], res[False]):
+        assert rel_err(x.cpu().numpy(), y.cpu().numpy()) < 1e-5

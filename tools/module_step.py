@@ -12,11 +12,13 @@ name = sys.argv[1] if len(sys.argv) > 1 else "cfg4_encoder"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 amp = os.environ.get("MODULE_AMP", "")            # "bf16": autocast + bf16 storage in the op
 fused = os.environ.get("MODULE_FUSED_PROLOGUE", "1") != "0"
+merged = os.environ.get("MODULE_MERGED_PROJECTION", "1") != "0"
 N, shapes, M, D, Lq, P = WORKLOADS[name]
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 mod = MSDeformAttn(M * D, len(shapes), M, P).to(dev)
 mod.fused_prologue = fused
+mod.merged_projection = merged
 with torch.no_grad():
     for p in mod.parameters():
         p.add_(torch.randn_like(p) * 0.02)

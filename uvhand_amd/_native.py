@@ -261,54 +261,92 @@ def prologue_supported(value, reference_points, sampling_offsets, attn_logits):
     return bool(lib.msda_prologue_supported(N, S, M, D, L, Lq, P))
 
 
+def _row_stride(t, name):
+    """Floats between consecutive (batch, query) rows of `t` [N, Lq, ...]: the trailing dimensions must be
+    dense and the batch stride Lq rows — i.e. `t` is a column block of a row-major [N*Lq, ld] matrix."""
+    inner = 1
+    for size, stride in zip(reversed(t.shape[2:]), reversed(t.stride()[2:])):
+        if size != 1 and stride != inner:
+            raise RuntimeError("%s tensor has to be contiguous within a query row" % name)
+        inner *= size
+    ld = t.stride(1) if t.shape[1] > 1 else inner
+    if ld < inner or (t.shape[0] > 1 and t.stride(0) != t.shape[1] * ld):
+        raise RuntimeError("%s tensor has to be contiguous or a column block of a row-major matrix" % name)
+    return ld
+
+
+_LL = ctypes.c_longlong
+
+
+def prologue_geometry_supported(N, S, M, D, L, Lq, P):
+    """msda_prologue_supported (include/msda.h) for fp32 tensors of these sizes."""
+    lib = _lib or load()
+    return bool(lib.msda_prologue_supported(N, S, M, D, L, Lq, P))
+
+
 def ms_deform_attn_forward_prologue(value, spatial_shapes, level_start_index, reference_points, sampling_offsets,
                                     attn_logits, im2col_step):
     """Fused-prologue forward (include/msda.h).  Returns (out, sampling_loc, attn_weight); the last two are
-    what the reference's Python would have computed and are what the backward consumes."""
+    what the reference's Python would have computed and are what the backward consumes.  `sampling_offsets`
+    [N,Lq,M,L,P,2] and `attn_logits` [N,Lq,M,L*P] may be column blocks of one wider projection output."""
     lib = _lib or load()
     _check_inputs((("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
-                   ("reference_points", reference_points), ("sampling_offsets", sampling_offsets),
-                   ("attn_logits", attn_logits)))
+                   ("reference_points", reference_points)))
+    for name, t in (("sampling_offsets", sampling_offsets), ("attn_logits", attn_logits)):
+        if not t.is_cuda or t.device != value.device:
+            raise RuntimeError("%s must be a CUDA tensor on the device of value" % name)
     N, S, M, D = value.shape
     Lq, L, P = sampling_offsets.shape[1], sampling_offsets.shape[3], sampling_offsets.shape[4]
-    if (tuple(sampling_offsets.shape) != (N, Lq, M, L, P, 2) or attn_logits.numel() != N * Lq * M * L * P
+    if (tuple(sampling_offsets.shape) != (N, Lq, M, L, P, 2) or tuple(attn_logits.shape) != (N, Lq, M, L * P)
             or tuple(reference_points.shape) != (N, Lq, L, 2) or tuple(spatial_shapes.shape) != (L, 2)):
         raise RuntimeError("ms_deform_attn_forward_prologue: inconsistent shapes")
+    ld_off, ld_log = _row_stride(sampling_offsets, "sampling_offsets"), _row_stride(attn_logits, "attn_logits")
     step = min(N, int(im2col_step))
     if N > 0 and (step <= 0 or N % step != 0):
         raise RuntimeError("batch(%d) must divide im2col_step(%d)" % (N, step))
     with _DeviceGuard(value.device):
         out = torch.empty((N, Lq, M * D), dtype=torch.float32, device=value.device)
-        loc = torch.empty_like(sampling_offsets)
+        loc = torch.empty((N, Lq, M, L, P, 2), dtype=torch.float32, device=value.device)
         attn = torch.empty((N, Lq, M, L, P), dtype=torch.float32, device=value.device)
-        rc = _entry(lib, "msda_forward_prologue_f32", [_VP] * 6 + [_CI] * 7 + [_VP] * 4)(
+        rc = _entry(lib, "msda_forward_prologue_f32", [_VP] * 6 + [_CI] * 7 + [_LL] * 2 + [_VP] * 4)(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), reference_points.data_ptr(),
-            sampling_offsets.data_ptr(), attn_logits.data_ptr(), N, S, M, D, L, Lq, P, out.data_ptr(), loc.data_ptr(),
-            attn.data_ptr(), _raw_stream(value.device))
+            sampling_offsets.data_ptr(), attn_logits.data_ptr(), N, S, M, D, L, Lq, P, ld_off, ld_log, out.data_ptr(),
+            loc.data_ptr(), attn.data_ptr(), _raw_stream(value.device))
     if rc != 0:
         _raise(lib, rc, "ms_deform_attn_forward_prologue")
     return out, loc, attn
 
 
-def ms_deform_attn_backward_prologue(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output):
-    """Returns (grad_value, grad_sampling_offsets, grad_attn_logits[N,Lq,M,L*P], grad_reference_points[N,Lq,L,2])."""
+def ms_deform_attn_backward_prologue(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output,
+                                     merged=False):
+    """Returns (grad_value, grad_sampling_offsets, grad_attn_logits[N,Lq,M,L*P], grad_reference_points[N,Lq,L,2]).
+    merged=True: the two raw gradients are the column blocks [0, 2*M*L*P) and [2*M*L*P, 3*M*L*P) of ONE
+    [N, Lq, 3*M*L*P] tensor — the gradient of a merged offsets+logits projection — returned as a fifth value."""
     lib = _lib or load()
     _check_inputs((("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
                    ("sampling_loc", sampling_loc), ("attn_weight", attn_weight), ("grad_output", grad_output)))
     N, S, M, D = value.shape
     Lq, L, P = sampling_loc.shape[1], sampling_loc.shape[3], sampling_loc.shape[4]
+    mlp = M * L * P
     with _DeviceGuard(value.device):
         gv = torch.empty_like(value)
-        goff = torch.empty_like(sampling_loc)
-        glog = torch.empty((N, Lq, M, L * P), dtype=torch.float32, device=value.device)
+        if merged:
+            both = torch.empty((N, Lq, 3 * mlp), dtype=torch.float32, device=value.device)
+            goff, glog = both[..., :2 * mlp].view(N, Lq, M, L, P, 2), both[..., 2 * mlp:].view(N, Lq, M, L * P)
+            ld_off = ld_log = 3 * mlp
+        else:
+            both = None
+            goff = torch.empty_like(sampling_loc)
+            glog = torch.empty((N, Lq, M, L * P), dtype=torch.float32, device=value.device)
+            ld_off = ld_log = 0
         gref = torch.empty((N, Lq, L, 2), dtype=torch.float32, device=value.device)
-        rc = _entry(lib, "msda_backward_prologue_f32", [_VP] * 6 + [_CI] * 7 + [_VP] * 5)(
+        rc = _entry(lib, "msda_backward_prologue_f32", [_VP] * 6 + [_CI] * 7 + [_LL] * 2 + [_VP] * 5)(
             grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
-            sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P, gv.data_ptr(), goff.data_ptr(),
-            glog.data_ptr(), gref.data_ptr(), _raw_stream(value.device))
+            sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P, ld_off, ld_log, gv.data_ptr(),
+            goff.data_ptr(), glog.data_ptr(), gref.data_ptr(), _raw_stream(value.device))
     if rc != 0:
         _raise(lib, rc, "ms_deform_attn_backward_prologue")
-    return gv, goff, glog, gref
+    return (gv, goff, glog, gref, both) if merged else (gv, goff, glog, gref)
 
 
 def path_for(elem_bytes, M, D, L, P):

@@ -37,6 +37,24 @@ static int check_args(const void *const *ptrs, int nptrs, int N, int S, int M, i
     return MSDA_OK;
 }
 
+// Row strides of the fused-prologue tensors: 0 selects the dense layout; otherwise at least the dense
+// width, and for the (x, y) pairs an even stride on an 8-byte aligned base (the kernels move float2).
+static int check_row_strides(const char *who, int M, int L, int P, const void *offsets, long long *ld_offsets,
+                             long long *ld_logits)
+{
+    const long long dense = (long long)M * L * P;
+    if (*ld_offsets == 0) *ld_offsets = 2 * dense;
+    if (*ld_logits == 0) *ld_logits = dense;
+    char buf[200];
+    if (*ld_offsets < 2 * dense || *ld_logits < dense || (*ld_offsets & 1) || ((uintptr_t)offsets & 7) ||
+        *ld_offsets - 2 * dense > 0x7fffffffLL || *ld_logits - dense > 0x7fffffffLL) {
+        std::snprintf(buf, sizeof(buf), "%s: row strides (%lld, %lld) must be >= (%lld, %lld), the first even on an "
+                      "8-byte aligned base", who, *ld_offsets, *ld_logits, 2 * dense, dense);
+        return set_error(MSDA_ERR_ARGUMENT, buf);
+    }
+    return MSDA_OK;
+}
+
 static bool use_d32(int N, int S, int M, int D, int L, int Lq, int P)
 {
     const int f = g_force_path.load(std::memory_order_relaxed);
@@ -188,22 +206,25 @@ int msda_prologue_supported(int N, int S, int M, int D, int L, int Lq, int P)
 
 int msda_forward_prologue_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
                               const float *reference_points, const float *sampling_offsets, const float *attn_logits,
-                              int N, int S, int M, int D, int L, int Lq, int P, float *out, float *sampling_loc_out,
-                              float *attn_weight_out, msda_stream_t stream)
+                              int N, int S, int M, int D, int L, int Lq, int P, long long ld_offsets, long long ld_logits,
+                              float *out, float *sampling_loc_out, float *attn_weight_out, msda_stream_t stream)
 {
     const void *ptrs[] = {value, spatial_shapes, level_start, reference_points, sampling_offsets, attn_logits, out,
                           sampling_loc_out, attn_weight_out};
     if (int rc = msda::check_args(ptrs, 9, N, S, M, D, L, Lq, P)) return rc;
     if (!msda_prologue_supported(N, S, M, D, L, Lq, P))
         return msda::set_error(MSDA_ERR_ARGUMENT, "msda_forward_prologue_f32: geometry not supported (msda_prologue_supported)");
+    if (int rc = msda::check_row_strides("msda_forward_prologue_f32", M, L, P, sampling_offsets, &ld_offsets, &ld_logits)) return rc;
     msda::g_err[0] = 0;
     return msda::launch_fwd_prologue(value, spatial_shapes, level_start, reference_points, sampling_offsets, attn_logits, N,
-                                     S, M, L, Lq, P, out, sampling_loc_out, attn_weight_out, (hipStream_t)stream);
+                                     S, M, L, Lq, P, ld_offsets, ld_logits, out, sampling_loc_out, attn_weight_out,
+                                     (hipStream_t)stream);
 }
 
 int msda_backward_prologue_f32(const float *grad_out, const float *value, const int64_t *spatial_shapes,
                                const int64_t *level_start, const float *sampling_loc, const float *attn_weight, int N,
-                               int S, int M, int D, int L, int Lq, int P, float *grad_value, float *grad_sampling_offsets,
+                               int S, int M, int D, int L, int Lq, int P, long long ld_grad_offsets,
+                               long long ld_grad_logits, float *grad_value, float *grad_sampling_offsets,
                                float *grad_attn_logits, float *grad_reference_points, msda_stream_t stream)
 {
     const void *ptrs[] = {grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, grad_value,
@@ -211,10 +232,12 @@ int msda_backward_prologue_f32(const float *grad_out, const float *value, const 
     if (int rc = msda::check_args(ptrs, 10, N, S, M, D, L, Lq, P)) return rc;
     if (!msda_prologue_supported(N, S, M, D, L, Lq, P))
         return msda::set_error(MSDA_ERR_ARGUMENT, "msda_backward_prologue_f32: geometry not supported (msda_prologue_supported)");
+    if (int rc = msda::check_row_strides("msda_backward_prologue_f32", M, L, P, grad_sampling_offsets, &ld_grad_offsets,
+                                         &ld_grad_logits)) return rc;
     msda::g_err[0] = 0;
     return msda::launch_bwd_prologue(grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M, L,
-                                     Lq, P, grad_value, grad_sampling_offsets, grad_attn_logits, grad_reference_points,
-                                     (hipStream_t)stream);
+                                     Lq, P, grad_value, ld_grad_offsets, ld_grad_logits, grad_sampling_offsets,
+                                     grad_attn_logits, grad_reference_points, (hipStream_t)stream);
 }
 
 unsigned long long msda_linear_wgrad_workspace_bytes(int M, int N, int K)

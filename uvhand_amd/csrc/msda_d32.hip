@@ -157,8 +157,11 @@ __device__ __forceinline__ void item_bm(int il, int b0, int r0, int m0, int LqM,
 // ms_deform_attn.py:101-108) done by the point lanes of the prepass instead of 3 elementwise launches
 // over the [N,Lq,M,L,P,*] tensors.  The L*P points of an item sit on L*P consecutive lanes (L*P a power
 // of two <= 64), so max and sum are xor-shuffles inside that lane group.
-struct PrologueIn  { const float *ref; float *loc_out; float *attn_out; };      // ref[N,Lq,L,2]; saved for backward
-struct PrologueOut { float *grad_ref; };                                        // grad_ref[N,Lq,L,2]
+// The raw offsets / logits (and their gradients) may be column blocks of a wider row-major matrix — the
+// output of ONE projection GEMM for both (f1) — so each carries the distance between consecutive query
+// rows beyond its own M*L*P points: off_pad in float2 units, log_pad in floats (0 = dense tensors).
+struct PrologueIn  { const float *ref; float *loc_out; float *attn_out; int off_pad, log_pad; };   // ref[N,Lq,L,2]
+struct PrologueOut { float *grad_ref; int off_pad, log_pad; };                                       // grad_ref[N,Lq,L,2]
 
 __device__ __forceinline__ float group_max(float x, int width)
 {
@@ -170,14 +173,6 @@ __device__ __forceinline__ float group_sum(float x, int width)
     for (int m = 1; m < width; m <<= 1) x += __shfl_xor(x, m, kWave);
     return x;
 }
-// query index of the il-th item after item0 (r0 = item0 % (Lq*M))
-__device__ __forceinline__ int item_query(int il, int r0, int LqM, int M, int m_shift)
-{
-    int t = r0 + il;
-    if (t >= LqM) t -= LqM * (t / LqM);
-    return fdiv(t, M, m_shift);
-}
-
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
@@ -187,7 +182,7 @@ __global__ __launch_bounds__(kBlock) void fwd_d32_kernel(
     const VT *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ level_start, const float *__restrict__ loc,
     const float *__restrict__ attn, int S, int M, int L, int Lq, int P, int items, int p_shift,
-    int lp_shift, int m_shift, VT *__restrict__ out, const PrologueIn pro = PrologueIn{nullptr, nullptr, nullptr})
+    int lp_shift, int m_shift, VT *__restrict__ out, const PrologueIn pro = PrologueIn{nullptr, nullptr, nullptr, 0, 0})
 {
     constexpr int IPW = 32 / SPLIT;                       // items per workgroup
     constexpr int OPW = 4 / SPLIT;                        // octets per workgroup
@@ -212,20 +207,21 @@ __global__ __launch_bounds__(kBlock) void fwd_d32_kernel(
         r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0.f;
         if (item < items) {
             const int l = fdiv(pt, P, p_shift);
-            float2 xy = reinterpret_cast<const float2 *>(loc)[(long long)item0 * LP + idx];
-            float a = attn[(long long)item0 * LP + idx];
+            const long long e = (long long)item0 * LP + idx;
+            const long long row = FUSED ? fdiv(item, M, m_shift) : 0;           // b*Lq + q
+            float2 xy = reinterpret_cast<const float2 *>(loc)[FUSED ? e + row * pro.off_pad : e];
+            float a = attn[FUSED ? e + row * pro.log_pad : e];
             LevelInfo li;
             li.H = (int)shapes[2 * l]; li.W = (int)shapes[2 * l + 1]; li.start = (int)level_start[l]; li.pad = 0;
             int b, m;
             item_bm(il, b0, r0, m0, LqM, M, m_shift, b, m);
             if (FUSED) {
-                const int q = item_query(il, r0, LqM, M, m_shift);
-                const float2 rp = reinterpret_cast<const float2 *>(pro.ref)[((long long)b * Lq + q) * L + l];
+                const float2 rp = reinterpret_cast<const float2 *>(pro.ref)[row * L + l];
                 xy = make_float2(rp.x + xy.x / (float)li.W, rp.y + xy.y / (float)li.H);
-                const float e = expf(a - group_max(a, LP));
-                a = e / group_sum(e, LP);
-                reinterpret_cast<float2 *>(pro.loc_out)[(long long)item0 * LP + idx] = xy;
-                pro.attn_out[(long long)item0 * LP + idx] = a;
+                const float ex = expf(a - group_max(a, LP));
+                a = ex / group_sum(ex, LP);
+                reinterpret_cast<float2 *>(pro.loc_out)[e] = xy;
+                pro.attn_out[e] = a;
             }
             const PointGeom<float> g = point_geom<float>(xy.x, xy.y, li.H, li.W);
             if (g.inside) {
@@ -311,7 +307,7 @@ __device__ __forceinline__ void bwd_query_body(
     const float *__restrict__ loc, const float *__restrict__ attn, int S, int M, int L, int Lq,
     int P, int items, int p_shift, int lp_shift, int m_shift, VT *__restrict__ grad_value,
     float *__restrict__ grad_loc, float *__restrict__ grad_attn, int block, unsigned char *smem,
-    const PrologueOut pro = PrologueOut{nullptr})
+    const PrologueOut pro = PrologueOut{nullptr, 0, 0})
 {
     constexpr int IPW = (THREADS / kWave) * 8 / SPLIT;      // items per workgroup
     unsigned char *recs = smem;
@@ -409,11 +405,12 @@ __device__ __forceinline__ void bwd_query_body(
             const float gx = r.x * (float)(int)shapes[2 * l + 1], gy = r.y * (float)(int)shapes[2 * l];
             if (FUSED) {
                 // d loc / d offset = 1 / (W, H): the pixel-space sums are the offset gradients
-                reinterpret_cast<float2 *>(grad_loc)[(long long)item0 * LP + idx] = make_float2(r.x, r.y);
+                const long long e = (long long)item0 * LP + idx, row = fdiv(item0 + il2, M, m_shift);
+                reinterpret_cast<float2 *>(grad_loc)[e + row * pro.off_pad] = make_float2(r.x, r.y);
                 // softmax backward over the item's L*P lanes
-                const float a = attn[(long long)item0 * LP + idx];
+                const float a = attn[e];
                 const float dot = group_sum(a * r.z, LP);
-                grad_attn[(long long)item0 * LP + idx] = a * (r.z - dot);
+                grad_attn[e + row * pro.log_pad] = a * (r.z - dot);
                 // reference point: sum over the level's P points here, over the heads below
                 const float sx = group_sum(gx, P), sy = group_sum(gy, P);
                 if ((pt & (P - 1)) == 0) refpart[il2 * L + l] = make_float2(sx, sy);
@@ -716,7 +713,7 @@ __global__ __launch_bounds__(kSBlock) void bwd_fused_d32_kernel(
     const float *__restrict__ loc, const float *__restrict__ attn, int S, int M, int L, int Lq,
     int P, int items, int p_shift, int lp_shift, int m_shift, int tp_cap, int W, int nB,
     VT *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attn,
-    const PrologueOut pro = PrologueOut{nullptr})
+    const PrologueOut pro = PrologueOut{nullptr, 0, 0})
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int bid = (int)blockIdx.x;
@@ -912,8 +909,9 @@ bool prologue_supported(int N, int S, int M, int D, int L, int Lq, int P)
 }
 
 int launch_fwd_prologue(const float *value, const int64_t *shapes, const int64_t *level_start, const float *ref,
-                        const float *offsets, const float *logits, int N, int S, int M, int L, int Lq, int P, float *out,
-                        float *loc_out, float *attn_out, hipStream_t stream)
+                        const float *offsets, const float *logits, int N, int S, int M, int L, int Lq, int P,
+                        long long ld_offsets, long long ld_logits, float *out, float *loc_out, float *attn_out,
+                        hipStream_t stream)
 {
     const int items = N * Lq * M, LP = L * P;
     const int item_stride = LP * kRecBytes + kItemPad;
@@ -921,7 +919,7 @@ int launch_fwd_prologue(const float *value, const int64_t *shapes, const int64_t
     const int ipw = 32 / split;
     const size_t lds = (size_t)ipw * item_stride + (split > 1 ? 4096 : 0);
     const dim3 grid((items + ipw - 1) / ipw), block(kBlock);
-    const PrologueIn pro{ref, loc_out, attn_out};
+    const PrologueIn pro{ref, loc_out, attn_out, (int)((ld_offsets - 2LL * M * LP) / 2), (int)(ld_logits - (long long)M * LP)};
 #define MSDA_LAUNCH_FP(SP)                                                                             \
     hipLaunchKernelGGL((fwd_d32_kernel<SP, float, true>), grid, block, lds, stream, value, shapes, level_start, offsets, \
                        logits, S, M, L, Lq, P, items, pow2_shift(P), pow2_shift(LP), pow2_shift(M), out, pro)
@@ -932,7 +930,8 @@ int launch_fwd_prologue(const float *value, const int64_t *shapes, const int64_t
 
 int launch_bwd_prologue(const float *grad_out, const float *value, const int64_t *shapes, const int64_t *level_start,
                         const float *loc, const float *attn, int N, int S, int M, int L, int Lq, int P, float *grad_value,
-                        float *grad_offsets, float *grad_logits, float *grad_ref, hipStream_t stream)
+                        long long ld_grad_offsets, long long ld_grad_logits, float *grad_offsets, float *grad_logits,
+                        float *grad_ref, hipStream_t stream)
 {
     const int items = N * Lq * M, LP = L * P;
     const int item_stride = LP * kRecBytes + kItemPad;
@@ -947,7 +946,7 @@ int launch_bwd_prologue(const float *grad_out, const float *value, const int64_t
         return set_error(MSDA_ERR_ARGUMENT, "msda backward (fused prologue): geometry not supported");
     const dim3 fgrid((unsigned)(nB + nA));
     const size_t flds = pl.lds > lds_a ? pl.lds : lds_a;
-    const PrologueOut pro{grad_ref};
+    const PrologueOut pro{grad_ref, (int)((ld_grad_offsets - 2LL * M * LP) / 2), (int)(ld_grad_logits - (long long)M * LP)};
 #define MSDA_LAUNCH_BP(SP, AC)                                                                         \
     hipLaunchKernelGGL((bwd_fused_d32_kernel<SP, AC, float, true>), fgrid, dim3(kSBlock), flds, stream, grad_out, value,  \
                        shapes, level_start, loc, attn, S, M, L, Lq, P, items, ps, lps, ms, pl.tp_cap, pl.W, (int)nB,    \

@@ -43,14 +43,18 @@ int launch_bwd_d32_bf16(const uint16_t *grad_out, const uint16_t *value, const i
                         int M, int L, int Lq, int P, uint16_t *grad_value, float *grad_loc, float *grad_attn,
                         hipStream_t stream);
 
-// ---- fused prologue (fp32, D = 32 family): softmax over L*P and loc = ref + offset/(W,H) inside the kernels
+// ---- fused prologue (fp32, D = 32 family): softmax over L*P and loc = ref + offset/(W,H) inside the kernels.
+// ld_* = floats between consecutive (batch, query) rows of the raw offsets / logits and of their gradients
+// (validated by the ABI layer: >= the dense width, offsets' even).
 bool prologue_supported(int N, int S, int M, int D, int L, int Lq, int P);
 int launch_fwd_prologue(const float *value, const int64_t *shapes, const int64_t *level_start, const float *ref,
-                        const float *offsets, const float *logits, int N, int S, int M, int L, int Lq, int P, float *out,
-                        float *loc_out, float *attn_out, hipStream_t stream);
+                        const float *offsets, const float *logits, int N, int S, int M, int L, int Lq, int P,
+                        long long ld_offsets, long long ld_logits, float *out, float *loc_out, float *attn_out,
+                        hipStream_t stream);
 int launch_bwd_prologue(const float *grad_out, const float *value, const int64_t *shapes, const int64_t *level_start,
                         const float *loc, const float *attn, int N, int S, int M, int L, int Lq, int P, float *grad_value,
-                        float *grad_offsets, float *grad_logits, float *grad_ref, hipStream_t stream);
+                        long long ld_grad_offsets, long long ld_grad_logits, float *grad_offsets, float *grad_logits,
+                        float *grad_ref, hipStream_t stream);
 
 // ---- weight / bias gradient of the bracketing nn.Linear layers (msda_linear.hip) -----------------
 size_t linear_wgrad_workspace_bytes(int M, int N, int K);

@@ -1,3 +1,5 @@
-from .ms_deform_attn_func import MSDeformAttnBF16Function, MSDeformAttnFunction, MSDeformAttnPrologueFunction
+from .ms_deform_attn_func import (MSDeformAttnBF16Function, MSDeformAttnFunction, MSDeformAttnMergedPrologueFunction,
+                                  MSDeformAttnPrologueFunction)
 
-__all__ = ["MSDeformAttnFunction", "MSDeformAttnBF16Function", "MSDeformAttnPrologueFunction"]
+__all__ = ["MSDeformAttnFunction", "MSDeformAttnBF16Function", "MSDeformAttnPrologueFunction",
+           "MSDeformAttnMergedPrologueFunction"]

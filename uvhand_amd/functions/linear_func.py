@@ -54,10 +54,21 @@ class _BracketLinearFn(Function):
 _ENABLED = os.environ.get("MSDA_BRACKET_LINEAR", "1") != "0"       # A/B knob: 0 = always the plain layer
 
 
+def _kernel_applies(x, weight):
+    return (_ENABLED and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32
+            and not torch.is_autocast_enabled() and torch.is_grad_enabled()
+            and weight.shape[1] % 4 == 0 and weight.shape[0] % 4 == 0)
+
+
+def bracket_linear_wb(x, weight, bias):
+    """``F.linear(x, weight, bias)``; custom weight-gradient kernel when applicable."""
+    if _kernel_applies(x, weight):
+        return _BracketLinearFn.apply(x, weight, bias)
+    return F.linear(x, weight, bias)
+
+
 def bracket_linear(x, layer):
     """``layer(x)`` for an ``nn.Linear`` ``layer``; custom weight-gradient kernel when applicable."""
-    if (_ENABLED and x.is_cuda and x.dtype == torch.float32 and layer.weight.dtype == torch.float32
-            and not torch.is_autocast_enabled() and torch.is_grad_enabled()
-            and layer.in_features % 4 == 0 and layer.out_features % 4 == 0):
+    if _kernel_applies(x, layer.weight):
         return _BracketLinearFn.apply(x, layer.weight, layer.bias)
     return layer(x)

@@ -100,9 +100,10 @@ class MSDeformAttnPrologueFunction(Function):
     @staticmethod
     def forward(ctx, value, value_spatial_shapes, value_level_start_index, reference_points, sampling_offsets,
                 attn_logits, im2col_step):
+        N, Lq, M, L, P, _ = sampling_offsets.shape
         out, loc, attn = MSDA.ms_deform_attn_forward_prologue(
             value, value_spatial_shapes, value_level_start_index, reference_points.contiguous(),
-            sampling_offsets.contiguous(), attn_logits.contiguous(), im2col_step)
+            sampling_offsets.contiguous(), attn_logits.contiguous().view(N, Lq, M, L * P), im2col_step)
         ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, loc, attn)
         ctx.logits_shape = attn_logits.shape
         return out
@@ -114,3 +115,41 @@ class MSDeformAttnPrologueFunction(Function):
         gv, goff, glog, gref = MSDA.ms_deform_attn_backward_prologue(
             value, value_spatial_shapes, value_level_start_index, loc, attn, grad_output.contiguous())
         return gv, None, None, gref, goff, glog.view(ctx.logits_shape), None
+
+
+class MSDeformAttnMergedPrologueFunction(Function):
+    """``MSDeformAttnPrologueFunction`` fed by ONE projection for offsets and logits (the
+    module's ``sampling_offsets`` and ``attention_weights`` layers, models/ops/modules/ms_deform_attn.py:100-101,
+    read the same ``query``):
+
+        out = apply(value, spatial_shapes, level_start_index, reference_points[N,Lq,L,2],
+                    projected[N,Lq,3*M*L*P], im2col_step, M, L, P)
+
+    ``projected[..., :2*M*L*P]`` are the raw offsets ([M,L,P,2] order), the rest the logits ([M,L*P]); the
+    kernels read both in place (row stride 3*M*L*P) and the backward writes their gradients into one tensor
+    of the same layout, so the projection's backward is one input-gradient GEMM and one weight-gradient GEMM
+    instead of two of each plus an add."""
+
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, reference_points, projected, im2col_step,
+                n_heads, n_levels, n_points):
+        N, Lq, width = projected.shape
+        mlp = n_heads * n_levels * n_points
+        if width != 3 * mlp:
+            raise RuntimeError("projected tensor must hold 2*M*L*P offsets and M*L*P logits per query (got %d, "
+                               "expected %d)" % (width, 3 * mlp))
+        projected = projected.contiguous()
+        out, loc, attn = MSDA.ms_deform_attn_forward_prologue(
+            value, value_spatial_shapes, value_level_start_index, reference_points.contiguous(),
+            projected[..., :2 * mlp].view(N, Lq, n_heads, n_levels, n_points, 2),
+            projected[..., 2 * mlp:].view(N, Lq, n_heads, n_levels * n_points), im2col_step)
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, loc, attn)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, value_spatial_shapes, value_level_start_index, loc, attn = ctx.saved_tensors
+        gv, _, _, gref, gproj = MSDA.ms_deform_attn_backward_prologue(
+            value, value_spatial_shapes, value_level_start_index, loc, attn, grad_output.contiguous(), merged=True)
+        return gv, None, None, gref, gproj, None, None, None, None

@@ -26,8 +26,9 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import _native
-from ..functions import MSDeformAttnBF16Function, MSDeformAttnFunction, MSDeformAttnPrologueFunction
-from ..functions.linear_func import bracket_linear
+from ..functions import (MSDeformAttnBF16Function, MSDeformAttnFunction, MSDeformAttnMergedPrologueFunction,
+                         MSDeformAttnPrologueFunction)
+from ..functions.linear_func import bracket_linear, bracket_linear_wb
 
 
 # (data_ptr, version, Len_in) of spatial_shapes tensors whose H*W sum was already verified: the
@@ -67,6 +68,9 @@ class MSDeformAttn(nn.Module):
         # softmax + location arithmetic inside the kernels where the geometry allows (fp32, 2-d / 42-d
         # reference points); False = compose them in PyTorch exactly like the reference
         self.fused_prologue = True
+        # with the fused prologue: sampling_offsets and attention_weights (two layers on the same query) as
+        # ONE GEMM whose output the kernels read in place; the parameters stay two nn.Linear modules
+        self.merged_projection = True
         self.d_model = d_model
         self.n_levels = n_levels
         self.n_heads = n_heads
@@ -120,12 +124,28 @@ class MSDeformAttn(nn.Module):
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], float(0))
         value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
+        ref_dim = reference_points.shape[-1]
+
+        if (self.fused_prologue and self.merged_projection and not self.bf16_storage and ref_dim in (2, 42)
+                and value.is_cuda and value.dtype == torch.float32 and query.dtype == torch.float32
+                and reference_points.dtype == torch.float32 and not torch.is_autocast_enabled()
+                and _native.prologue_geometry_supported(N, Len_in, self.n_heads, self.d_model // self.n_heads,
+                                                        self.n_levels, Len_q, self.n_points)):
+            centre = reference_points if ref_dim == 2 else torch.stack(
+                [reference_points[..., 0::2].mean(-1), reference_points[..., 1::2].mean(-1)], -1)
+            projected = bracket_linear_wb(
+                query, torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0),
+                torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0))
+            output = MSDeformAttnMergedPrologueFunction.apply(
+                value, input_spatial_shapes, input_level_start_index, centre, projected, self.im2col_step,
+                self.n_heads, self.n_levels, self.n_points)
+            return bracket_linear(output, self.output_proj)
+
         sampling_offsets = bracket_linear(query, self.sampling_offsets).view(
             N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
         attention_weights = bracket_linear(query, self.attention_weights).view(
             N, Len_q, self.n_heads, self.n_levels * self.n_points)
 
-        ref_dim = reference_points.shape[-1]
         if self.fused_prologue and not self.bf16_storage and ref_dim in (2, 42):
             # reference point per level: given (2-d) or the mean of the 21 keypoints (42-d, :121-122)
             centre = reference_points if ref_dim == 2 else torch.stack(
