@@ -147,6 +147,18 @@ unsigned long long msda_linear_wgrad_workspace_bytes(int M, int N, int K);
 int msda_linear_wgrad_f32(const float *grad_out, const float *input, int M, int N, int K,
                           float *grad_weight, float *grad_bias, void *workspace, msda_stream_t stream);
 
+/* Padding mask of value_proj (models/ops/modules/ms_deform_attn.py:97-98:
+ * value = value.masked_fill(input_padding_mask[..., None], 0)) without the two full passes over
+ * [N, S, C] that masked_fill and its backward cost:
+ *   msda_zero_masked_rows_f32     x[r, :] = 0 where row_mask[r] != 0, in place (forward: on the GEMM output;
+ *                                 backward: on the input gradient) — touches the mask and the masked rows only;
+ *   msda_linear_wgrad_masked_f32  msda_linear_wgrad_f32 with the rows of grad_out where row_mask[r] != 0
+ *                                 taken as zero (row_mask may be NULL = no mask).
+ * row_mask: one byte per row (a torch.bool tensor's storage).  cols must be a multiple of 4, x 16-byte aligned. */
+int msda_linear_wgrad_masked_f32(const float *grad_out, const float *input, const uint8_t *row_mask, int M, int N, int K,
+                                 float *grad_weight, float *grad_bias, void *workspace, msda_stream_t stream);
+int msda_zero_masked_rows_f32(float *x, const uint8_t *row_mask, long long rows, int cols, msda_stream_t stream);
+
 /* Thread-local description of the last failure on the calling thread ("" if none). */
 const char *msda_last_error(void);
 

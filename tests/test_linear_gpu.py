@@ -61,3 +61,46 @@ def test_bracket_linear_equals_nn_linear():
     z = torch.randn(5, 10).cuda().requires_grad_(True)
     bracket_linear(z, odd).sum().backward()
     assert z.grad is not None
+
+
+@pytest.mark.parametrize("M,N,K,frac", [(600, 256, 256, 0.3), (6120, 256, 256, 0.05), (37, 12, 20, 0.5), (70, 68, 132, 1.0)])
+def test_masked_wgrad_and_zero_rows(M, N, K, frac):
+    """Rows flagged in the padding mask count as zero rows of grad_out; zero_masked_rows_ touches exactly them."""
+    from uvhand_amd import _native
+    g = torch.Generator().manual_seed(M + N)
+    dy = torch.randn(M, N, generator=g).cuda()
+    x = torch.randn(M, K, generator=g).cuda()
+    mask = (torch.rand(M, generator=g) < frac).cuda()
+    dym = dy.masked_fill(mask[:, None], 0.0)
+    gw, gb = _native.linear_wgrad(dy, x, row_mask=mask)
+    gw_ref, gb_ref = _native.linear_wgrad(dym, x)
+    assert torch.equal(gw, gw_ref) and torch.equal(gb, gb_ref)         # same products, same order
+    y = dy.clone()
+    y[mask] = float("nan")                                             # masked rows may hold anything
+    assert torch.equal(_native.zero_masked_rows_(y, mask), dym)
+    with pytest.raises(RuntimeError, match="row_mask"):
+        _native.linear_wgrad(dy, x, row_mask=mask[:-1])
+
+
+def test_bracket_linear_masked_equals_linear_then_masked_fill():
+    """value_proj + padding mask (modules/ms_deform_attn.py:96-98) through the masked-rows path."""
+    from uvhand_amd.functions.linear_func import bracket_linear_masked
+    torch.manual_seed(1)
+    lin = torch.nn.Linear(256, 256).cuda()
+    x = torch.randn(2, 85, 256).cuda().requires_grad_(True)
+    mask = torch.zeros(2, 85, dtype=torch.bool)
+    mask[0, 80:] = True; mask[1, 3] = True
+    mask = mask.cuda()
+    go = torch.randn(2, 85, 256).cuda()
+    y = bracket_linear_masked(x, lin, mask)
+    y.backward(go)
+    got = (x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone())
+    x.grad = None; lin.zero_grad()
+    y_ref = lin(x).masked_fill(mask[..., None], 0.0)
+    y_ref.backward(go)
+    assert torch.equal(y, y_ref)
+    assert torch.allclose(got[0], x.grad, rtol=1e-5, atol=1e-5) and not got[0][mask].any()
+    assert rel_err(got[1].cpu().numpy(), lin.weight.grad.cpu().numpy()) < 2e-6
+    assert rel_err(got[2].cpu().numpy(), lin.bias.grad.cpu().numpy()) < 2e-6
+    with torch.no_grad():                                              # preconditions not met -> the reference composition
+        assert torch.equal(bracket_linear_masked(x, lin, mask), y_ref)

@@ -30,15 +30,17 @@ ref_requires_grad = True
 src = torch.randn(N, S, M * D, device=dev, requires_grad=True)
 ref = torch.rand(N, Lq, len(shapes), 2, device=dev, requires_grad=True)
 go = torch.randn(N, Lq, M * D, device=dev)
+# MODULE_MASK=1: a padding mask with ~5 % of the pixels flagged (MSDA_MASKED_ROWS=0 -> reference's masked_fill)
+mask = (torch.rand(N, S, device=dev) < 0.05) if os.environ.get("MODULE_MASK", "") == "1" else None
 def step():
     mod.zero_grad(set_to_none=True); q.grad = src.grad = ref.grad = None
     if amp == "bf16":
         mod.bf16_storage = True
         with torch.autocast("cuda", dtype=torch.bfloat16):
-            out = mod(q, ref, src, sh, lsi)
+            out = mod(q, ref, src, sh, lsi, mask)
         out.backward(go.to(out.dtype))
     else:
-        out = mod(q, ref, src, sh, lsi)
+        out = mod(q, ref, src, sh, lsi, mask)
         out.backward(go)
 
 use_graph = os.environ.get("MODULE_GRAPH", "") == "1"              # replay a HIP graph: GPU-bound time

@@ -23,7 +23,8 @@ _lib = None
 _SYMBOLS = (
     "msda_forward_f32", "msda_backward_f32", "msda_forward_f64", "msda_backward_f64",
     "msda_forward_bf16", "msda_backward_bf16",
-    "msda_linear_wgrad_f32", "msda_linear_wgrad_workspace_bytes",
+    "msda_linear_wgrad_f32", "msda_linear_wgrad_masked_f32", "msda_linear_wgrad_workspace_bytes",
+    "msda_zero_masked_rows_f32",
     "msda_prologue_supported", "msda_forward_prologue_f32", "msda_backward_prologue_f32",
     "msda_last_error", "msda_version", "msda_path_for", "msda_force_path",
 )
@@ -217,7 +218,8 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     return grad_value, grad_loc, grad_attn
 
 
-_WGRAD_ARGTYPES = [_VP, _VP, _CI, _CI, _CI, _VP, _VP, _VP, _VP]
+_LL = ctypes.c_longlong
+_WGRAD_ARGTYPES = [_VP, _VP, _VP, _CI, _CI, _CI, _VP, _VP, _VP, _VP]
 
 
 def linear_wgrad_supported(grad_out, inp):
@@ -228,8 +230,31 @@ def linear_wgrad_supported(grad_out, inp):
             and grad_out.shape[1] % 4 == 0 and inp.shape[1] % 4 == 0 and inp.shape[0] < (1 << 30))
 
 
-def linear_wgrad(grad_out, inp, want_bias=True):
-    """(grad_weight[N,K], grad_bias[N] or None) = (grad_out^T @ inp, grad_out.sum(0)) — include/msda.h."""
+def _row_mask_ptr(row_mask, rows, device):
+    if row_mask is None:
+        return None
+    if not (row_mask.dtype == torch.bool and row_mask.is_contiguous() and row_mask.numel() == rows
+            and row_mask.device == device):
+        raise RuntimeError("row_mask must be a contiguous bool tensor with one entry per row, on the same device")
+    return row_mask.data_ptr()
+
+
+def zero_masked_rows_(x, row_mask):
+    """In place: x[r, :] = 0 where row_mask[r] (x: contiguous fp32 [rows, cols], cols % 4 == 0) — include/msda.h."""
+    lib = _lib or load()
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous() and x.shape[1] % 4 == 0):
+        raise RuntimeError("zero_masked_rows_: expected a contiguous fp32 CUDA matrix with cols % 4 == 0")
+    with _DeviceGuard(x.device):
+        rc = _entry(lib, "msda_zero_masked_rows_f32", [_VP, _VP, _LL, _CI, _VP])(
+            x.data_ptr(), _row_mask_ptr(row_mask, x.shape[0], x.device), x.shape[0], x.shape[1], _raw_stream(x.device))
+    if rc != 0:
+        _raise(lib, rc, "zero_masked_rows_")
+    return x
+
+
+def linear_wgrad(grad_out, inp, want_bias=True, row_mask=None):
+    """(grad_weight[N,K], grad_bias[N] or None) = (grad_out^T @ inp, grad_out.sum(0)) — include/msda.h.
+    Rows of grad_out with row_mask[r] True count as zero."""
     lib = _lib or load()
     if not linear_wgrad_supported(grad_out, inp):
         raise RuntimeError("linear_wgrad: expected contiguous fp32 CUDA matrices [M,N] and [M,K] with N, K % 4 == 0")
@@ -240,8 +265,9 @@ def linear_wgrad(grad_out, inp, want_bias=True):
         gb = torch.empty((N,), dtype=torch.float32, device=inp.device) if want_bias else None
         nbytes = lib.msda_linear_wgrad_workspace_bytes(M, N, K)
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=inp.device) if nbytes else None
-        rc = _entry(lib, "msda_linear_wgrad_f32", _WGRAD_ARGTYPES)(
-            grad_out.data_ptr(), inp.data_ptr(), M, N, K, gw.data_ptr(), gb.data_ptr() if want_bias else None,
+        rc = _entry(lib, "msda_linear_wgrad_masked_f32", _WGRAD_ARGTYPES)(
+            grad_out.data_ptr(), inp.data_ptr(), _row_mask_ptr(row_mask, M, inp.device), M, N, K, gw.data_ptr(),
+            gb.data_ptr() if want_bias else None,
             ws.data_ptr() if ws is not None else None, _raw_stream(inp.device))
     if rc != 0:
         _raise(lib, rc, "linear_wgrad")

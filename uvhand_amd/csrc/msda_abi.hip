@@ -249,6 +249,12 @@ unsigned long long msda_linear_wgrad_workspace_bytes(int M, int N, int K)
 int msda_linear_wgrad_f32(const float *grad_out, const float *input, int M, int N, int K, float *grad_weight,
                           float *grad_bias, void *workspace, msda_stream_t stream)
 {
+    return msda_linear_wgrad_masked_f32(grad_out, input, nullptr, M, N, K, grad_weight, grad_bias, workspace, stream);
+}
+
+int msda_linear_wgrad_masked_f32(const float *grad_out, const float *input, const uint8_t *row_mask, int M, int N, int K,
+                                 float *grad_weight, float *grad_bias, void *workspace, msda_stream_t stream)
+{
     if (M < 0 || N <= 0 || K <= 0 || (N & 3) || (K & 3))
         return msda::set_error(MSDA_ERR_ARGUMENT, "msda_linear_wgrad_f32: need N, K > 0 and multiples of 4");
     if (grad_weight == nullptr || (M > 0 && (grad_out == nullptr || input == nullptr)))
@@ -259,13 +265,25 @@ int msda_linear_wgrad_f32(const float *grad_out, const float *input, int M, int 
         if (e == hipSuccess && grad_bias) e = hipMemsetAsync(grad_bias, 0, sizeof(float) * (size_t)N, (hipStream_t)stream);
         return e == hipSuccess ? MSDA_OK : msda::set_error(MSDA_ERR_LAUNCH, hipGetErrorString(e));
     }
-    return msda::launch_linear_wgrad(grad_out, input, M, N, K, grad_weight, grad_bias, static_cast<float *>(workspace),
-                                     (hipStream_t)stream);
+    return msda::launch_linear_wgrad(grad_out, input, row_mask, M, N, K, grad_weight, grad_bias,
+                                     static_cast<float *>(workspace), (hipStream_t)stream);
+}
+
+int msda_zero_masked_rows_f32(float *x, const uint8_t *row_mask, long long rows, int cols, msda_stream_t stream)
+{
+    if (rows < 0 || cols <= 0 || (cols & 3) || ((uintptr_t)x & 15))
+        return msda::set_error(MSDA_ERR_ARGUMENT, "msda_zero_masked_rows_f32: need rows >= 0, cols > 0 and a multiple of 4, "
+                                                  "16-byte aligned rows");
+    if (rows > 0 && (x == nullptr || row_mask == nullptr))
+        return msda::set_error(MSDA_ERR_ARGUMENT, "msda_zero_masked_rows_f32: null device pointer");
+    if (rows > 4LL * 0x7fffffffLL) return msda::set_error(MSDA_ERR_ARGUMENT, "msda_zero_masked_rows_f32: too many rows");
+    msda::g_err[0] = 0;
+    return msda::launch_zero_masked_rows(x, row_mask, rows, cols, (hipStream_t)stream);
 }
 
 const char *msda_last_error(void) { return msda::g_err; }
 
-int msda_version(void) { return 100; }
+int msda_version(void) { return 101; }
 
 int msda_path_for(int elem_bytes, int M, int D, int L, int P)
 {

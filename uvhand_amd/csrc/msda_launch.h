@@ -58,7 +58,9 @@ int launch_bwd_prologue(const float *grad_out, const float *value, const int64_t
 
 // ---- weight / bias gradient of the bracketing nn.Linear layers (msda_linear.hip) -----------------
 size_t linear_wgrad_workspace_bytes(int M, int N, int K);
-int launch_linear_wgrad(const float *dY, const float *X, int M, int N, int K, float *dW, float *db, float *workspace,
-                        hipStream_t stream);
+// row_mask (may be null): one byte per row of dY, non-zero = that row counts as zero
+int launch_linear_wgrad(const float *dY, const float *X, const uint8_t *row_mask, int M, int N, int K, float *dW, float *db,
+                        float *workspace, hipStream_t stream);
+int launch_zero_masked_rows(float *x, const uint8_t *mask, long long rows, int cols, hipStream_t stream);
 
 }  // namespace msda

@@ -20,6 +20,12 @@
 //            of 32x32; next stage's global loads are issued before the current stage's MFMAs.
 //            Column sums of dY (the bias gradient) ride along in the tiles with k0 == 0.
 //   stage 2  sums the SPLITS partial slabs in split order (skipped when SPLITS == 1).
+//
+// Padding mask (modules/ms_deform_attn.py:97-98: value.masked_fill(padding_mask[..., None], 0) after
+// value_proj): instead of two full passes over [N, S, 256] (the masked_fill and its backward), the forward
+// zeroes only the masked ROWS of the GEMM output in place (zero_masked_rows_kernel), and the backward passes
+// the row mask to stage 1, which stages zeros for masked rows of dY — the weight and bias gradients of the
+// masked product without materialising it; the input gradient's masked rows are zeroed the same way.
 #include "msda_common.h"
 #include "msda_launch.h"
 
@@ -31,8 +37,8 @@ constexpr int kWgBlock = 256;      // 4 wavefronts
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 __global__ __launch_bounds__(kWgBlock) void linear_wgrad_partial_kernel(
-    const float *__restrict__ dY, const float *__restrict__ X, int M, int N, int K, int chunk, long long slab,
-    float *__restrict__ out_w, float *__restrict__ out_b)
+    const float *__restrict__ dY, const float *__restrict__ X, const uint8_t *__restrict__ row_mask, int M, int N, int K,
+    int chunk, long long slab, float *__restrict__ out_w, float *__restrict__ out_b)
 {
     // `slab` = elements between consecutive splits' partial results (0 when there is one split and the
     // results go straight to dW / db)
@@ -50,11 +56,14 @@ __global__ __launch_bounds__(kWgBlock) void linear_wgrad_partial_kernel(
     const int lrow = tid >> 4, lcol = (tid & 15) * 4;                 // rows lrow, lrow + 16, ...
     const bool a_ok = n0 + lcol < N, b_ok = k0 + lcol < K;            // N, K are multiples of 4 (host check)
     float4 ra[kLd], rb[kLd];
+    uint8_t dead[kLd];                                                 // row is masked: stage zeros for it
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     auto load_stage = [&](int m0) {
 #pragma unroll
         for (int r = 0; r < kLd; ++r) {
             const int m = m0 + lrow + 16 * r;
+            // the mask byte travels with the row loads (no dependent load) and is applied at the LDS store
+            dead[r] = (row_mask && m < m_end) ? row_mask[m] : (uint8_t)0;
             ra[r] = (a_ok && m < m_end) ? *reinterpret_cast<const float4 *>(dY + (long long)m * N + n0 + lcol) : zero;
             rb[r] = (b_ok && m < m_end) ? *reinterpret_cast<const float4 *>(X + (long long)m * K + k0 + lcol) : zero;
         }
@@ -70,7 +79,7 @@ __global__ __launch_bounds__(kWgBlock) void linear_wgrad_partial_kernel(
         __syncthreads();                                                // previous stage's reads are done
 #pragma unroll
         for (int r = 0; r < kLd; ++r) {
-            *reinterpret_cast<float4 *>(&At[lrow + 16 * r][lcol]) = ra[r];
+            *reinterpret_cast<float4 *>(&At[lrow + 16 * r][lcol]) = dead[r] ? zero : ra[r];
             *reinterpret_cast<float4 *>(&Bs[lrow + 16 * r][lcol]) = rb[r];
         }
         __syncthreads();
@@ -110,6 +119,24 @@ __global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(const float *_
     *reinterpret_cast<float4 *>(e < nw ? dW + e : db + (e - nw)) = s;
 }
 
+// x[r, :] = 0 for every row with mask[r] != 0; one wavefront per row, float4 per lane.  Unmasked rows
+// cost one byte of mask.
+__global__ __launch_bounds__(256) void zero_masked_rows_kernel(float *__restrict__ x, const uint8_t *__restrict__ mask,
+                                                                long long rows, int cols)
+{
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows || mask[r] == 0) return;
+    float4 *row = reinterpret_cast<float4 *>(x + r * cols);
+    for (int c = threadIdx.x & 63; c < cols / 4; c += 64) row[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+int launch_zero_masked_rows(float *x, const uint8_t *mask, long long rows, int cols, hipStream_t stream)
+{
+    if (rows == 0) return MSDA_OK;
+    hipLaunchKernelGGL(zero_masked_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, mask, rows, cols);
+    return check_launch("msda zero masked rows");
+}
+
 static int wgrad_splits(int M, int N, int K)
 {
     const int tiles = ((N + kWgTile - 1) / kWgTile) * ((K + kWgTile - 1) / kWgTile);
@@ -125,8 +152,8 @@ size_t linear_wgrad_workspace_bytes(int M, int N, int K)
     return splits <= 1 ? 0 : sizeof(float) * (size_t)splits * ((size_t)N * K + (size_t)N);
 }
 
-int launch_linear_wgrad(const float *dY, const float *X, int M, int N, int K, float *dW, float *db, float *workspace,
-                        hipStream_t stream)
+int launch_linear_wgrad(const float *dY, const float *X, const uint8_t *row_mask, int M, int N, int K, float *dW, float *db,
+                        float *workspace, hipStream_t stream)
 {
     const int splits = wgrad_splits(M, N, K);
     int chunk = (M + splits - 1) / splits;
@@ -134,12 +161,14 @@ int launch_linear_wgrad(const float *dY, const float *X, int M, int N, int K, fl
     const int tiles = ((N + kWgTile - 1) / kWgTile) * ((K + kWgTile - 1) / kWgTile);
     const dim3 grid((unsigned)tiles, (unsigned)splits);
     if (splits == 1) {
-        hipLaunchKernelGGL(linear_wgrad_partial_kernel, grid, dim3(kWgBlock), 0, stream, dY, X, M, N, K, chunk, 0LL, dW, db);
+        hipLaunchKernelGGL(linear_wgrad_partial_kernel, grid, dim3(kWgBlock), 0, stream, dY, X, row_mask, M, N, K, chunk, 0LL, dW,
+                           db);
         return check_launch("msda linear wgrad");
     }
     if (workspace == nullptr) return set_error(MSDA_ERR_ARGUMENT, "msda linear wgrad: workspace required");
     const long long nw = (long long)N * K, slab = nw + N;               // per split: weight partials, then bias partials
-    hipLaunchKernelGGL(linear_wgrad_partial_kernel, grid, dim3(kWgBlock), 0, stream, dY, X, M, N, K, chunk, slab, workspace,
+    hipLaunchKernelGGL(linear_wgrad_partial_kernel, grid, dim3(kWgBlock), 0, stream, dY, X, row_mask, M, N, K, chunk, slab,
+                       workspace,
                        db ? workspace + nw : nullptr);
     if (int rc = check_launch("msda linear wgrad (partial)")) return rc;
     hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((unsigned)((slab / 4 + 255) / 256)), dim3(256), 0, stream, workspace,

@@ -51,7 +51,41 @@ class _BracketLinearFn(Function):
         return grad_x, grad_w, grad_b
 
 
+class _MaskedBracketLinearFn(Function):
+    """``F.linear(x, weight, bias).masked_fill(row_mask[..., None], 0)`` (value_proj + padding mask,
+    models/ops/modules/ms_deform_attn.py:96-98) touching only the masked rows: the forward zeroes them in the
+    GEMM output in place; the backward hands the mask to the weight-gradient kernel (masked rows of grad_out
+    count as zero) and zeroes the same rows of the input gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, row_mask):
+        y = F.linear(x, weight, bias)
+        mask = row_mask.reshape(-1).contiguous()
+        MSDA.zero_masked_rows_(y.view(-1, y.shape[-1]), mask)
+        ctx.save_for_backward(x, weight, mask)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        x, weight, mask = ctx.saved_tensors
+        need_x, need_w, need_b = ctx.needs_input_grad[:3]
+        go2 = grad_out.reshape(-1, grad_out.shape[-1]).contiguous()
+        grad_x = grad_w = grad_b = None
+        if need_x:
+            gx2 = go2 @ weight                                      # fresh buffer: safe to edit in place
+            grad_x = MSDA.zero_masked_rows_(gx2, mask).view_as(x)
+        if need_w or (need_b and ctx.has_bias):
+            x2 = x.reshape(-1, x.shape[-1]).contiguous()
+            grad_w, grad_b = MSDA.linear_wgrad(go2, x2, want_bias=ctx.has_bias and need_b, row_mask=mask)
+            if not need_w:
+                grad_w = None
+        return grad_x, grad_w, grad_b, None
+
+
 _ENABLED = os.environ.get("MSDA_BRACKET_LINEAR", "1") != "0"       # A/B knob: 0 = always the plain layer
+_MASKED_ROWS = os.environ.get("MSDA_MASKED_ROWS", "1") != "0"      # A/B knob: 0 = masked_fill after the layer
 
 
 def _kernel_applies(x, weight):
@@ -65,6 +99,15 @@ def bracket_linear_wb(x, weight, bias):
     if _kernel_applies(x, weight):
         return _BracketLinearFn.apply(x, weight, bias)
     return F.linear(x, weight, bias)
+
+
+def bracket_linear_masked(x, layer, row_mask):
+    """``layer(x).masked_fill(row_mask[..., None], 0)`` for an ``nn.Linear`` ``layer`` and a bool mask over the
+    leading dimensions of ``x``; the masked rows only are touched when the kernels apply."""
+    if (_MASKED_ROWS and _kernel_applies(x, layer.weight) and row_mask.dtype == torch.bool and row_mask.is_cuda
+            and row_mask.shape == x.shape[:-1]):
+        return _MaskedBracketLinearFn.apply(x, layer.weight, layer.bias, row_mask)
+    return bracket_linear(x, layer).masked_fill(row_mask[..., None], float(0))
 
 
 def bracket_linear(x, layer):

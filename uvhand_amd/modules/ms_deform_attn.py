@@ -28,7 +28,7 @@ from torch import nn
 from .. import _native
 from ..functions import (MSDeformAttnBF16Function, MSDeformAttnFunction, MSDeformAttnMergedPrologueFunction,
                          MSDeformAttnPrologueFunction)
-from ..functions.linear_func import bracket_linear, bracket_linear_wb
+from ..functions.linear_func import bracket_linear, bracket_linear_masked, bracket_linear_wb
 
 
 # (data_ptr, version, Len_in) of spatial_shapes tensors whose H*W sum was already verified: the
@@ -120,9 +120,10 @@ class MSDeformAttn(nn.Module):
 
         # the four projections are nn.Linear (same parameters, same forward GEMM as the reference);
         # bracket_linear only swaps the weight-gradient GEMM of their backward (functions/linear_func.py)
-        value = bracket_linear(input_flatten, self.value_proj)
         if input_padding_mask is not None:
-            value = value.masked_fill(input_padding_mask[..., None], float(0))
+            value = bracket_linear_masked(input_flatten, self.value_proj, input_padding_mask)
+        else:
+            value = bracket_linear(input_flatten, self.value_proj)
         value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
         ref_dim = reference_points.shape[-1]
 
