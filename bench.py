@@ -194,6 +194,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="cfg2_decoder", choices=sorted(WORKLOADS))
     ap.add_argument("--no-graph", action="store_true", help="time the eager autograd path")
+    ap.add_argument("--graph-steps", type=int, default=10,
+                    help="steps captured per HIP graph (the timed loop replays it steps/graph-steps times; "
+                         "reduced to a divisor of --steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-iters", type=int, default=200)
     ap.add_argument("--locations", default="uniform", choices=["uniform", "model"],
@@ -243,24 +246,29 @@ def main():
         for _ in range(3):
             step()
         stream.synchronize()
+        per_graph = 1
         if not args.no_graph:
+            per_graph = max(1, min(args.graph_steps, args.steps))
+            while args.steps % per_graph:                 # exactly --steps steps are timed
+                per_graph -= 1
             try:
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, stream=stream):
-                    step()
+                    for _ in range(per_graph):            # stream order chains them: no two steps overlap
+                        step()
             except Exception as exc:                      # report, then fall back to eager timing
                 print("bench: HIP graph capture failed (%s); timing eager" % exc, file=sys.stderr)
-                graph = None
+                graph, per_graph = None, 1
         run = graph.replay if graph is not None else step
 
         def barrier():
             harness.barrier(device)
 
-        for _ in range(args.warmup):
+        for _ in range((args.warmup + per_graph - 1) // per_graph):
             run()
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(args.steps // per_graph):
             run()
         barrier()
         elapsed = time.perf_counter() - t0
@@ -307,7 +315,8 @@ def main():
                                       S, Lq, M, D, P, "fp32" if not bf16 else "bf16 storage / fp32 accumulate"),
                        "locations": args.locations,
                        "step": "MSDeformAttnFunction.apply forward + backward (3 grads)",
-                       "launch": "hipGraph replay" if graph is not None else "eager autograd",
+                       "launch": ("hipGraph replay, %d step(s) per graph" % per_graph) if graph is not None
+                                 else "eager autograd",
                        "sharding": "batch-sharded, no collective"},
             "roofline": {"bound": "hbm", "kernel": "backward: msda::bwd_fused_d32_kernel (grad_value sort+gather "
                                                     "workgroups and grad_loc/grad_attn workgroups in one launch)",
