@@ -12,7 +12,7 @@ def main():
     dev = torch.device("cuda", 0)
     st = torch.cuda.Stream(dev)
     for name in names:
-        _, d, dims = make_inputs(name, 1000, dev)
+        _, d, dims = make_inputs(name, 1000, dev, os.environ.get("KTIME_LOCATIONS", "uniform"))
         fb, bb = algorithmic_bytes(*dims)
         fns = {"fwd": lambda: _native.ms_deform_attn_forward(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], 64),
                "bwd": lambda: _native.ms_deform_attn_backward(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], d["go"], 64)}

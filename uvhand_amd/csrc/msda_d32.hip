@@ -140,6 +140,14 @@ __device__ __forceinline__ float octlane_sum(float x)
     return x;
 }
 
+// Workgroup ids are dealt round-robin to the 8 XCDs (id % 8), each with its own L2.  xcd_block() renumbers
+// them so that every XCD works on ONE contiguous range of the logical blocks (bijection for any count).
+__device__ __forceinline__ int xcd_block(int bid, int nb)
+{
+    const int x = bid & 7, idx = bid >> 3, q = nb >> 3, r = nb & 7;
+    return x * q + (x < r ? x : r) + idx;
+}
+
 // n / d for a divisor that is usually a power of two (shift >= 0), exact otherwise.
 __device__ __forceinline__ int fdiv(int n, int d, int shift) { return shift >= 0 ? (n >> shift) : n / d; }
 
@@ -182,7 +190,8 @@ __global__ __launch_bounds__(kBlock) void fwd_d32_kernel(
     const VT *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ level_start, const float *__restrict__ loc,
     const float *__restrict__ attn, int S, int M, int L, int Lq, int P, int items, int p_shift,
-    int lp_shift, int m_shift, VT *__restrict__ out, const PrologueIn pro = PrologueIn{nullptr, nullptr, nullptr, 0, 0})
+    int lp_shift, int m_shift, VT *__restrict__ out, const PrologueIn pro = PrologueIn{nullptr, nullptr, nullptr, 0, 0},
+    int xcd = 0)
 {
     constexpr int IPW = 32 / SPLIT;                       // items per workgroup
     constexpr int OPW = 4 / SPLIT;                        // octets per workgroup
@@ -191,7 +200,7 @@ __global__ __launch_bounds__(kBlock) void fwd_d32_kernel(
     const int LP = L * P;
     const int item_stride = LP * kRecBytes + kItemPad;
     const int tid = threadIdx.x;
-    const int item0 = blockIdx.x * IPW;
+    const int item0 = (xcd ? xcd_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x) * IPW;
     MSDA_STAMP_AT(2, 0);
     const int LqM = Lq * M;
     const int b0 = item0 / LqM, r0 = item0 - b0 * LqM, m0 = item0 % M;      // uniform (scalar unit)
@@ -441,12 +450,12 @@ __global__ __launch_bounds__(kBlock) void bwd_query_d32_kernel(
     const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
     const float *__restrict__ loc, const float *__restrict__ attn, int S, int M, int L, int Lq,
     int P, int items, int p_shift, int lp_shift, int m_shift, VT *__restrict__ grad_value,
-    float *__restrict__ grad_loc, float *__restrict__ grad_attn)
+    float *__restrict__ grad_loc, float *__restrict__ grad_attn, int xcd)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bwd_query_body<SPLIT, ATOMIC, kBlock, VT>(grad_out, value, shapes, level_start, loc, attn, S, M, L, Lq, P, items,
                                           p_shift, lp_shift, m_shift, grad_value, grad_loc, grad_attn,
-                                          (int)blockIdx.x, smem);
+                                          xcd ? xcd_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x, smem);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -693,13 +702,14 @@ template <int ACC, int PPT, typename VT>
 __global__ __launch_bounds__(kSBlock) void bwd_value_d32_kernel(
     const VT *__restrict__ grad_out, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ level_start, const float *__restrict__ loc,
-    const float *__restrict__ attn, int S, int M, int L, int Lq, int P, int p_shift, int tp_cap,
-    VT *__restrict__ grad_value)
+    const float *__restrict__ attn, int S, int M, int L, int Lq, int P, int p_shift, int tp_cap, int W,
+    VT *__restrict__ grad_value, int xcd)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // grid = (W ranges, L levels, N*M pairs)
+    // grid = W ranges x L levels x N*M pairs, range fastest
+    const int bid = xcd ? xcd_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
     bwd_value_body<ACC, PPT, VT>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, tp_cap,
-                                   grad_value, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y, (int)blockIdx.z, smem);
+                                   grad_value, bid % W, W, (bid / W) % L, bid / (W * L), smem);
 }
 
 // One launch for the whole backward of a single-pass problem: the first nB workgroups are role B
@@ -713,18 +723,19 @@ __global__ __launch_bounds__(kSBlock) void bwd_fused_d32_kernel(
     const float *__restrict__ loc, const float *__restrict__ attn, int S, int M, int L, int Lq,
     int P, int items, int p_shift, int lp_shift, int m_shift, int tp_cap, int W, int nB,
     VT *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attn,
-    const PrologueOut pro = PrologueOut{nullptr, 0, 0})
+    const PrologueOut pro = PrologueOut{nullptr, 0, 0}, int xcd = 0)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int bid = (int)blockIdx.x;
+    int bid = (int)blockIdx.x;
     if (bid < nB) {
+        if (xcd) bid = xcd_block(bid, nB);
         const int ti = bid % W, l = (bid / W) % L, pr = bid / (W * L);
         bwd_value_body<ACC, kSinglePPT, VT>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, tp_cap,
                                           grad_value, ti, W, l, pr, smem);
     } else {
         bwd_query_body<SPLIT, false, kSBlock, VT, FUSED>(grad_out, value, shapes, level_start, loc, attn, S, M, L, Lq, P,
                                                      items, p_shift, lp_shift, m_shift, grad_value, grad_loc, grad_attn,
-                                                     bid - nB, smem, pro);
+                                                     xcd ? xcd_block(bid - nB, (int)gridDim.x - nB) : bid - nB, smem, pro);
     }
 }
 
@@ -737,7 +748,7 @@ bool d32_supported(int N, int S, int M, int D, int L, int Lq, int P)
     const long long items = (long long)N * Lq * M;
     if ((long long)N * S * M * kD >= (1LL << 31)) return false;        // int32 element offsets
     if (items * L * P * 2 >= (1LL << 31) || items >= (1LL << 30)) return false;
-    if ((long long)N * M > 65535 || S > (1 << 19)) return false;       // role-B grid (W, L, N*M), 32-bit S*W
+    if ((long long)N * M > 65535 || S > (1 << 19)) return false;       // role-B workgroup count and S*W stay 32-bit
     return true;
 }
 
@@ -750,6 +761,13 @@ static int env_int(const char *name, int dflt)
 static int bwd_target_wgs()
 {
     static const int v = [] { int t = env_int("MSDA_BWD_WGS", 256); return t < 1 ? 1 : t; }();
+    return v;
+}
+
+// XCD-aware workgroup numbering (xcd_block); MSDA_XCD=0 keeps the hardware's round-robin order (A/B knob)
+static int xcd_remap()
+{
+    static const int v = env_int("MSDA_XCD", 1) != 0;
     return v;
 }
 
@@ -781,7 +799,9 @@ static int launch_fwd_d32_t(const VT *value, const int64_t *shapes, const int64_
     const dim3 grid((items + ipw - 1) / ipw), block(kBlock);
 #define MSDA_LAUNCH_FWD(SP)                                                                            \
     hipLaunchKernelGGL((fwd_d32_kernel<SP, VT>), grid, block, lds, stream, value, shapes, level_start, loc, attn, \
-                       S, M, L, Lq, P, items, pow2_shift(P), pow2_shift(LP), pow2_shift(M), out)
+                       S, M, L, Lq, P, items, pow2_shift(P), pow2_shift(LP), pow2_shift(M), out,                  \
+                       PrologueIn{nullptr, nullptr, nullptr, 0, 0}, xcd)
+    const int xcd = xcd_remap();
     if (split == 4) MSDA_LAUNCH_FWD(4); else if (split == 2) MSDA_LAUNCH_FWD(2); else MSDA_LAUNCH_FWD(1);
 #undef MSDA_LAUNCH_FWD
     return check_launch("msda forward (d32)");
@@ -846,6 +866,7 @@ static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *
     const int target_wgs = bwd_target_wgs();
     const int split = pick_split(items, LP);
     const int ps = pow2_shift(P), lps = pow2_shift(LP), ms = pow2_shift(M);
+    const int xcd = xcd_remap();
 
     if (bwd_mode == 2) {
         hipError_t e = hipMemsetAsync(grad_value, 0, sizeof(VT) * (size_t)N * S * M * kD, stream);
@@ -863,18 +884,19 @@ static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *
 #define MSDA_LAUNCH_F(SP, AC)                                                                          \
             hipLaunchKernelGGL((bwd_fused_d32_kernel<SP, AC, VT>), fgrid, dim3(kSBlock), flds, stream, grad_out,  \
                                value, shapes, level_start, loc, attn, S, M, L, Lq, P, items, ps, lps, ms,        \
-                               pl.tp_cap, pl.W, (int)nB, grad_value, grad_loc, grad_attn)
+                               pl.tp_cap, pl.W, (int)nB, grad_value, grad_loc, grad_attn, PrologueOut{nullptr, 0, 0}, xcd)
             if (pl.acc == kAccNone) { if (split == 4) MSDA_LAUNCH_F(4, kAccNone); else if (split == 2) MSDA_LAUNCH_F(2, kAccNone); else MSDA_LAUNCH_F(1, kAccNone); }
             else                    { if (split == 4) MSDA_LAUNCH_F(4, kAccRmw); else if (split == 2) MSDA_LAUNCH_F(2, kAccRmw); else MSDA_LAUNCH_F(1, kAccRmw); }
 #undef MSDA_LAUNCH_F
             return check_launch("msda backward (d32, fused)");
         }
         // ---- role B as its own launch (large record arrays / bf16 tile / A-B knob) ----
-        const dim3 grid((unsigned)pl.W, (unsigned)L, (unsigned)(N * M));
+        if (nB > 0x7fffffffLL) return set_error(MSDA_ERR_ARGUMENT, "msda backward (d32): too many grad_value workgroups");
+        const dim3 grid((unsigned)nB);
 #define MSDA_LAUNCH_B(AC, PPT_)                                                                        \
         do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_value_d32_kernel<AC, PPT_, VT>), pl.lds)) return rc; \
              hipLaunchKernelGGL((bwd_value_d32_kernel<AC, PPT_, VT>), grid, dim3(kSBlock), pl.lds, stream, grad_out,    \
-                                shapes, level_start, loc, attn, S, M, L, Lq, P, ps, pl.tp_cap, grad_value); } while (0)
+                                shapes, level_start, loc, attn, S, M, L, Lq, P, ps, pl.tp_cap, pl.W, grad_value, xcd); } while (0)
         if (pl.acc == kAccNone) MSDA_LAUNCH_B(kAccNone, kSinglePPT);
         else if (pl.acc == kAccTile) MSDA_LAUNCH_B(kAccTile, kMultiPPT);
         else if (pl.ppt == kMultiPPT) MSDA_LAUNCH_B(kAccRmw, kMultiPPT);
@@ -888,7 +910,7 @@ static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *
         const dim3 grid((items + ipw - 1) / ipw), block(kBlock);
 #define MSDA_LAUNCH_A(SP, AT)                                                                          \
         hipLaunchKernelGGL((bwd_query_d32_kernel<SP, AT, VT>), grid, block, lds, stream, grad_out, value, shapes, \
-                           level_start, loc, attn, S, M, L, Lq, P, items, ps, lps, ms, grad_value, grad_loc, grad_attn)
+                           level_start, loc, attn, S, M, L, Lq, P, items, ps, lps, ms, grad_value, grad_loc, grad_attn, xcd)
         if (bwd_mode == 2) { if (split == 4) MSDA_LAUNCH_A(4, true); else if (split == 2) MSDA_LAUNCH_A(2, true); else MSDA_LAUNCH_A(1, true); }
         else               { if (split == 4) MSDA_LAUNCH_A(4, false); else if (split == 2) MSDA_LAUNCH_A(2, false); else MSDA_LAUNCH_A(1, false); }
 #undef MSDA_LAUNCH_A
@@ -920,9 +942,10 @@ int launch_fwd_prologue(const float *value, const int64_t *shapes, const int64_t
     const size_t lds = (size_t)ipw * item_stride + (split > 1 ? 4096 : 0);
     const dim3 grid((items + ipw - 1) / ipw), block(kBlock);
     const PrologueIn pro{ref, loc_out, attn_out, (int)((ld_offsets - 2LL * M * LP) / 2), (int)(ld_logits - (long long)M * LP)};
+    const int xcd = xcd_remap();
 #define MSDA_LAUNCH_FP(SP)                                                                             \
     hipLaunchKernelGGL((fwd_d32_kernel<SP, float, true>), grid, block, lds, stream, value, shapes, level_start, offsets, \
-                       logits, S, M, L, Lq, P, items, pow2_shift(P), pow2_shift(LP), pow2_shift(M), out, pro)
+                       logits, S, M, L, Lq, P, items, pow2_shift(P), pow2_shift(LP), pow2_shift(M), out, pro, xcd)
     if (split == 4) MSDA_LAUNCH_FP(4); else if (split == 2) MSDA_LAUNCH_FP(2); else MSDA_LAUNCH_FP(1);
 #undef MSDA_LAUNCH_FP
     return check_launch("msda forward (d32, fused prologue)");
@@ -950,7 +973,7 @@ int launch_bwd_prologue(const float *grad_out, const float *value, const int64_t
 #define MSDA_LAUNCH_BP(SP, AC)                                                                         \
     hipLaunchKernelGGL((bwd_fused_d32_kernel<SP, AC, float, true>), fgrid, dim3(kSBlock), flds, stream, grad_out, value,  \
                        shapes, level_start, loc, attn, S, M, L, Lq, P, items, ps, lps, ms, pl.tp_cap, pl.W, (int)nB,    \
-                       grad_value, grad_offsets, grad_logits, pro)
+                       grad_value, grad_offsets, grad_logits, pro, xcd_remap())
     if (pl.acc == kAccNone) { if (split == 4) MSDA_LAUNCH_BP(4, kAccNone); else if (split == 2) MSDA_LAUNCH_BP(2, kAccNone); else MSDA_LAUNCH_BP(1, kAccNone); }
     else                    { if (split == 4) MSDA_LAUNCH_BP(4, kAccRmw); else if (split == 2) MSDA_LAUNCH_BP(2, kAccRmw); else MSDA_LAUNCH_BP(1, kAccRmw); }
 #undef MSDA_LAUNCH_BP
