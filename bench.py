@@ -278,7 +278,10 @@ def main():
         if bf16:
             ld, ad = ld.float(), ad.float()
         fwd = lambda: _native.ms_deform_attn_forward(vd, shapes, lsi, ld, ad, 64)
-        bwd = lambda: _native.ms_deform_attn_backward(vd, shapes, lsi, ld, ad, go, 64)
+        # bf16 rows: the kernel variant MSDeformAttnBF16Function picks for a bf16 `value` (fp32 grad_value
+        # when the backward takes several passes)
+        gv32 = bf16 and _native.backward_passes(Lq, P) > 1
+        bwd = lambda: _native.ms_deform_attn_backward(vd, shapes, lsi, ld, ad, go, 64, fp32_grad_value=gv32)
         kt = {}
         for name, fn in (("fwd", fwd), ("bwd", bwd)):
             g2 = None

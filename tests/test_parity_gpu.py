@@ -378,6 +378,30 @@ def test_bf16_storage_matches_oracle_on_rounded_inputs(native, oracle, name):
     assert rel_err(l.grad.cpu().numpy()[keep], r_gl[keep]) < 2e-5
 
 
+@pytest.mark.parametrize("name", ["model_small", "many_queries", "cfg2_decoder"])
+def test_bf16_rows_with_fp32_grad_value(native, oracle, name):
+    """msda_backward_bf16_gv32: bf16 value / grad_out, float32 grad_value — no rounding of the result, so on
+    bf16-representable inputs all three gradients sit within fp32 summation-order distance of the oracle
+    (2e-5 of max), single-pass and multi-pass ("many_queries") alike."""
+    case = ORACLE_CASES[name] if name in ORACLE_CASES else FULL[name]
+    z = make_case(6, *case)
+    z["value"] = _bf16_round(z["value"])
+    z["grad_out"] = _bf16_round(z["grad_out"])
+    gv, gl, ga = native.ms_deform_attn_backward(
+        dev(z["value"]).to(torch.bfloat16), dev(z["shapes"]), dev(z["level_start"]), dev(z["loc"]), dev(z["attn"]),
+        dev(z["grad_out"]).to(torch.bfloat16), 64, fp32_grad_value=True)
+    assert gv.dtype == torch.float32
+    args = [z["value"], z["shapes"], z["level_start"], z["loc"], z["attn"]]
+    r_gv, r_gl, r_ga = oracle.backward(z["grad_out"], *args)
+    assert rel_err(gv.cpu().numpy(), r_gv) < 2e-5
+    assert rel_err(ga.cpu().numpy(), r_ga) < 2e-5
+    keep = ~near_boundary_mask(z, tol=1e-5)
+    assert rel_err(gl.cpu().numpy()[keep], r_gl[keep]) < 2e-5
+    with pytest.raises(RuntimeError, match="bfloat16 rows only"):
+        native.ms_deform_attn_backward(dev(z["value"]), dev(z["shapes"]), dev(z["level_start"]), dev(z["loc"]),
+                                       dev(z["attn"]), dev(z["grad_out"]), 64, fp32_grad_value=True)
+
+
 def test_bf16_storage_vs_fp32_path_and_errors(native):
     from uvhand_amd.functions import MSDeformAttnBF16Function, MSDeformAttnFunction
     z = make_case(5, *ORACLE_CASES["model_small"])
@@ -387,6 +411,13 @@ def test_bf16_storage_vs_fp32_path_and_errors(native):
     o16 = MSDeformAttnBF16Function.apply(v, s, i, l, a, 64)         # fp32 value is rounded on entry
     # bf16 rounding of value (2^-9) and of the result: rtol 2e-2, atol 1e-3*max|out|
     assert torch.allclose(o16.float(), o32, rtol=2e-2, atol=1e-3 * o32.abs().max().item())
+    # an fp32 `value` gets its gradient in fp32 straight from the kernel (no bf16 round trip)
+    v32 = v.clone().requires_grad_(True)
+    MSDeformAttnBF16Function.apply(v32, s, i, l, a, 64).float().sum().backward()
+    vref = v.clone().requires_grad_(True)
+    MSDeformAttnFunction.apply(vref, s, i, l, a, 64).sum().backward()
+    assert v32.grad.dtype == torch.float32
+    assert rel_err(v32.grad.cpu().numpy(), vref.grad.cpu().numpy()) < 1e-5      # same weights, grad_out = 1 exactly
     # D != 32 has no bf16 kernel: loud error, no silent fallback
     zz = make_case(5, *ORACLE_CASES["d64"])
     with pytest.raises(RuntimeError, match="bf16"):

@@ -22,7 +22,7 @@ _lib = None
 
 _SYMBOLS = (
     "msda_forward_f32", "msda_backward_f32", "msda_forward_f64", "msda_backward_f64",
-    "msda_forward_bf16", "msda_backward_bf16",
+    "msda_forward_bf16", "msda_backward_bf16", "msda_backward_bf16_gv32", "msda_backward_passes",
     "msda_linear_wgrad_f32", "msda_linear_wgrad_masked_f32", "msda_linear_wgrad_workspace_bytes",
     "msda_zero_masked_rows_f32",
     "msda_prologue_supported", "msda_forward_prologue_f32", "msda_backward_prologue_f32",
@@ -192,10 +192,16 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     return out
 
 
+def backward_passes(Lq, P):
+    """Query chunks the D = 32 backward takes for Lq*P sampling points per (batch, head, level); 1 = single pass."""
+    return int((_lib or load()).msda_backward_passes(ctypes.c_int(Lq), ctypes.c_int(P)))
+
+
 def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output,
-                            im2col_step):
+                            im2col_step, fp32_grad_value=False):
     """Replaces MSDA.ms_deform_attn_backward (vision.cpp:15).
-    Returns (grad_value, grad_sampling_loc, grad_attn_weight)."""
+    Returns (grad_value, grad_sampling_loc, grad_attn_weight).  fp32_grad_value (bf16 rows only): grad_value
+    comes back in float32 (msda_backward_bf16_gv32, include/msda.h)."""
     lib = _lib or load()
     _check_inputs((("value", value), ("spatial_shapes", spatial_shapes),
                    ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
@@ -205,11 +211,13 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     if grad_output.dtype != value.dtype or grad_output.numel() != N * Lq * M * D:
         raise RuntimeError("ms_deform_attn_backward: grad_output must be %s[%d,%d,%d]"
                            % (value.dtype, N, Lq, M * D))
+    if fp32_grad_value and suf != "bf16":
+        raise RuntimeError("fp32_grad_value applies to bfloat16 rows only")
     with _DeviceGuard(value.device):
-        grad_value = torch.empty_like(value)
+        grad_value = torch.empty_like(value, dtype=torch.float32) if fp32_grad_value else torch.empty_like(value)
         grad_loc = torch.empty_like(sampling_loc)
         grad_attn = torch.empty_like(attn_weight)
-        rc = _entry(lib, "msda_backward_" + suf, _BWD_ARGTYPES)(
+        rc = _entry(lib, "msda_backward_" + suf + ("_gv32" if fp32_grad_value else ""), _BWD_ARGTYPES)(
             grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
             sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P,
             grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(), _raw_stream(value.device))

@@ -111,6 +111,38 @@ static int backward_impl(const T *grad_out, const T *value, const int64_t *shape
 
 }  // namespace msda
 
+template <typename GT>
+static int backward_bf16_impl(const uint16_t *grad_out, const uint16_t *value, const int64_t *spatial_shapes,
+                              const int64_t *level_start, const float *sampling_loc, const float *attn_weight, int N,
+                              int S, int M, int D, int L, int Lq, int P, GT *grad_value, float *grad_sampling_loc,
+                              float *grad_attn_weight, msda_stream_t stream)
+{
+    const void *ptrs[] = {grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, grad_value,
+                          grad_sampling_loc, grad_attn_weight};
+    if (int rc = msda::check_args(ptrs, 9, N, S, M, D, L, Lq, P)) return rc;
+    msda::g_err[0] = 0;
+    if (N == 0) return MSDA_OK;
+    if (Lq == 0 || S == 0) {
+        hipError_t e = hipSuccess;
+        if (S > 0) e = hipMemsetAsync(grad_value, 0, sizeof(GT) * (size_t)N * S * M * D, (hipStream_t)stream);
+        if (e == hipSuccess && Lq > 0) {
+            e = hipMemsetAsync(grad_sampling_loc, 0, 4 * (size_t)N * Lq * M * L * P * 2, (hipStream_t)stream);
+            if (e == hipSuccess) e = hipMemsetAsync(grad_attn_weight, 0, 4 * (size_t)N * Lq * M * L * P, (hipStream_t)stream);
+        }
+        return e == hipSuccess ? MSDA_OK : msda::set_error(MSDA_ERR_LAUNCH, hipGetErrorString(e));
+    }
+    if (!msda::d32_supported(N, S, M, D, L, Lq, P))
+        return msda::set_error(MSDA_ERR_ARGUMENT, "msda bf16: only the D=32 kernel family implements bf16 storage "
+                                                  "(needs D == 32, L <= 16, L*P <= 32)");
+    if constexpr (sizeof(GT) == 2)
+        return msda::launch_bwd_d32_bf16(grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M,
+                                         L, Lq, P, grad_value, grad_sampling_loc, grad_attn_weight, (hipStream_t)stream);
+    else
+        return msda::launch_bwd_d32_bf16_gv32(grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S,
+                                              M, L, Lq, P, grad_value, grad_sampling_loc, grad_attn_weight,
+                                              (hipStream_t)stream);
+}
+
 extern "C" {
 
 int msda_forward_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
@@ -176,26 +208,22 @@ int msda_backward_bf16(const uint16_t *grad_out, const uint16_t *value, const in
                        int S, int M, int D, int L, int Lq, int P, uint16_t *grad_value, float *grad_sampling_loc,
                        float *grad_attn_weight, msda_stream_t stream)
 {
-    const void *ptrs[] = {grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, grad_value,
-                          grad_sampling_loc, grad_attn_weight};
-    if (int rc = msda::check_args(ptrs, 9, N, S, M, D, L, Lq, P)) return rc;
-    msda::g_err[0] = 0;
-    if (N == 0) return MSDA_OK;
-    if (Lq == 0 || S == 0) {
-        hipError_t e = hipSuccess;
-        if (S > 0) e = hipMemsetAsync(grad_value, 0, 2 * (size_t)N * S * M * D, (hipStream_t)stream);
-        if (e == hipSuccess && Lq > 0) {
-            e = hipMemsetAsync(grad_sampling_loc, 0, 4 * (size_t)N * Lq * M * L * P * 2, (hipStream_t)stream);
-            if (e == hipSuccess) e = hipMemsetAsync(grad_attn_weight, 0, 4 * (size_t)N * Lq * M * L * P, (hipStream_t)stream);
-        }
-        return e == hipSuccess ? MSDA_OK : msda::set_error(MSDA_ERR_LAUNCH, hipGetErrorString(e));
-    }
-    if (!msda::d32_supported(N, S, M, D, L, Lq, P))
-        return msda::set_error(MSDA_ERR_ARGUMENT, "msda bf16: only the D=32 kernel family implements bf16 storage "
-                                                  "(needs D == 32, L <= 16, L*P <= 32)");
-    return msda::launch_bwd_d32_bf16(grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M,
-                                     L, Lq, P, grad_value, grad_sampling_loc, grad_attn_weight, (hipStream_t)stream);
+    return backward_bf16_impl<uint16_t>(grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M, D,
+                                        L, Lq, P, grad_value, grad_sampling_loc, grad_attn_weight, stream);
 }
+
+int msda_backward_bf16_gv32(const uint16_t *grad_out, const uint16_t *value, const int64_t *spatial_shapes,
+                            const int64_t *level_start, const float *sampling_loc, const float *attn_weight, int N,
+                            int S, int M, int D, int L, int Lq, int P, float *grad_value, float *grad_sampling_loc,
+                            float *grad_attn_weight, msda_stream_t stream)
+{
+    return backward_bf16_impl<float>(grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M, D, L,
+                                     Lq, P, grad_value, grad_sampling_loc, grad_attn_weight, stream);
+}
+
+int msda_backward_passes(int Lq, int P) { return (Lq > 0 && P > 0) ? msda::backward_passes(Lq, P) : 0; }
+
+
 
 int msda_prologue_supported(int N, int S, int M, int D, int L, int Lq, int P)
 {

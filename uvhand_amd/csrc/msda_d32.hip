@@ -517,8 +517,8 @@ __device__ __forceinline__ void add4(float4 &a, const float4 &b) { a.x += b.x; a
 // CH*SLOTS records of two rows.  (A balanced "linear" variant — the sorted records cut evenly over
 // the lane groups, partial row runs combined in a fix-up phase — was measured and is not faster:
 // its per-record run bookkeeping costs what the load imbalance costs here; profiles/r01_notes.md.)
-template <int SLOTS, int ACC, typename VT>
-__device__ __forceinline__ void gather_rows(const VT *__restrict__ go_base, VT *__restrict__ gv_base,
+template <int SLOTS, int ACC, typename VT, typename GT>
+__device__ __forceinline__ void gather_rows(const VT *__restrict__ go_base, GT *__restrict__ gv_base,
                                             const int *cnt, const int *start, const SRec *rec, float *tile,
                                             int npx, int row_stride, bool first_pass)
 {
@@ -565,13 +565,13 @@ __device__ __forceinline__ void gather_rows(const VT *__restrict__ go_base, VT *
                     if (first_pass) *tB = accB; else { float4 o = *tB; add4(o, accB); *tB = o; }
                 }
             } else {
-                VT *pA = gv_base + (long long)dA * row_stride, *pB = gv_base + (long long)dB * row_stride;
+                GT *pA = gv_base + (long long)dA * row_stride, *pB = gv_base + (long long)dB * row_stride;
                 if (ACC == kAccRmw && !first_pass) {
-                    add4(accA, Row<VT>::load(pA));
-                    if (hasB) add4(accB, Row<VT>::load(pB));
+                    add4(accA, Row<GT>::load(pA));
+                    if (hasB) add4(accB, Row<GT>::load(pB));
                 }
-                Row<VT>::store(pA, accA);
-                if (hasB) Row<VT>::store(pB, accB);
+                Row<GT>::store(pA, accA);
+                if (hasB) Row<GT>::store(pB, accB);
             }
         }
     }
@@ -580,12 +580,14 @@ __device__ __forceinline__ void gather_rows(const VT *__restrict__ go_base, VT *
 // PPT = sampling points per thread per pass: all of a thread's points are loaded up front (2*PPT
 // independent global loads in flight), their taps and histogram ranks stay in registers between
 // step 1 and step 3, so loc / attn are read exactly once and step 3 needs no atomics.
-template <int ACC, int PPT, typename VT>
+// VT = storage type of grad_out, GT = storage type of grad_value (the same, or float for bf16 rows with an
+// fp32 grad_value: no rounding between passes, kAccRmw instead of the LDS tile).
+template <int ACC, int PPT, typename VT, typename GT = VT>
 __device__ __forceinline__ void bwd_value_body(
     const VT *__restrict__ grad_out, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ level_start, const float *__restrict__ loc,
     const float *__restrict__ attn, int S, int M, int L, int Lq, int P, int p_shift, int tp_cap,
-    VT *__restrict__ grad_value, int ti, int W, int l, int pr, unsigned char *smem)
+    GT *__restrict__ grad_value, int ti, int W, int l, int pr, unsigned char *smem)
 {
     constexpr int NPC = PPT * kSBlock;                       // points per pass
     // LDS: [tile: tp_cap*32 floats if kAccTile] [cnt tp_cap] [start tp_cap] [wsum 16] [rec]
@@ -609,7 +611,7 @@ __device__ __forceinline__ void bwd_value_body(
     const long long item_base = (long long)b * Lq * M + m;                   // item(q) = item_base + q*M
     const int row_stride = M * kD;
     const VT *go_base = grad_out + item_base * kD + (lane & 7) * 4;
-    VT *gv_base = grad_value + ((long long)(b * S + lstart + px0) * M + m) * kD + (lane & 7) * 4;
+    GT *gv_base = grad_value + ((long long)(b * S + lstart + px0) * M + m) * kD + (lane & 7) * 4;
 
     for (int c0 = 0; c0 < NP; c0 += NPC) {
         // ---- loads of this pass's points first: they overlap the histogram reset ----
@@ -680,10 +682,10 @@ __device__ __forceinline__ void bwd_value_body(
         // ---- 4. gather; lanes per row chosen from the mean segment length (uniform) ----
         const int mean2 = (2 * total) / npx;                                  // 2 x mean records per row
         const bool first = (c0 == 0);
-        if (mean2 <= 8)       gather_rows<1, ACC, VT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
-        else if (mean2 <= 16) gather_rows<2, ACC, VT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
-        else if (mean2 <= 32) gather_rows<4, ACC, VT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
-        else                  gather_rows<8, ACC, VT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
+        if (mean2 <= 8)       gather_rows<1, ACC, VT, GT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
+        else if (mean2 <= 16) gather_rows<2, ACC, VT, GT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
+        else if (mean2 <= 32) gather_rows<4, ACC, VT, GT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
+        else                  gather_rows<8, ACC, VT, GT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
         if (ACC != kAccNone) __syncthreads();                // next pass reuses the LDS arrays / re-reads rows
         MSDA_STAMP(5);
     }
@@ -693,36 +695,36 @@ __device__ __forceinline__ void bwd_value_body(
         for (int i = tid; i < npx * 8; i += kSBlock) {
             const int d = i >> 3, jj = i & 7;
             const float4 v = NP > 0 ? reinterpret_cast<const float4 *>(tile)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-            Row<VT>::store(grad_value + ((long long)(b * S + lstart + px0 + d) * M + m) * kD + jj * 4, v);
+            Row<GT>::store(grad_value + ((long long)(b * S + lstart + px0 + d) * M + m) * kD + jj * 4, v);
         }
     }
 }
 
-template <int ACC, int PPT, typename VT>
+template <int ACC, int PPT, typename VT, typename GT = VT>
 __global__ __launch_bounds__(kSBlock) void bwd_value_d32_kernel(
     const VT *__restrict__ grad_out, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ level_start, const float *__restrict__ loc,
     const float *__restrict__ attn, int S, int M, int L, int Lq, int P, int p_shift, int tp_cap, int W,
-    VT *__restrict__ grad_value, int xcd)
+    GT *__restrict__ grad_value, int xcd)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // grid = W ranges x L levels x N*M pairs, range fastest
     const int bid = xcd ? xcd_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
-    bwd_value_body<ACC, PPT, VT>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, tp_cap,
-                                   grad_value, bid % W, W, (bid / W) % L, bid / (W * L), smem);
+    bwd_value_body<ACC, PPT, VT, GT>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, tp_cap,
+                                       grad_value, bid % W, W, (bid / W) % L, bid / (W * L), smem);
 }
 
 // One launch for the whole backward of a single-pass problem: the first nB workgroups are role B
 // (grad_value), the rest role A (grad_sampling_loc / grad_attn_weight).  The two roles share no
 // data, so this is plain concurrency inside one grid — it removes a dependent kernel boundary
 // (~1.5 us) and lets role A's short workgroups fill the CUs around role B's longer ones.
-template <int SPLIT, int ACC, typename VT, bool FUSED = false>
+template <int SPLIT, int ACC, typename VT, bool FUSED = false, typename GT = VT>
 __global__ __launch_bounds__(kSBlock) void bwd_fused_d32_kernel(
     const VT *__restrict__ grad_out, const VT *__restrict__ value,
     const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
     const float *__restrict__ loc, const float *__restrict__ attn, int S, int M, int L, int Lq,
     int P, int items, int p_shift, int lp_shift, int m_shift, int tp_cap, int W, int nB,
-    VT *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attn,
+    GT *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attn,
     const PrologueOut pro = PrologueOut{nullptr, 0, 0}, int xcd = 0)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -730,11 +732,12 @@ __global__ __launch_bounds__(kSBlock) void bwd_fused_d32_kernel(
     if (bid < nB) {
         if (xcd) bid = xcd_block(bid, nB);
         const int ti = bid % W, l = (bid / W) % L, pr = bid / (W * L);
-        bwd_value_body<ACC, kSinglePPT, VT>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, tp_cap,
-                                          grad_value, ti, W, l, pr, smem);
+        bwd_value_body<ACC, kSinglePPT, VT, GT>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift,
+                                              tp_cap, grad_value, ti, W, l, pr, smem);
     } else {
+        // role A never touches grad_value unless it scatters with atomics (separate kernel, MSDA_BWD_MODE=atomic)
         bwd_query_body<SPLIT, false, kSBlock, VT, FUSED>(grad_out, value, shapes, level_start, loc, attn, S, M, L, Lq, P,
-                                                     items, p_shift, lp_shift, m_shift, grad_value, grad_loc, grad_attn,
+                                                     items, p_shift, lp_shift, m_shift, static_cast<VT *>(nullptr), grad_loc, grad_attn,
                                                      xcd ? xcd_block(bid - nB, (int)gridDim.x - nB) : bid - nB, smem, pro);
     }
 }
@@ -848,10 +851,11 @@ static int allow_lds(const void *fn, size_t bytes)
     return e == hipSuccess ? MSDA_OK : set_error(MSDA_ERR_LAUNCH, hipGetErrorString(e));
 }
 
-template <typename VT>
+// VT = storage of value / grad_out, GT = storage of grad_value (VT, or float for bf16 rows)
+template <typename VT, typename GT = VT>
 static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *shapes,
                             const int64_t *level_start, const float *loc, const float *attn, int N, int S,
-                            int M, int L, int Lq, int P, VT *grad_value, float *grad_loc, float *grad_attn,
+                            int M, int L, int Lq, int P, GT *grad_value, float *grad_loc, float *grad_attn,
                             hipStream_t stream)
 {
     const int items = N * Lq * M, LP = L * P;
@@ -869,10 +873,10 @@ static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *
     const int xcd = xcd_remap();
 
     if (bwd_mode == 2) {
-        hipError_t e = hipMemsetAsync(grad_value, 0, sizeof(VT) * (size_t)N * S * M * kD, stream);
+        hipError_t e = hipMemsetAsync(grad_value, 0, sizeof(GT) * (size_t)N * S * M * kD, stream);
         if (e != hipSuccess) return set_error(MSDA_ERR_LAUNCH, hipGetErrorString(e));
     } else {
-        const ValuePlan pl = plan_value<VT>(N, S, M, L, Lq, P, target_wgs);
+        const ValuePlan pl = plan_value<GT>(N, S, M, L, Lq, P, target_wgs);
         const long long nB = (long long)pl.W * N * M * L;
         // ---- whole backward in one launch when role A's workgroups can share the CUs (LDS) ----
         const int ipw_f = 64 / split;                                   // 512-thread role-A workgroups
@@ -882,7 +886,7 @@ static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *
             const dim3 fgrid((unsigned)(nB + nA));
             const size_t flds = pl.lds > lds_a ? pl.lds : lds_a;
 #define MSDA_LAUNCH_F(SP, AC)                                                                          \
-            hipLaunchKernelGGL((bwd_fused_d32_kernel<SP, AC, VT>), fgrid, dim3(kSBlock), flds, stream, grad_out,  \
+            hipLaunchKernelGGL((bwd_fused_d32_kernel<SP, AC, VT, false, GT>), fgrid, dim3(kSBlock), flds, stream, grad_out,  \
                                value, shapes, level_start, loc, attn, S, M, L, Lq, P, items, ps, lps, ms,        \
                                pl.tp_cap, pl.W, (int)nB, grad_value, grad_loc, grad_attn, PrologueOut{nullptr, 0, 0}, xcd)
             if (pl.acc == kAccNone) { if (split == 4) MSDA_LAUNCH_F(4, kAccNone); else if (split == 2) MSDA_LAUNCH_F(2, kAccNone); else MSDA_LAUNCH_F(1, kAccNone); }
@@ -894,8 +898,8 @@ static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *
         if (nB > 0x7fffffffLL) return set_error(MSDA_ERR_ARGUMENT, "msda backward (d32): too many grad_value workgroups");
         const dim3 grid((unsigned)nB);
 #define MSDA_LAUNCH_B(AC, PPT_)                                                                        \
-        do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_value_d32_kernel<AC, PPT_, VT>), pl.lds)) return rc; \
-             hipLaunchKernelGGL((bwd_value_d32_kernel<AC, PPT_, VT>), grid, dim3(kSBlock), pl.lds, stream, grad_out,    \
+        do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_value_d32_kernel<AC, PPT_, VT, GT>), pl.lds)) return rc; \
+             hipLaunchKernelGGL((bwd_value_d32_kernel<AC, PPT_, VT, GT>), grid, dim3(kSBlock), pl.lds, stream, grad_out,    \
                                 shapes, level_start, loc, attn, S, M, L, Lq, P, ps, pl.tp_cap, pl.W, grad_value, xcd); } while (0)
         if (pl.acc == kAccNone) MSDA_LAUNCH_B(kAccNone, kSinglePPT);
         else if (pl.acc == kAccTile) MSDA_LAUNCH_B(kAccTile, kMultiPPT);
@@ -910,7 +914,9 @@ static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *
         const dim3 grid((items + ipw - 1) / ipw), block(kBlock);
 #define MSDA_LAUNCH_A(SP, AT)                                                                          \
         hipLaunchKernelGGL((bwd_query_d32_kernel<SP, AT, VT>), grid, block, lds, stream, grad_out, value, shapes, \
-                           level_start, loc, attn, S, M, L, Lq, P, items, ps, lps, ms, grad_value, grad_loc, grad_attn, xcd)
+                           level_start, loc, attn, S, M, L, Lq, P, items, ps, lps, ms, gv_atomic, grad_loc, grad_attn, xcd)
+        VT *gv_atomic = nullptr;                                        // only the v1 atomic scatter writes grad_value here
+        if constexpr (sizeof(VT) == sizeof(GT)) gv_atomic = grad_value;
         if (bwd_mode == 2) { if (split == 4) MSDA_LAUNCH_A(4, true); else if (split == 2) MSDA_LAUNCH_A(2, true); else MSDA_LAUNCH_A(1, true); }
         else               { if (split == 4) MSDA_LAUNCH_A(4, false); else if (split == 2) MSDA_LAUNCH_A(2, false); else MSDA_LAUNCH_A(1, false); }
 #undef MSDA_LAUNCH_A
@@ -1005,5 +1011,14 @@ int launch_bwd_d32_bf16(const uint16_t *grad_out, const uint16_t *value, const i
     return launch_bwd_d32_t<bf16_t>(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, grad_value,
                                     grad_loc, grad_attn, stream);
 }
+int launch_bwd_d32_bf16_gv32(const uint16_t *grad_out, const uint16_t *value, const int64_t *shapes,
+                             const int64_t *level_start, const float *loc, const float *attn, int N, int S, int M, int L,
+                             int Lq, int P, float *grad_value, float *grad_loc, float *grad_attn, hipStream_t stream)
+{
+    return launch_bwd_d32_t<bf16_t, float>(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, grad_value,
+                                           grad_loc, grad_attn, stream);
+}
+
+int backward_passes(int Lq, int P) { return (Lq * P + kSingleMaxPoints - 1) / kSingleMaxPoints; }
 
 }  // namespace msda

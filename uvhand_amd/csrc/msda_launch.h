@@ -43,6 +43,14 @@ int launch_bwd_d32_bf16(const uint16_t *grad_out, const uint16_t *value, const i
                         int M, int L, int Lq, int P, uint16_t *grad_value, float *grad_loc, float *grad_attn,
                         hipStream_t stream);
 
+// bf16 rows in, fp32 grad_value out: nothing is rounded between the passes of a multi-pass backward (and a
+// caller whose value tensor is fp32 needs no conversion of the result)
+int launch_bwd_d32_bf16_gv32(const uint16_t *grad_out, const uint16_t *value, const int64_t *shapes,
+                             const int64_t *level_start, const float *loc, const float *attn, int N, int S, int M, int L,
+                             int Lq, int P, float *grad_value, float *grad_loc, float *grad_attn, hipStream_t stream);
+// number of query chunks ("passes") role B of the D = 32 backward takes for Lq*P sampling points per (b, m, l)
+int backward_passes(int Lq, int P);
+
 // ---- fused prologue (fp32, D = 32 family): softmax over L*P and loc = ref + offset/(W,H) inside the kernels.
 // ld_* = floats between consecutive (batch, query) rows of the raw offsets / logits and of their gradients
 // (validated by the ABI layer: >= the dense width, offsets' even).

@@ -77,10 +77,14 @@ class MSDeformAttnBF16Function(Function):
     def backward(ctx, grad_output):
         value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights = \
             ctx.saved_tensors
+        # grad_value in float32 straight from the kernel when that is what `value` needs anyway, and for long
+        # backwards (several query chunks accumulate: fp32 in place, one rounding at the end)
+        Lq, P = sampling_locations.shape[1], sampling_locations.shape[4]
+        fp32_gv = value.dtype == torch.float32 or MSDA.backward_passes(Lq, P) > 1
         grad_value, grad_sampling_loc, grad_attn_weight = MSDA.ms_deform_attn_backward(
             value.to(torch.bfloat16), value_spatial_shapes, value_level_start_index,
             sampling_locations.float(), attention_weights.float(),
-            grad_output.to(torch.bfloat16).contiguous(), ctx.im2col_step)
+            grad_output.to(torch.bfloat16).contiguous(), ctx.im2col_step, fp32_grad_value=fp32_gv)
         return (grad_value.to(value.dtype), None, None, grad_sampling_loc.to(sampling_locations.dtype),
                 grad_attn_weight.to(attention_weights.dtype), None)
 
