@@ -13,23 +13,51 @@
 // Here: fp32 MFMA (v_mfma_f32_32x32x2_f32: exact fp32 fma chain, no reduced precision), split over
 // the reduction dimension M so that a small output still fills the chip, and a fixed-order second
 // stage so the result is bitwise reproducible (no float atomics):
-//   stage 1  grid (N/64 * K/64 tiles, SPLITS): each workgroup owns a 64x64 tile of dW and a chunk of
-//            rows; both operands are row-major with the reduction index as the row, so 32-row stages
-//            are straight coalesced copies into LDS (At[kk][i], Bs[kk][j]) and every MFMA operand
-//            read is 32 consecutive floats (conflict-free ds_read_b32); 4 wavefronts = 2x2 sub-tiles
-//            of 32x32; next stage's global loads are issued before the current stage's MFMAs.
-//            Column sums of dY (the bias gradient) ride along in the tiles with k0 == 0.
-//   stage 2  sums the SPLITS partial slabs in split order (skipped when SPLITS == 1).
+//   stage 1  1-D grid of (N/64 * K/64 tiles) x SPLITS workgroups (~3 per CU): each owns a 64x64 tile of dW
+//            and a chunk of rows; both operands are row-major with the reduction index as the row, so
+//            32-row stages are straight coalesced copies into LDS (At[kk][i], Bs[kk][j]) and every MFMA
+//            operand read is 32 consecutive floats; 4 wavefronts = 2x2 sub-tiles of 32x32; the stage's
+//            32 operand reads are issued ahead of its 16 MFMAs, and the next stage's global loads before
+//            them.  Column sums of dY (the bias gradient) ride along in the tiles with k0 == 0.
+//   stage 2  sums the SPLITS partial slabs in a fixed association (skipped when SPLITS == 1).
+// 8.8 us at M = 600 (N = K = 256), 20.7 us at M = 6120, 59 us at M = 33440 (74 TFLOP/s; hipBLASLt + the
+// bias reduction: 152 / 62 / 170 us) — tools/wgrad_time.py.
 //
 // Padding mask (modules/ms_deform_attn.py:97-98: value.masked_fill(padding_mask[..., None], 0) after
 // value_proj): instead of two full passes over [N, S, 256] (the masked_fill and its backward), the forward
 // zeroes only the masked ROWS of the GEMM output in place (zero_masked_rows_kernel), and the backward passes
 // the row mask to stage 1, which stages zeros for masked rows of dY — the weight and bias gradients of the
 // masked product without materialising it; the input gradient's masked rows are zeroed the same way.
+#include <cstdlib>
+
 #include "msda_common.h"
 #include "msda_launch.h"
 
 namespace msda {
+
+// (output tile, M-split) of a workgroup in the 1-D grid of tiles*splits.  All the tiles of one split read the
+// same rows of dY and X (each row 4x at N = K = 256 with 64-wide tiles): numbered naively they land on
+// different XCDs (workgroup id mod 8) and every XCD's L2 fetches those rows from HBM again — the kernel was
+// bandwidth-bound at ~4.7 TB/s that way.  With splits a multiple of 8, XCD x takes the splits x, x+8, ...
+// whole, so a split's rows are fetched into ONE L2 and its other tiles hit there.
+__device__ __forceinline__ void tile_and_split(int id, int tiles, int splits, int &tile, int &split)
+{
+    if ((splits & 7) == 0) {
+        const int x = id & 7, slot = id >> 3;
+        split = (slot / tiles) * 8 + x;
+        tile = slot % tiles;
+    } else {
+        tile = id % tiles;
+        split = id / tiles;
+    }
+}
+
+// v or zeros, component-wise selects (a float4 ?: makes the compiler select between two addresses and
+// park both operands in scratch memory)
+__device__ __forceinline__ float4 keep4(const float4 &v, bool keep)
+{
+    return make_float4(keep ? v.x : 0.f, keep ? v.y : 0.f, keep ? v.z : 0.f, keep ? v.w : 0.f);
+}
 
 constexpr int kWgTile = 64;        // output tile is kWgTile x kWgTile
 constexpr int kWgStage = 32;       // reduction rows per LDS stage (64 measured: no faster)
@@ -38,55 +66,64 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 __global__ __launch_bounds__(kWgBlock) void linear_wgrad_partial_kernel(
     const float *__restrict__ dY, const float *__restrict__ X, const uint8_t *__restrict__ row_mask, int M, int N, int K,
-    int chunk, long long slab, float *__restrict__ out_w, float *__restrict__ out_b)
+    int chunk, int tiles, int splits, long long slab, float *__restrict__ out_w, float *__restrict__ out_b)
 {
     // `slab` = elements between consecutive splits' partial results (0 when there is one split and the
     // results go straight to dW / db)
     __shared__ __attribute__((aligned(16))) float At[kWgStage][kWgTile];
     __shared__ __attribute__((aligned(16))) float Bs[kWgStage][kWgTile];
     const int tiles_k = (K + kWgTile - 1) / kWgTile;
-    const int n0 = ((int)blockIdx.x / tiles_k) * kWgTile, k0 = ((int)blockIdx.x % tiles_k) * kWgTile;
-    const int split = blockIdx.y;
+    int tile, split;
+    tile_and_split((int)blockIdx.x, tiles, splits, tile, split);
+    const int n0 = (tile / tiles_k) * kWgTile, k0 = (tile % tiles_k) * kWgTile;
     const int m_begin = split * chunk, m_end = min(M, m_begin + chunk);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int i0 = (wave >> 1) * 32, j0 = (wave & 1) * 32, h = lane >> 5, c = lane & 31;
 
     // global -> register staging: kWgStage rows x 64 floats per operand = kLd float4 per thread and operand
-    constexpr int kLd = kWgStage / 16;
+    constexpr int kLd = kWgStage / 16, kRowStep = 16;
     const int lrow = tid >> 4, lcol = (tid & 15) * 4;                 // rows lrow, lrow + 16, ...
     const bool a_ok = n0 + lcol < N, b_ok = k0 + lcol < K;            // N, K are multiples of 4 (host check)
     float4 ra[kLd], rb[kLd];
-    uint8_t dead[kLd];                                                 // row is masked: stage zeros for it
+    unsigned mk[kLd];                                                  // mask byte of each staged row (0 = live)
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto load_stage = [&](int m0) {
-#pragma unroll
-        for (int r = 0; r < kLd; ++r) {
-            const int m = m0 + lrow + 16 * r;
-            // the mask byte travels with the row loads (no dependent load) and is applied at the LDS store
-            dead[r] = (row_mask && m < m_end) ? row_mask[m] : (uint8_t)0;
-            ra[r] = (a_ok && m < m_end) ? *reinterpret_cast<const float4 *>(dY + (long long)m * N + n0 + lcol) : zero;
-            rb[r] = (b_ok && m < m_end) ? *reinterpret_cast<const float4 *>(X + (long long)m * K + k0 + lcol) : zero;
-        }
-    };
+    // (a macro, not a lambda: capturing ra / rb by reference parks them in scratch memory)
+#define MSDA_LOAD_STAGE(m0_)                                                                                        \
+    do {                                                                                                            \
+        _Pragma("unroll") for (int r = 0; r < kLd; ++r) {                                                           \
+            const int m = (m0_) + lrow + kRowStep * r;                                                              \
+            /* the mask byte travels with the row loads (nothing waits on it) and is applied at the LDS store */    \
+            mk[r] = 0;                                                                                              \
+            if (row_mask != nullptr && m < m_end) mk[r] = row_mask[m];                                              \
+            ra[r] = zero; rb[r] = zero;                                                                             \
+            if (a_ok && m < m_end) ra[r] = *reinterpret_cast<const float4 *>(dY + (long long)m * N + n0 + lcol);    \
+            if (b_ok && m < m_end) rb[r] = *reinterpret_cast<const float4 *>(X + (long long)m * K + k0 + lcol);     \
+        }                                                                                                           \
+    } while (0)
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     float bsum = 0.f;                                                   // column sum of dY (threads 0..63, k0 == 0 tiles)
     const bool do_bias = out_b != nullptr && k0 == 0;
 
-    load_stage(m_begin);
+    MSDA_LOAD_STAGE(m_begin);
     for (int m0 = m_begin; m0 < m_end; m0 += kWgStage) {
         __syncthreads();                                                // previous stage's reads are done
 #pragma unroll
         for (int r = 0; r < kLd; ++r) {
-            *reinterpret_cast<float4 *>(&At[lrow + 16 * r][lcol]) = dead[r] ? zero : ra[r];
+            *reinterpret_cast<float4 *>(&At[lrow + 16 * r][lcol]) = keep4(ra[r], mk[r] == 0);
             *reinterpret_cast<float4 *>(&Bs[lrow + 16 * r][lcol]) = rb[r];
         }
         __syncthreads();
-        if (m0 + kWgStage < m_end) load_stage(m0 + kWgStage);          // in flight during the MFMAs below
+        if (m0 + kWgStage < m_end) MSDA_LOAD_STAGE(m0 + kWgStage);     // in flight during the MFMAs below
+        // all operand reads of the stage first, then the MFMA chain: the LDS latency is paid once per stage,
+        // not once per MFMA (lane half h supplies reduction row 2s + h)
+        float av[kWgStage / 2], bv[kWgStage / 2];
 #pragma unroll
-        for (int s = 0; s < kWgStage / 2; ++s)                          // lane half h supplies reduction row 2s + h
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(At[2 * s + h][i0 + c], Bs[2 * s + h][j0 + c], acc, 0, 0, 0);
+        for (int s = 0; s < kWgStage / 2; ++s) { av[s] = At[2 * s + h][i0 + c]; bv[s] = Bs[2 * s + h][j0 + c]; }
+        __builtin_amdgcn_sched_barrier(0);               // keep the reads ahead of the chain (the scheduler sinks them back)
+#pragma unroll
+        for (int s = 0; s < kWgStage / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
         if (do_bias && tid < kWgTile) {
 #pragma unroll
             for (int kk = 0; kk < kWgStage; ++kk) bsum += At[kk][tid];
@@ -103,20 +140,47 @@ __global__ __launch_bounds__(kWgBlock) void linear_wgrad_partial_kernel(
     if (do_bias && tid < kWgTile && n0 + tid < N) out_b[(long long)split * slab + n0 + tid] = bsum;
 }
 
+#undef MSDA_LOAD_STAGE
+
 // Fixed-order sum of the partial slabs (each slab = [N*K weight partials][N bias partials]):
-// out[e] = part[0][e] + part[1][e] + ...; elements below nw go to dW, the rest to db.
+// out[e] = sum_k part[k][e]; elements below nw go to dW, the rest to db.  A workgroup takes 64 float4 columns;
+// its 4 wavefronts each sum a quarter of the splits (4 independent loads in flight per lane), and the four
+// partial sums are combined through LDS in wavefront order — the association is fixed, so the result is
+// bitwise reproducible, and the chain of dependent loads is splits/4 long instead of splits.
 __global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(const float *__restrict__ part, int splits, long long nw,
                                                                    long long n, float *__restrict__ dW,
                                                                    float *__restrict__ db)
 {
-    const long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (e >= n || (e >= nw && db == nullptr)) return;                   // nw and n are multiples of 4
-    float4 s = *reinterpret_cast<const float4 *>(part + e);
-    for (int k = 1; k < splits; ++k) {
-        const float4 v = *reinterpret_cast<const float4 *>(part + (long long)k * n + e);
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    __shared__ float4 sums[4][64];
+    const int g = threadIdx.x >> 6, col = threadIdx.x & 63;
+    const long long e = ((long long)blockIdx.x * 64 + col) * 4;
+    const bool live = e < n && !(e >= nw && db == nullptr);              // nw and n are multiples of 4
+    const int per = (splits + 3) / 4, k0 = g * per, k1 = min(splits, k0 + per);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+        int k = k0;
+        for (; k + 4 <= k1; k += 4) {
+            const float4 v0 = *reinterpret_cast<const float4 *>(part + (long long)k * n + e);
+            const float4 v1 = *reinterpret_cast<const float4 *>(part + (long long)(k + 1) * n + e);
+            const float4 v2 = *reinterpret_cast<const float4 *>(part + (long long)(k + 2) * n + e);
+            const float4 v3 = *reinterpret_cast<const float4 *>(part + (long long)(k + 3) * n + e);
+            s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+            s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
+            s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
+            s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
+        }
+        for (; k < k1; ++k) {
+            const float4 v = *reinterpret_cast<const float4 *>(part + (long long)k * n + e);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
     }
-    *reinterpret_cast<float4 *>(e < nw ? dW + e : db + (e - nw)) = s;
+    sums[g][col] = s;
+    __syncthreads();
+    if (g == 0 && live) {
+#pragma unroll
+        for (int w = 1; w < 4; ++w) { const float4 v = sums[w][col]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+        *reinterpret_cast<float4 *>(e < nw ? dW + e : db + (e - nw)) = s;
+    }
 }
 
 // x[r, :] = 0 for every row with mask[r] != 0; one wavefront per row, float4 per lane.  Unmasked rows
@@ -137,12 +201,24 @@ int launch_zero_masked_rows(float *x, const uint8_t *mask, long long rows, int c
     return check_launch("msda zero masked rows");
 }
 
+static int env_knob(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+// Number of M-splits: enough workgroups to fill the chip (a few per CU: the kernel hides its barriers and
+// LDS round trips behind other wavefronts' MFMAs), at least two stages per chunk, and — when there are 8 or
+// more — a multiple of 8 so that whole splits go to one XCD (tile_and_split).
 static int wgrad_splits(int M, int N, int K)
 {
+    static const int target = env_knob("MSDA_WGRAD_WGS", 768);
     const int tiles = ((N + kWgTile - 1) / kWgTile) * ((K + kWgTile - 1) / kWgTile);
-    int splits = (512 + tiles - 1) / tiles;                             // aim at ~512 workgroups
-    const int max_splits = (M + 2 * kWgStage - 1) / (2 * kWgStage);     // at least two stages per chunk
+    int splits = (target + tiles - 1) / tiles;
+    const int max_splits = (M + 2 * kWgStage - 1) / (2 * kWgStage);
     if (splits > max_splits) splits = max_splits;
+    if (splits >= 8) splits = (splits + 4) & ~7;                        // nearest multiple of 8
+    if (splits > max_splits) splits -= 8;
     return splits < 1 ? 1 : splits;
 }
 
@@ -159,19 +235,18 @@ int launch_linear_wgrad(const float *dY, const float *X, const uint8_t *row_mask
     int chunk = (M + splits - 1) / splits;
     chunk = ((chunk + kWgStage - 1) / kWgStage) * kWgStage;
     const int tiles = ((N + kWgTile - 1) / kWgTile) * ((K + kWgTile - 1) / kWgTile);
-    const dim3 grid((unsigned)tiles, (unsigned)splits);
+    const dim3 grid((unsigned)(tiles * splits));
+    auto partial = linear_wgrad_partial_kernel;
     if (splits == 1) {
-        hipLaunchKernelGGL(linear_wgrad_partial_kernel, grid, dim3(kWgBlock), 0, stream, dY, X, row_mask, M, N, K, chunk, 0LL, dW,
-                           db);
+        hipLaunchKernelGGL(partial, grid, dim3(kWgBlock), 0, stream, dY, X, row_mask, M, N, K, chunk, tiles, splits, 0LL, dW, db);
         return check_launch("msda linear wgrad");
     }
     if (workspace == nullptr) return set_error(MSDA_ERR_ARGUMENT, "msda linear wgrad: workspace required");
     const long long nw = (long long)N * K, slab = nw + N;               // per split: weight partials, then bias partials
-    hipLaunchKernelGGL(linear_wgrad_partial_kernel, grid, dim3(kWgBlock), 0, stream, dY, X, row_mask, M, N, K, chunk, slab,
-                       workspace,
+    hipLaunchKernelGGL(partial, grid, dim3(kWgBlock), 0, stream, dY, X, row_mask, M, N, K, chunk, tiles, splits, slab, workspace,
                        db ? workspace + nw : nullptr);
     if (int rc = check_launch("msda linear wgrad (partial)")) return rc;
-    hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((unsigned)((slab / 4 + 255) / 256)), dim3(256), 0, stream, workspace,
+    hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((unsigned)((slab / 4 + 63) / 64)), dim3(256), 0, stream, workspace,
                        splits, nw, slab, dW, db);
     return check_launch("msda linear wgrad (reduce)");
 }
