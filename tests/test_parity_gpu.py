@@ -108,6 +108,24 @@ ORACLE_CASES = {
 }
 
 
+@pytest.mark.parametrize("spread", [0.0, 0.02, 0.2])
+def test_taps_piled_on_few_pixels(native, oracle, spread):
+    """grad_value's counting sort with every sampling point inside a small patch (collisions: thousands of
+    taps on one pixel, most rows of the map empty).  cfg-2 decoder geometry; compared with the C oracle."""
+    z = make_case(11, 2, [(48, 48), (24, 24), (12, 12), (6, 6)], 8, 32, 300, 4)
+    g = torch.Generator().manual_seed(12)
+    centre = torch.tensor([0.37, 0.61])
+    z["loc"] = (centre + (torch.rand(z["loc"].shape, generator=g) - 0.5) * spread).numpy().astype(np.float32)
+    out, gv, gl, ga = run_hip(z, torch.float32)
+    args = [z["value"], z["shapes"], z["level_start"], z["loc"], z["attn"]]
+    r_gv, r_gl, r_ga = oracle.backward(z["grad_out"], *args)
+    assert rel_err(out, oracle.forward(*args)) < 5e-6
+    assert rel_err(gv, r_gv) < 2e-5                     # up to 9 600 taps on one pixel: fp32 summation order
+    assert rel_err(ga, r_ga) < 2e-5
+    keep = ~near_boundary_mask(z, tol=1e-5)
+    assert rel_err(gl[keep], r_gl[keep]) < 2e-5
+
+
 @pytest.mark.parametrize("name", list(ORACLE_CASES))
 def test_fp32_matches_c_oracle(native, oracle, path, name):
     z = make_case(1, *ORACLE_CASES[name])
