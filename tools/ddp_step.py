@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--dec", type=int, default=6)
     ap.add_argument("--ballast-mb", type=float, default=0.0)
     ap.add_argument("--levels", default="28,14,7,4")
+    ap.add_argument("--amp", default="", choices=["", "bf16"],
+                    help="bf16: torch.autocast(bfloat16) around the forward + bf16 row storage in the op (BASELINE config 3)")
     args = ap.parse_args()
 
     rank, local_rank, world = harness.dist_env()
@@ -135,9 +137,18 @@ def main():
     pos = torch.randn(args.window, S, 256, generator=g).to(device) * 0.1
     enc_ref = encoder_reference_points(shapes_list, device).expand(args.window, -1, -1, -1).contiguous()
 
+    if args.amp == "bf16":
+        for mod in model.modules():
+            if isinstance(mod, MSDeformAttn):
+                mod.bf16_storage = True
+
     def step():
         opt.zero_grad(set_to_none=True)
-        loss = model(src, pos, enc_ref, shapes, lsi)
+        if args.amp == "bf16":
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = model(src, pos, enc_ref, shapes, lsi)
+        else:
+            loss = model(src, pos, enc_ref, shapes, lsi)
         loss.backward()
         torch.nn.utils.clip_grad_norm_(model.parameters(), 0.1)
         opt.step()
@@ -157,7 +168,7 @@ def main():
         print(json.dumps({"harness": "ddp_step", "n_gpus": world, "frames_per_s": total / elapsed,
                           "ms_per_step": 1e3 * elapsed / args.steps, "steps": args.steps,
                           "per_rank": {"window": args.window, "S": S, "queries": args.queries, "enc": args.enc,
-                                       "dec": args.dec, "ballast_mb": args.ballast_mb},
+                                       "dec": args.dec, "ballast_mb": args.ballast_mb, "amp": args.amp or None},
                           "backend": backend if distributed else None, "loss_finite": finite}))
     if distributed:
         torch.distributed.barrier()
