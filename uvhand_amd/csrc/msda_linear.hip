@@ -17,10 +17,11 @@
 //            and a chunk of rows; both operands are row-major with the reduction index as the row, so
 //            32-row stages are straight coalesced copies into LDS (At[kk][i], Bs[kk][j]) and every MFMA
 //            operand read is 32 consecutive floats; 4 wavefronts = 2x2 sub-tiles of 32x32; the stage's
-//            32 operand reads are issued ahead of its 16 MFMAs, and the next stage's global loads before
-//            them.  Column sums of dY (the bias gradient) ride along in the tiles with k0 == 0.
+//            32 operand reads are issued ahead of its 16 MFMAs; LDS is double-buffered (the stage loaded
+//            during the MFMAs is stored behind them, one barrier per stage) and the global loads run two
+//            stages ahead.  Column sums of dY (the bias gradient) ride along in the tiles with k0 == 0.
 //   stage 2  sums the SPLITS partial slabs in a fixed association (skipped when SPLITS == 1).
-// 8.8 us at M = 600 (N = K = 256), 20.7 us at M = 6120, 59 us at M = 33440 (74 TFLOP/s; hipBLASLt + the
+// 9.0 us at M = 600 (N = K = 256), 21.5 us at M = 6120, 53.7 us at M = 33440 (82 TFLOP/s; hipBLASLt + the
 // bias reduction: 152 / 62 / 170 us) — tools/wgrad_time.py.
 //
 // Padding mask (modules/ms_deform_attn.py:97-98: value.masked_fill(padding_mask[..., None], 0) after
@@ -70,8 +71,8 @@ __global__ __launch_bounds__(kWgBlock) void linear_wgrad_partial_kernel(
 {
     // `slab` = elements between consecutive splits' partial results (0 when there is one split and the
     // results go straight to dW / db)
-    __shared__ __attribute__((aligned(16))) float At[kWgStage][kWgTile];
-    __shared__ __attribute__((aligned(16))) float Bs[kWgStage][kWgTile];
+    __shared__ __attribute__((aligned(16))) float At[2][kWgStage][kWgTile];
+    __shared__ __attribute__((aligned(16))) float Bs[2][kWgStage][kWgTile];
     const int tiles_k = (K + kWgTile - 1) / kWgTile;
     int tile, split;
     tile_and_split((int)blockIdx.x, tiles, splits, tile, split);
@@ -103,31 +104,47 @@ __global__ __launch_bounds__(kWgBlock) void linear_wgrad_partial_kernel(
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    float bsum = 0.f;                                                   // column sum of dY (threads 0..63, k0 == 0 tiles)
+    // bias gradient (k0 == 0 tiles): thread t sums column t & 63 over the 8 stage rows 8*(t >> 6) ...; the four
+    // partial sums of a column are combined through LDS at the end (fixed association)
+    float bsum = 0.f;
     const bool do_bias = out_b != nullptr && k0 == 0;
+    const int bcol = tid & (kWgTile - 1), brow = (tid >> 6) * (kWgStage / 4);
 
+    // LDS is double-buffered: the stage being multiplied and the next one being filled, ONE barrier per stage
     MSDA_LOAD_STAGE(m_begin);
-    for (int m0 = m_begin; m0 < m_end; m0 += kWgStage) {
-        __syncthreads();                                                // previous stage's reads are done
 #pragma unroll
-        for (int r = 0; r < kLd; ++r) {
-            *reinterpret_cast<float4 *>(&At[lrow + 16 * r][lcol]) = keep4(ra[r], mk[r] == 0);
-            *reinterpret_cast<float4 *>(&Bs[lrow + 16 * r][lcol]) = rb[r];
-        }
-        __syncthreads();
-        if (m0 + kWgStage < m_end) MSDA_LOAD_STAGE(m0 + kWgStage);     // in flight during the MFMAs below
+    for (int r = 0; r < kLd; ++r) {
+        *reinterpret_cast<float4 *>(&At[0][lrow + 16 * r][lcol]) = keep4(ra[r], mk[r] == 0);
+        *reinterpret_cast<float4 *>(&Bs[0][lrow + 16 * r][lcol]) = rb[r];
+    }
+    MSDA_LOAD_STAGE(m_begin + kWgStage);                                // rows past m_end load as zeros
+    __syncthreads();
+    int cur = 0;
+    for (int m0 = m_begin; m0 < m_end; m0 += kWgStage) {
         // all operand reads of the stage first, then the MFMA chain: the LDS latency is paid once per stage,
         // not once per MFMA (lane half h supplies reduction row 2s + h)
         float av[kWgStage / 2], bv[kWgStage / 2];
 #pragma unroll
-        for (int s = 0; s < kWgStage / 2; ++s) { av[s] = At[2 * s + h][i0 + c]; bv[s] = Bs[2 * s + h][j0 + c]; }
+        for (int s = 0; s < kWgStage / 2; ++s) { av[s] = At[cur][2 * s + h][i0 + c]; bv[s] = Bs[cur][2 * s + h][j0 + c]; }
+        if (do_bias) {
+#pragma unroll
+            for (int kk = 0; kk < kWgStage / 4; ++kk) bsum += At[cur][brow + kk][bcol];
+        }
         __builtin_amdgcn_sched_barrier(0);               // keep the reads ahead of the chain (the scheduler sinks them back)
 #pragma unroll
         for (int s = 0; s < kWgStage / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
-        if (do_bias && tid < kWgTile) {
+        // the next stage (loaded while the MFMAs ran) goes into the other buffer, whose last readers passed
+        // the barrier of the previous iteration; then the loads of the stage after it are issued
+        if (m0 + kWgStage < m_end) {
 #pragma unroll
-            for (int kk = 0; kk < kWgStage; ++kk) bsum += At[kk][tid];
+            for (int r = 0; r < kLd; ++r) {
+                *reinterpret_cast<float4 *>(&At[cur ^ 1][lrow + 16 * r][lcol]) = keep4(ra[r], mk[r] == 0);
+                *reinterpret_cast<float4 *>(&Bs[cur ^ 1][lrow + 16 * r][lcol]) = rb[r];
+            }
+            if (m0 + 2 * kWgStage < m_end) MSDA_LOAD_STAGE(m0 + 2 * kWgStage);
         }
+        __syncthreads();
+        cur ^= 1;
     }
 
     // C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
@@ -137,7 +154,13 @@ __global__ __launch_bounds__(kWgBlock) void linear_wgrad_partial_kernel(
         const int i = n0 + i0 + (r & 3) + 8 * (r >> 2) + 4 * h, j = k0 + j0 + c;
         if (i < N && j < K) ow[(long long)i * K + j] = acc[r];
     }
-    if (do_bias && tid < kWgTile && n0 + tid < N) out_b[(long long)split * slab + n0 + tid] = bsum;
+    if (do_bias) {                                                      // uniform per workgroup
+        float *bpart = &At[0][0][0];                                    // the stage buffers are free now (barrier above)
+        bpart[tid] = bsum;
+        __syncthreads();
+        if (tid < kWgTile && n0 + tid < N)
+            out_b[(long long)split * slab + n0 + tid] = (bpart[tid] + bpart[tid + 64]) + (bpart[tid + 128] + bpart[tid + 192]);
+    }
 }
 
 #undef MSDA_LOAD_STAGE
