@@ -48,10 +48,15 @@ def shard_batch(global_batch, rank, world):
 
 
 def barrier(device=None):
-    if device is not None and device.type == "cuda":
+    """All ranks' queued GPU work done, every rank arrived, and (NCCL's barrier is itself stream work) that
+    arrival observed by the host: synchronize, barrier, synchronize."""
+    cuda = device is not None and device.type == "cuda"
+    if cuda:
         torch.cuda.synchronize(device)
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
+        if cuda:
+            torch.cuda.synchronize(device)
 
 
 def max_over_ranks(seconds, device=None):
