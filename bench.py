@@ -190,8 +190,8 @@ def event_time_ms(fn, iters, stream):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=500)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", default="cfg2_decoder", choices=sorted(WORKLOADS))
     ap.add_argument("--no-graph", action="store_true", help="time the eager autograd path")
     ap.add_argument("--graph-steps", type=int, default=10,
