@@ -495,6 +495,16 @@ constexpr int kSBlock = 512;
 constexpr int kSWaves = kSBlock / kWave;
 constexpr int kAccNone = 0, kAccRmw = 1, kAccTile = 2;
 struct alignas(8) SRec { float w; int q; };
+// Fixed-capacity segments (FIXED = true: steps 1-3 in one scan, for problems small enough that every workgroup
+// is resident at once and the backward is one latency chain): row d owns the record slots [d*CAP, (d+1)*CAP),
+// CAP = the largest power of two with rows*CAP <= the record array, so a tap's record goes straight to
+// d*CAP + (its rank from the histogram atomic) — no prefix sum, no second scan, two barriers fewer.  The few
+// taps whose row is already full go to a short overflow list that the gather of exactly those rows also walks;
+// a workgroup whose overflow list fills up (many taps piled on few pixels) starts over on the prefix-sum path.
+// Not used on large problems: there the sort phases hide behind other workgroups' gathers, and clustered
+// locations make many rows walk the overflow list (profiles/r01_notes.md).
+struct SOvf { float w; int q; int row; };
+constexpr int kOvfCap = 256;                // overflow entries per workgroup (3 KB of LDS)
 
 // role-B sizing: single pass while 4*Lq*P records (8 B) fit beside the histogram in 64 KB of LDS
 constexpr int kSinglePPT = 3;               // points per thread: 3*512 = 1536 points, 48 KB of records
@@ -520,8 +530,11 @@ __device__ __forceinline__ void add4(float4 &a, const float4 &b) { a.x += b.x; a
 template <int SLOTS, int ACC, typename VT, typename GT>
 __device__ __forceinline__ void gather_rows(const VT *__restrict__ go_base, GT *__restrict__ gv_base,
                                             const int *cnt, const int *start, const SRec *rec, float *tile,
-                                            int npx, int row_stride, bool first_pass)
+                                            int npx, int row_stride, bool first_pass, int cap_shift = -1,
+                                            const SOvf *ovf = nullptr, int novf = 0)
 {
+    // cap_shift >= 0: fixed-capacity segments (row d at d << cap_shift, at most 1 << cap_shift records there,
+    // the rest of a fuller row in ovf[0, novf)); cap_shift < 0: segments from the prefix sum (start[])
     constexpr int DPW = 8 / SLOTS;
     constexpr int CH = 4;
     constexpr int RSTEP = kSWaves * DPW;                     // rows per workgroup trip
@@ -530,8 +543,11 @@ __device__ __forceinline__ void gather_rows(const VT *__restrict__ go_base, GT *
     for (int dA = wave * DPW + dsub; dA < npx; dA += 2 * RSTEP) {
         const int dB = dA + RSTEP;
         const bool hasB = dB < npx;
-        const int nA = cnt[dA], nB = hasB ? cnt[dB] : 0;
-        const SRec *rA = rec + start[dA], *rB = rec + (hasB ? start[dB] : 0);
+        const int fullA = cnt[dA], fullB = hasB ? cnt[dB] : 0;
+        const int nA = cap_shift >= 0 ? min(fullA, 1 << cap_shift) : fullA;
+        const int nB = cap_shift >= 0 ? min(fullB, 1 << cap_shift) : fullB;
+        const SRec *rA = rec + (cap_shift >= 0 ? dA << cap_shift : start[dA]);
+        const SRec *rB = rec + (!hasB ? 0 : cap_shift >= 0 ? dB << cap_shift : start[dB]);
         float4 accA = make_float4(0.f, 0.f, 0.f, 0.f), accB = accA;
         const int nmax = max(nA, nB);
         for (int i0 = slot; i0 < nmax; i0 += CH * SLOTS) {
@@ -552,6 +568,13 @@ __device__ __forceinline__ void gather_rows(const VT *__restrict__ go_base, GT *
             }
 #pragma unroll
             for (int u = 0; u < CH; ++u) { fma4(accA, ra[u].w, ga[u]); fma4(accB, rb[u].w, gb[u]); }
+        }
+        if (novf > 0 && (fullA > nA || fullB > nB)) {                  // rare: this lane group's row overflowed
+            for (int i = slot; i < novf; i += SLOTS) {
+                const SOvf e = ovf[i];
+                if (e.row == dA) fma4(accA, e.w, Row<VT>::load(go_base + (long long)e.q * row_stride));
+                else if (hasB && e.row == dB) fma4(accB, e.w, Row<VT>::load(go_base + (long long)e.q * row_stride));
+            }
         }
         if (SLOTS >= 2) { add4(accA, shfl_xor4(accA, 8)); add4(accB, shfl_xor4(accB, 8)); }
         if (SLOTS >= 4) { add4(accA, shfl_xor4(accA, 16)); add4(accB, shfl_xor4(accB, 16)); }
@@ -582,7 +605,7 @@ __device__ __forceinline__ void gather_rows(const VT *__restrict__ go_base, GT *
 // step 1 and step 3, so loc / attn are read exactly once and step 3 needs no atomics.
 // VT = storage type of grad_out, GT = storage type of grad_value (the same, or float for bf16 rows with an
 // fp32 grad_value: no rounding between passes, kAccRmw instead of the LDS tile).
-template <int ACC, int PPT, typename VT, typename GT = VT>
+template <int ACC, int PPT, typename VT, typename GT = VT, bool FIXED = false>
 __device__ __forceinline__ void bwd_value_body(
     const VT *__restrict__ grad_out, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ level_start, const float *__restrict__ loc,
@@ -590,12 +613,13 @@ __device__ __forceinline__ void bwd_value_body(
     GT *__restrict__ grad_value, int ti, int W, int l, int pr, unsigned char *smem)
 {
     constexpr int NPC = PPT * kSBlock;                       // points per pass
-    // LDS: [tile: tp_cap*32 floats if kAccTile] [cnt tp_cap] [start tp_cap] [wsum 16] [rec]
+    // LDS: [tile: tp_cap*32 floats if kAccTile] [cnt tp_cap] [start tp_cap] [wsum 16] [rec] [ovf kOvfCap if FIXED]
     float *tile = reinterpret_cast<float *>(smem);
     int *cnt = reinterpret_cast<int *>(smem + (ACC == kAccTile ? (size_t)tp_cap * kD * 4 : 0));
     int *start = cnt + tp_cap;
     int *wsum = start + tp_cap;
     SRec *rec = reinterpret_cast<SRec *>(wsum + 16);
+    int *novf_p = wsum + 8, *total_p = wsum + 9;             // wsum[0..7]: per-wavefront sums of the prefix scan
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     MSDA_STAMP(0);
@@ -610,6 +634,10 @@ __device__ __forceinline__ void bwd_value_body(
     const int NP = Lq * P;
     const long long item_base = (long long)b * Lq * M + m;                   // item(q) = item_base + q*M
     const int row_stride = M * kD;
+    const int rec_cap = 4 * min(NP, NPC);                                    // records the host sized `rec` for
+    SOvf *ovf = reinterpret_cast<SOvf *>(rec + rec_cap);
+    // fixed-capacity segments need a few slots per row (uniform; small maps with few queries go the prefix way)
+    const int cap_shift = (FIXED && rec_cap >= 4 * npx) ? 31 - __clz(rec_cap / npx) : -1;
     const VT *go_base = grad_out + item_base * kD + (lane & 7) * 4;
     GT *gv_base = grad_value + ((long long)(b * S + lstart + px0) * M + m) * kD + (lane & 7) * 4;
 
@@ -629,10 +657,12 @@ __device__ __forceinline__ void bwd_value_body(
             }
         }
         for (int i = tid; i < npx; i += kSBlock) cnt[i] = 0;
+        if (FIXED && tid == 0) { *novf_p = 0; *total_p = 0; }
         __syncthreads();
         MSDA_STAMP(1);
-        // ---- 1. taps of each point; histogram rank of each tap on its row ----
-        int dest[PPT][4], rank[PPT][4]; float tw[PPT][4];
+        // ---- 1. taps of each point ----
+        int dest[PPT][4]; float tw[PPT][4];
+        const bool first = (c0 == 0);
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             const PointGeom<float> g = point_geom<float>(xy[k].x, xy[k].y, H, Wd);
@@ -646,9 +676,53 @@ __device__ __forceinline__ void bwd_value_body(
             const float hh = 1.f - g.lh, hw = 1.f - g.lw;
             tw[k][0] = hh * hw * at[k]; tw[k][1] = hh * g.lw * at[k];
             tw[k][2] = g.lh * hw * at[k]; tw[k][3] = g.lh * g.lw * at[k];
+        }
+        // ---- 1-3 the short way: fixed-capacity segments, a tap's record goes straight to its slot ----
+        if (FIXED && cap_shift >= 0) {
+            // all the histogram atomics first (they pipeline: nothing waits on a returned rank yet), then the
+            // record writes
+            int mine_taps = 0, rk[PPT][4];
+#pragma unroll
+            for (int k = 0; k < PPT; ++k)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { rk[k][t] = 0; if (dest[k][t] >= 0) { rk[k][t] = atomicAdd(&cnt[dest[k][t]], 1); ++mine_taps; } }
+#pragma unroll
+            for (int k = 0; k < PPT; ++k)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (dest[k][t] >= 0) {
+                        const int r = rk[k][t];
+                        if (r < (1 << cap_shift)) { SRec e; e.w = tw[k][t]; e.q = qq[k]; rec[(dest[k][t] << cap_shift) + r] = e; }
+                        else {
+                            const int o = atomicAdd(novf_p, 1);
+                            if (o < kOvfCap) { SOvf e; e.w = tw[k][t]; e.q = qq[k]; e.row = dest[k][t]; ovf[o] = e; }
+                        }
+                    }
+            mine_taps = wave_sum(mine_taps);
+            if (lane == 0) atomicAdd(total_p, mine_taps);
+            __syncthreads();
+            const int novf = *novf_p;
+            if (novf <= kOvfCap) {
+                MSDA_STAMP(2); MSDA_STAMP(3); MSDA_STAMP(4);
+                const int mean2f = (2 * *total_p) / npx;
+                if (mean2f <= 8)       gather_rows<1, ACC, VT, GT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first, cap_shift, ovf, novf);
+                else if (mean2f <= 16) gather_rows<2, ACC, VT, GT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first, cap_shift, ovf, novf);
+                else if (mean2f <= 32) gather_rows<4, ACC, VT, GT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first, cap_shift, ovf, novf);
+                else                   gather_rows<8, ACC, VT, GT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first, cap_shift, ovf, novf);
+                if (ACC != kAccNone) __syncthreads();
+                MSDA_STAMP(5);
+                continue;
+            }
+            // the overflow list filled up (taps piled on few pixels): start over on the prefix-sum path
+            for (int i = tid; i < npx; i += kSBlock) cnt[i] = 0;
+            __syncthreads();
+        }
+        // ---- 1. histogram rank of each tap on its row ----
+        int rank[PPT][4];
+#pragma unroll
+        for (int k = 0; k < PPT; ++k)
 #pragma unroll
             for (int t = 0; t < 4; ++t) { rank[k][t] = 0; if (dest[k][t] >= 0) rank[k][t] = atomicAdd(&cnt[dest[k][t]], 1); }
-        }
         __syncthreads();
         MSDA_STAMP(2);
         // ---- 2. exclusive prefix sum over the rows (512 threads x CH consecutive rows) ----
@@ -681,7 +755,6 @@ __device__ __forceinline__ void bwd_value_body(
         MSDA_STAMP(4);
         // ---- 4. gather; lanes per row chosen from the mean segment length (uniform) ----
         const int mean2 = (2 * total) / npx;                                  // 2 x mean records per row
-        const bool first = (c0 == 0);
         if (mean2 <= 8)       gather_rows<1, ACC, VT, GT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
         else if (mean2 <= 16) gather_rows<2, ACC, VT, GT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
         else if (mean2 <= 32) gather_rows<4, ACC, VT, GT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
@@ -700,6 +773,36 @@ __device__ __forceinline__ void bwd_value_body(
     }
 }
 
+
+// Role-B workgroup id -> (pair, level, range, ranges of that level).  A (batch, head) pair has W*L workgroups.
+// They are dealt W per level, except that on a pyramid (the level with the most pixels has >= 4x the pixels
+// of the one with the fewest; W >= 2) the largest level takes one range from the smallest: every level
+// receives the same number of taps, but a fine level's gather also walks 4-64x more rows, and the launch ends
+// with its slowest workgroup (cfg-2 decoder: level 0 gather 5.9 us vs 3.6 us for level 3 with W = 4 each).
+// Uniform (scalar) arithmetic; the shapes come from the scalar cache.
+__device__ __forceinline__ void value_block_to_range(int bid, int W, int L, const int64_t *__restrict__ shapes,
+                                                     int &pr, int &l, int &ti, int &Wl)
+{
+    const int T = W * L;
+    pr = bid / T;
+    const int s = bid - pr * T;
+    int lmax = 0, lmin = 0;
+    long long rmax = shapes[0] * shapes[1], rmin = rmax;
+    for (int k = 1; k < L; ++k) {
+        const long long r = shapes[2 * k] * shapes[2 * k + 1];
+        if (r > rmax) { rmax = r; lmax = k; }
+        if (r <= rmin) { rmin = r; lmin = k; }
+    }
+    const bool skew = L >= 2 && W >= 2 && lmax != lmin && rmax >= 4 * rmin;
+    int base = 0;
+    l = 0; ti = 0; Wl = W;
+    for (int k = 0; k < L; ++k) {
+        const int wk = W + (skew ? (int)(k == lmax) - (int)(k == lmin) : 0);
+        if (s < base + wk) { l = k; ti = s - base; Wl = wk; return; }
+        base += wk;
+    }
+}
+
 template <int ACC, int PPT, typename VT, typename GT = VT>
 __global__ __launch_bounds__(kSBlock) void bwd_value_d32_kernel(
     const VT *__restrict__ grad_out, const int64_t *__restrict__ shapes,
@@ -710,15 +813,17 @@ __global__ __launch_bounds__(kSBlock) void bwd_value_d32_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // grid = W ranges x L levels x N*M pairs, range fastest
     const int bid = xcd ? xcd_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+    int pr, l, ti, Wl;
+    value_block_to_range(bid, W, L, shapes, pr, l, ti, Wl);
     bwd_value_body<ACC, PPT, VT, GT>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, tp_cap,
-                                       grad_value, bid % W, W, (bid / W) % L, bid / (W * L), smem);
+                                       grad_value, ti, Wl, l, pr, smem);
 }
 
 // One launch for the whole backward of a single-pass problem: the first nB workgroups are role B
 // (grad_value), the rest role A (grad_sampling_loc / grad_attn_weight).  The two roles share no
 // data, so this is plain concurrency inside one grid — it removes a dependent kernel boundary
 // (~1.5 us) and lets role A's short workgroups fill the CUs around role B's longer ones.
-template <int SPLIT, int ACC, typename VT, bool FUSED = false, typename GT = VT>
+template <int SPLIT, int ACC, typename VT, bool FUSED = false, typename GT = VT, bool FIXED = false>
 __global__ __launch_bounds__(kSBlock) void bwd_fused_d32_kernel(
     const VT *__restrict__ grad_out, const VT *__restrict__ value,
     const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
@@ -731,9 +836,10 @@ __global__ __launch_bounds__(kSBlock) void bwd_fused_d32_kernel(
     int bid = (int)blockIdx.x;
     if (bid < nB) {
         if (xcd) bid = xcd_block(bid, nB);
-        const int ti = bid % W, l = (bid / W) % L, pr = bid / (W * L);
-        bwd_value_body<ACC, kSinglePPT, VT, GT>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift,
-                                              tp_cap, grad_value, ti, W, l, pr, smem);
+        int pr, l, ti, Wl;
+        value_block_to_range(bid, W, L, shapes, pr, l, ti, Wl);
+        bwd_value_body<ACC, kSinglePPT, VT, GT, FIXED>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift,
+                                                     tp_cap, grad_value, ti, Wl, l, pr, smem);
     } else {
         // role A never touches grad_value unless it scatters with atomics (separate kernel, MSDA_BWD_MODE=atomic)
         bwd_query_body<SPLIT, false, kSBlock, VT, FUSED>(grad_out, value, shapes, level_start, loc, attn, S, M, L, Lq, P,
@@ -840,7 +946,7 @@ static ValuePlan plan_value(int N, int S, int M, int L, int Lq, int P, int targe
     pl.tp_cap = (pl.tp_cap + 3) & ~3;                                 // keeps the LDS arrays 16-B aligned
     const int pass_points = min(NP, pl.ppt * kSBlock);
     pl.lds = (pl.acc == kAccTile ? (size_t)pl.tp_cap * kD * 4 : 0) + (2 * (size_t)pl.tp_cap + 16) * 4 +
-             (size_t)4 * pass_points * sizeof(SRec);
+             (size_t)4 * pass_points * sizeof(SRec) + (size_t)kOvfCap * sizeof(SOvf);
     return pl;
 }
 
@@ -849,6 +955,28 @@ static int allow_lds(const void *fn, size_t bytes)
     if (bytes <= 64 * 1024) return MSDA_OK;
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     return e == hipSuccess ? MSDA_OK : set_error(MSDA_ERR_LAUNCH, hipGetErrorString(e));
+}
+
+// The fused backward launch of a SMALL problem.  The fused kernel keeps two 512-thread workgroups per CU (its
+// ~100 VGPRs allow 4 wavefronts per SIMD), i.e. 512 resident at once.  When role B's and role A's workgroups
+// do not all fit, the last role-A workgroups start only after a slot frees up and become the tail of the
+// launch; halving their number (role A's SPLIT 4 -> 2) lets everything start at once.  If everything is resident
+// the backward is one latency chain and role B takes the short sort (FIXED, see SOvf); bigger problems keep
+// the prefix-sum sort, whose phases hide behind other workgroups' gathers.  MSDA_BWD_FIXED=0 disables both.
+struct FusedPlan { int split; bool fixed; };
+static FusedPlan plan_fused(int items, int LP, int split, long long nB, int acc, int whole_queries_of = 0)
+{
+    // whole_queries_of = M when role A must hold whole queries per workgroup (fused prologue), else 0
+    static const int enabled = env_int("MSDA_BWD_FIXED", 1);
+    constexpr long long kResident = 512;
+    FusedPlan fp{split, false};
+    if (!enabled || acc != kAccNone) return fp;
+    auto n_a = [&](int sp) { const int ipw = 64 / sp; return (long long)((items + ipw - 1) / ipw); };
+    if (nB + n_a(split) > kResident && split == 4 && LP >= 2 && nB + n_a(2) <= kResident &&
+        (whole_queries_of == 0 || (64 / 2) % whole_queries_of == 0))
+        fp.split = 2;
+    fp.fixed = nB + n_a(fp.split) <= kResident;
+    return fp;
 }
 
 // VT = storage of value / grad_out, GT = storage of grad_value (VT, or float for bf16 rows)
@@ -879,20 +1007,24 @@ static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *
         const ValuePlan pl = plan_value<GT>(N, S, M, L, Lq, P, target_wgs);
         const long long nB = (long long)pl.W * N * M * L;
         // ---- whole backward in one launch when role A's workgroups can share the CUs (LDS) ----
-        const int ipw_f = 64 / split;                                   // 512-thread role-A workgroups
-        const size_t lds_a = (size_t)ipw_f * item_stride + (size_t)ipw_f * LP * 16;
-        const long long nA = (items + ipw_f - 1) / ipw_f;
-        if (bwd_mode == 0 && pl.ppt == kSinglePPT && pl.acc != kAccTile && nB + nA <= 0x7fffffffLL) {
-            const dim3 fgrid((unsigned)(nB + nA));
-            const size_t flds = pl.lds > lds_a ? pl.lds : lds_a;
-#define MSDA_LAUNCH_F(SP, AC)                                                                          \
-            hipLaunchKernelGGL((bwd_fused_d32_kernel<SP, AC, VT, false, GT>), fgrid, dim3(kSBlock), flds, stream, grad_out,  \
-                               value, shapes, level_start, loc, attn, S, M, L, Lq, P, items, ps, lps, ms,        \
-                               pl.tp_cap, pl.W, (int)nB, grad_value, grad_loc, grad_attn, PrologueOut{nullptr, 0, 0}, xcd)
-            if (pl.acc == kAccNone) { if (split == 4) MSDA_LAUNCH_F(4, kAccNone); else if (split == 2) MSDA_LAUNCH_F(2, kAccNone); else MSDA_LAUNCH_F(1, kAccNone); }
-            else                    { if (split == 4) MSDA_LAUNCH_F(4, kAccRmw); else if (split == 2) MSDA_LAUNCH_F(2, kAccRmw); else MSDA_LAUNCH_F(1, kAccRmw); }
+        if (bwd_mode == 0 && pl.ppt == kSinglePPT && pl.acc != kAccTile) {
+            const FusedPlan fp = plan_fused(items, LP, split, nB, pl.acc);
+            const int ipw_f = 64 / fp.split;                            // 512-thread role-A workgroups
+            const size_t lds_a = (size_t)ipw_f * item_stride + (size_t)ipw_f * LP * 16;
+            const long long nA = (items + ipw_f - 1) / ipw_f;
+            if (nB + nA <= 0x7fffffffLL) {
+                const dim3 fgrid((unsigned)(nB + nA));
+                const size_t flds = pl.lds > lds_a ? pl.lds : lds_a;
+#define MSDA_LAUNCH_F(SP, AC, FX)                                                                      \
+                hipLaunchKernelGGL((bwd_fused_d32_kernel<SP, AC, VT, false, GT, FX>), fgrid, dim3(kSBlock), flds, stream,  \
+                                   grad_out, value, shapes, level_start, loc, attn, S, M, L, Lq, P, items, ps, lps, ms,  \
+                                   pl.tp_cap, pl.W, (int)nB, grad_value, grad_loc, grad_attn, PrologueOut{nullptr, 0, 0}, xcd)
+                if (fp.fixed)                { if (fp.split == 4) MSDA_LAUNCH_F(4, kAccNone, true); else if (fp.split == 2) MSDA_LAUNCH_F(2, kAccNone, true); else MSDA_LAUNCH_F(1, kAccNone, true); }
+                else if (pl.acc == kAccNone) { if (fp.split == 4) MSDA_LAUNCH_F(4, kAccNone, false); else if (fp.split == 2) MSDA_LAUNCH_F(2, kAccNone, false); else MSDA_LAUNCH_F(1, kAccNone, false); }
+                else                         { if (fp.split == 4) MSDA_LAUNCH_F(4, kAccRmw, false); else if (fp.split == 2) MSDA_LAUNCH_F(2, kAccRmw, false); else MSDA_LAUNCH_F(1, kAccRmw, false); }
 #undef MSDA_LAUNCH_F
-            return check_launch("msda backward (d32, fused)");
+                return check_launch("msda backward (d32, fused)");
+            }
         }
         // ---- role B as its own launch (large record arrays / bf16 tile / A-B knob) ----
         if (nB > 0x7fffffffLL) return set_error(MSDA_ERR_ARGUMENT, "msda backward (d32): too many grad_value workgroups");
@@ -968,7 +1100,8 @@ int launch_bwd_prologue(const float *grad_out, const float *value, const int64_t
     const int ps = pow2_shift(P), lps = pow2_shift(LP), ms = pow2_shift(M);
     const ValuePlan pl = plan_value<float>(N, S, M, L, Lq, P, bwd_target_wgs());
     const long long nB = (long long)pl.W * N * M * L;
-    const int ipw_f = kSWaves * 8 / split;
+    const FusedPlan fp = plan_fused(items, LP, split, nB, pl.acc, M);
+    const int ipw_f = kSWaves * 8 / fp.split;
     const size_t lds_a = (size_t)ipw_f * item_stride + (size_t)ipw_f * LP * 16;
     const long long nA = (items + ipw_f - 1) / ipw_f;
     if (pl.ppt != kSinglePPT || pl.acc == kAccTile || nB + nA > 0x7fffffffLL)
@@ -976,12 +1109,13 @@ int launch_bwd_prologue(const float *grad_out, const float *value, const int64_t
     const dim3 fgrid((unsigned)(nB + nA));
     const size_t flds = pl.lds > lds_a ? pl.lds : lds_a;
     const PrologueOut pro{grad_ref, (int)((ld_grad_offsets - 2LL * M * LP) / 2), (int)(ld_grad_logits - (long long)M * LP)};
-#define MSDA_LAUNCH_BP(SP, AC)                                                                         \
-    hipLaunchKernelGGL((bwd_fused_d32_kernel<SP, AC, float, true>), fgrid, dim3(kSBlock), flds, stream, grad_out, value,  \
-                       shapes, level_start, loc, attn, S, M, L, Lq, P, items, ps, lps, ms, pl.tp_cap, pl.W, (int)nB,    \
+#define MSDA_LAUNCH_BP(SP, AC, FX)                                                                     \
+    hipLaunchKernelGGL((bwd_fused_d32_kernel<SP, AC, float, true, float, FX>), fgrid, dim3(kSBlock), flds, stream, grad_out, \
+                       value, shapes, level_start, loc, attn, S, M, L, Lq, P, items, ps, lps, ms, pl.tp_cap, pl.W, (int)nB,  \
                        grad_value, grad_offsets, grad_logits, pro, xcd_remap())
-    if (pl.acc == kAccNone) { if (split == 4) MSDA_LAUNCH_BP(4, kAccNone); else if (split == 2) MSDA_LAUNCH_BP(2, kAccNone); else MSDA_LAUNCH_BP(1, kAccNone); }
-    else                    { if (split == 4) MSDA_LAUNCH_BP(4, kAccRmw); else if (split == 2) MSDA_LAUNCH_BP(2, kAccRmw); else MSDA_LAUNCH_BP(1, kAccRmw); }
+    if (fp.fixed)                { if (fp.split == 4) MSDA_LAUNCH_BP(4, kAccNone, true); else if (fp.split == 2) MSDA_LAUNCH_BP(2, kAccNone, true); else MSDA_LAUNCH_BP(1, kAccNone, true); }
+    else if (pl.acc == kAccNone) { if (fp.split == 4) MSDA_LAUNCH_BP(4, kAccNone, false); else if (fp.split == 2) MSDA_LAUNCH_BP(2, kAccNone, false); else MSDA_LAUNCH_BP(1, kAccNone, false); }
+    else                         { if (fp.split == 4) MSDA_LAUNCH_BP(4, kAccRmw, false); else if (fp.split == 2) MSDA_LAUNCH_BP(2, kAccRmw, false); else MSDA_LAUNCH_BP(1, kAccRmw, false); }
 #undef MSDA_LAUNCH_BP
     return check_launch("msda backward (d32, fused prologue)");
 }
