@@ -105,6 +105,8 @@ ORACLE_CASES = {
     "d200":          (1, [(6, 6)], 2, 200, 5, 3),
     "five_levels":   (1, [(10, 10), (5, 5), (3, 3), (2, 2), (1, 1)], 8, 32, 50, 2),
     "wide_map":      (1, [(3, 40), (20, 2)], 8, 32, 64, 4),
+    "few_queries":   (1, [(40, 40), (20, 20)], 8, 32, 3, 2),                    # more rows than record slots per workgroup
+    "flat_levels":   (2, [(9, 9), (9, 9), (8, 10)], 8, 32, 120, 4),             # equal-size levels: no range skew
 }
 
 
