@@ -641,7 +641,10 @@ __device__ __forceinline__ void bwd_value_body(
     const VT *go_base = grad_out + item_base * kD + (lane & 7) * 4;
     GT *gv_base = grad_value + ((long long)(b * S + lstart + px0) * M + m) * kD + (lane & 7) * 4;
 
-    for (int c0 = 0; c0 < NP; c0 += NPC) {
+    // single-pass kernels (the host only picks them when NP <= NPC): a visible trip count of one lets the
+    // compiler keep the per-pass arrays out of the loop-carried state (103 -> 90 VGPRs)
+    const int np_loop = ACC == kAccNone ? min(NP, NPC) : NP;
+    for (int c0 = 0; c0 < np_loop; c0 += NPC) {
         // ---- loads of this pass's points first: they overlap the histogram reset ----
         float2 xy[PPT]; float at[PPT]; int qq[PPT];
 #pragma unroll
