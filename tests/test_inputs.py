@@ -1,0 +1,67 @@
+"""uvhand_amd.utils — the op's argument construction against a fixture produced by the
+reference's own get_valid_ratio / get_reference_points (tests/golden/gen_golden_inputs.py), and the flatten /
+decoder helpers against their definition (models/arctic_transformer.py:157-177, :413-419).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from uvhand_amd.utils import (decoder_reference_points, encoder_reference_points, flatten_feature_levels,
+                              get_valid_ratio)
+
+
+def _fixture():
+    z = load_golden("inputs")
+    shapes = [tuple(int(x) for x in hw) for hw in z["shapes"]]
+    masks = [torch.from_numpy(z["mask%d" % i]) for i in range(len(shapes))]
+    return z, shapes, masks
+
+
+def test_valid_ratio_and_encoder_reference_points_match_the_reference():
+    z, shapes, masks = _fixture()
+    valid = torch.stack([get_valid_ratio(m) for m in masks], 1)
+    assert np.array_equal(valid.numpy(), z["valid_ratios"])
+    for spec in (shapes, torch.tensor(shapes, dtype=torch.long)):          # list of (H, W) or the int64 tensor
+        ref = encoder_reference_points(spec, valid)
+        assert ref.shape == z["enc_reference_points"].shape
+        assert np.allclose(ref.numpy(), z["enc_reference_points"], rtol=0, atol=1e-7)
+
+
+def test_flatten_feature_levels_layout():
+    _, shapes, masks = _fixture()
+    g = torch.Generator().manual_seed(3)
+    N, C = masks[0].shape[0], 8
+    srcs = [torch.randn(N, C, h, w, generator=g) for h, w in shapes]
+    poss = [torch.randn(N, C, h, w, generator=g) for h, w in shapes]
+    level_embed = torch.randn(len(shapes), C, generator=g)
+    src, mask, pos, ss, lsi, valid = flatten_feature_levels(srcs, masks, poss, level_embed)
+    S = sum(h * w for h, w in shapes)
+    assert src.shape == (N, S, C) and pos.shape == (N, S, C) and mask.shape == (N, S)
+    assert ss.dtype == torch.int64 and ss.tolist() == [list(s) for s in shapes]
+    assert lsi.dtype == torch.int64 and lsi.tolist() == [0, 192, 240, 252]
+    assert torch.equal(valid, torch.stack([get_valid_ratio(m) for m in masks], 1))
+    # element (b, level l, pixel (y, x), channel c) sits at row level_start[l] + y*W + x
+    for l, (h, w) in enumerate(shapes):
+        y, x = h - 1, w // 2
+        row = int(lsi[l]) + y * w + x
+        assert torch.equal(src[:, row], srcs[l][:, :, y, x])
+        assert torch.equal(pos[:, row], poss[l][:, :, y, x] + level_embed[l])
+        assert torch.equal(mask[:, row], masks[l][:, y, x])
+
+
+def test_decoder_reference_points_2d_and_42d():
+    z, _, _ = _fixture()
+    valid = torch.from_numpy(z["valid_ratios"])                            # [N, L, 2] = (w, h)
+    N, L = valid.shape[:2]
+    g = torch.Generator().manual_seed(5)
+    p2 = torch.rand(N, 7, 2, generator=g)
+    out2 = decoder_reference_points(p2, valid)
+    assert out2.shape == (N, 7, L, 2)
+    assert torch.equal(out2[1, 3, 2], p2[1, 3] * valid[1, 2])
+    p42 = torch.rand(N, 7, 42, generator=g)
+    out42 = decoder_reference_points(p42, valid)
+    assert out42.shape == (N, 7, L, 42)
+    assert torch.equal(out42[2, 5, 1, 0::2], p42[2, 5, 0::2] * valid[2, 1, 0])     # x coordinates scale with w
+    assert torch.equal(out42[2, 5, 1, 1::2], p42[2, 5, 1::2] * valid[2, 1, 1])     # y coordinates with h
+    with pytest.raises(ValueError):
+        decoder_reference_points(torch.rand(N, 7, 4), valid)

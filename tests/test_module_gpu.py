@@ -202,3 +202,31 @@ def test_module_merged_and_separate_projections_agree():
         res[merged] = [out.detach()] + [t.grad for t in a[:3]] + [p.grad.clone() for p in mod.parameters()]
     for x, y in zip(res[True], res[False]):
         assert rel_err(x.cpu().numpy(), y.cpu().numpy()) < 1e-5
+
+
+def test_caller_side_argument_construction_feeds_the_module():
+    """A feature pyramid with padded samples -> flatten_feature_levels / encoder_reference_points (uvhand_amd.utils,
+    the reference transformer's glue) -> MSDeformAttn on the GPU: shapes, finiteness, and zero influence of the
+    padded pixels' features (they are masked out of value)."""
+    from uvhand_amd.modules import MSDeformAttn
+    from uvhand_amd.utils import encoder_reference_points, flatten_feature_levels
+    torch.manual_seed(0)
+    shapes, N, C = [(12, 16), (6, 8), (3, 4), (2, 2)], 2, 256
+    srcs = [torch.randn(N, C, h, w, device="cuda") for h, w in shapes]
+    poss = [torch.randn(N, C, h, w, device="cuda") * 0.1 for h, w in shapes]
+    masks = []
+    for h, w in shapes:
+        m = torch.zeros(N, h, w, dtype=torch.bool, device="cuda")
+        m[1, :, w - w // 4:] = True                                       # sample 1: right quarter is padding
+        masks.append(m)
+    level_embed = torch.randn(len(shapes), C, device="cuda") * 0.1
+    mod = MSDeformAttn(C, len(shapes), 8, 4).cuda()
+    src, mask, pos, ss, lsi, valid = flatten_feature_levels(srcs, masks, poss, level_embed)
+    ref = encoder_reference_points(ss, valid)
+    assert ss.is_cuda and ss.dtype == torch.int64 and ref.shape == (N, src.shape[1], len(shapes), 2)
+    out = mod(src + pos, ref, src, ss, lsi, mask)
+    assert out.shape == src.shape and torch.isfinite(out).all()
+    src2 = src.clone()
+    src2[mask] = 1e6                                                       # garbage in the padded pixels' features
+    out2 = mod(src + pos, ref, src2, ss, lsi, mask)
+    assert torch.equal(out, out2)

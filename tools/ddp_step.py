@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 
 from uvhand_amd import harness                      # noqa: E402
 from uvhand_amd.modules import MSDeformAttn         # noqa: E402
+from uvhand_amd.utils import encoder_reference_points  # noqa: E402
 
 
 class EncoderLayer(nn.Module):
@@ -89,17 +90,6 @@ class SyntheticDeformableStack(nn.Module):
         return loss
 
 
-def encoder_reference_points(shapes_list, device):
-    """Pixel-centre grid per level, normalised (models/arctic_transformer.py:310-323 with valid_ratio 1)."""
-    refs = []
-    for h, w in shapes_list:
-        ys, xs = torch.meshgrid(torch.linspace(0.5, h - 0.5, h, device=device) / h,
-                                torch.linspace(0.5, w - 0.5, w, device=device) / w, indexing="ij")
-        refs.append(torch.stack((xs.reshape(-1), ys.reshape(-1)), -1))
-    ref = torch.cat(refs, 0)                                   # [S, 2]
-    return ref[None, :, None, :].expand(1, -1, len(shapes_list), -1)
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=10)
@@ -135,7 +125,8 @@ def main():
     g = torch.Generator(device="cpu").manual_seed(harness.rank_seed(100, rank))     # each rank: its own frames
     src = torch.randn(args.window, S, 256, generator=g).to(device)
     pos = torch.randn(args.window, S, 256, generator=g).to(device) * 0.1
-    enc_ref = encoder_reference_points(shapes_list, device).expand(args.window, -1, -1, -1).contiguous()
+    valid_ratios = torch.ones(args.window, len(shapes_list), 2, device=device)         # unpadded crops
+    enc_ref = encoder_reference_points(shapes_list, valid_ratios, device)               # [window, S, L, 2]
 
     if args.amp == "bf16":
         for mod in model.modules():
