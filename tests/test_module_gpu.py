@@ -230,3 +230,40 @@ def test_caller_side_argument_construction_feeds_the_module():
     src2[mask] = 1e6                                                       # garbage in the padded pixels' features
     out2 = mod(src + pos, ref, src2, ss, lsi, mask)
     assert torch.equal(out, out2)
+
+
+def _random_prologue_geometries(count, seed):
+    rng = np.random.RandomState(seed)
+    out = []
+    while len(out) < count:
+        L, P, M = int(rng.choice([1, 2, 4])), int(rng.choice([1, 2, 4])), int(rng.choice([1, 2, 4, 8]))
+        shapes = [(int(rng.randint(1, 20)), int(rng.randint(1, 20))) for _ in range(L)]
+        out.append((int(rng.randint(1, 4)), int(rng.choice([1, 5, 64, 300, 500])), shapes, M, P))
+    return out
+
+
+@pytest.mark.parametrize("idx,geo", list(enumerate(_random_prologue_geometries(16, 7))))
+def test_prologue_random_geometries(idx, geo):
+    """Fused prologue (merged projection layout) on random supported geometries against the fp64 composition of
+    the plain function; geometries the kernels do not take must be reported unsupported, not mis-computed."""
+    from uvhand_amd import _native
+    from uvhand_amd.functions import MSDeformAttnFunction, MSDeformAttnMergedPrologueFunction
+    N, Lq, shapes, M, P = geo
+    sh, lsi, value, ref, off, logits, go = _prologue_case(900 + idx, N, Lq, shapes, M=M, P=P)
+    L = len(shapes)
+    if not _native.prologue_supported(value, ref, off, logits):
+        pytest.skip("geometry not taken by the fused-prologue kernels (the module composes the plain ops)")
+    proj = torch.cat([off.detach().reshape(N, Lq, -1), logits.detach().reshape(N, Lq, -1)], -1).requires_grad_(True)
+    out = MSDeformAttnMergedPrologueFunction.apply(value, sh, lsi, ref, proj, 64, M, L, P)
+    out.backward(go)
+    wh = torch.stack([sh[:, 1], sh[:, 0]], -1).double()
+    vd, rd, pd = (t.detach().double().requires_grad_(True) for t in (value, ref, proj))
+    mlp = M * L * P
+    od, ld = pd[..., :2 * mlp].reshape(N, Lq, M, L, P, 2), pd[..., 2 * mlp:].reshape(N, Lq, M, L * P)
+    attn = torch.softmax(ld, -1).view(N, Lq, M, L, P)
+    loc = rd[:, :, None, :, None, :] + od / wh[None, None, None, :, None, :]
+    out_ref = MSDeformAttnFunction.apply(vd, sh, lsi, loc, attn, 64)
+    out_ref.backward(go.double())
+    assert rel_err(out.detach().cpu().numpy(), out_ref.detach().cpu().numpy()) < 2e-5
+    for name, g32, t64 in zip(("value", "ref", "projected"), (value.grad, ref.grad, proj.grad), (vd, rd, pd)):
+        assert rel_err(g32.cpu().numpy(), t64.grad.cpu().numpy()) < 1e-4, (name, geo)

@@ -110,6 +110,41 @@ ORACLE_CASES = {
 }
 
 
+def _random_geometries(count, seed):
+    """Seeded random D=32 geometries: 1-5 levels of 1x1 ... 24x24 pixels (some pyramids, some not), 1-9 heads,
+    1-4 points, 1-700 queries, 1-3 batch elements — the workgroup numbering, range dealing, SPLIT choice and
+    single / multi-pass plans all depend on these."""
+    rng = np.random.RandomState(seed)
+    cases = []
+    for _ in range(count):
+        L = int(rng.randint(1, 6))
+        P = int(rng.randint(1, 5))
+        if rng.rand() < 0.5:                                            # a pyramid
+            h, w = int(rng.randint(4, 25)), int(rng.randint(4, 25))
+            shapes = [(max(1, h >> k), max(1, w >> k)) for k in range(L)]
+        else:
+            shapes = [(int(rng.randint(1, 25)), int(rng.randint(1, 25))) for _ in range(L)]
+        M = int(rng.choice([1, 2, 3, 4, 5, 8, 8, 8, 9]))
+        Lq = int(rng.choice([1, 2, 7, 33, 100, 300, 301, 450, 700]))
+        N = int(rng.randint(1, 4))
+        cases.append((N, shapes, M, 32, Lq, P))
+    return cases
+
+
+@pytest.mark.parametrize("idx,case", list(enumerate(_random_geometries(36, 2024))))
+def test_random_geometries_match_c_oracle(native, oracle, idx, case):
+    z = make_case(100 + idx, *case)
+    out, gv, gl, ga = run_hip(z, torch.float32)
+    args = [z["value"], z["shapes"], z["level_start"], z["loc"], z["attn"]]
+    r_gv, r_gl, r_ga = oracle.backward(z["grad_out"], *args)
+    assert rel_err(out, oracle.forward(*args)) < 5e-6, case
+    assert rel_err(gv, r_gv) < 2e-5, case
+    assert rel_err(ga, r_ga) < 2e-5, case
+    keep = ~near_boundary_mask(z, tol=1e-5)
+    if keep.any():
+        assert rel_err(gl[keep], r_gl[keep]) < 2e-5, case
+
+
 @pytest.mark.parametrize("spread", [0.0, 0.02, 0.2])
 def test_taps_piled_on_few_pixels(native, oracle, spread):
     """grad_value's counting sort with every sampling point inside a small patch (collisions: thousands of

@@ -303,7 +303,12 @@ def _row_stride(t, name):
         if size != 1 and stride != inner:
             raise RuntimeError("%s tensor has to be contiguous within a query row" % name)
         inner *= size
-    ld = t.stride(1) if t.shape[1] > 1 else inner
+    if t.shape[1] > 1:
+        ld = t.stride(1)
+    elif t.shape[0] > 1:
+        ld = t.stride(0)                       # one query per batch element: the rows are the batch elements
+    else:
+        ld = inner
     if ld < inner or (t.shape[0] > 1 and t.stride(0) != t.shape[1] * ld):
         raise RuntimeError("%s tensor has to be contiguous or a column block of a row-major matrix" % name)
     return ld
