@@ -145,6 +145,34 @@ def test_random_geometries_match_c_oracle(native, oracle, idx, case):
         assert rel_err(gl[keep], r_gl[keep]) < 2e-5, case
 
 
+def _random_generic_geometries(count, seed):
+    rng = np.random.RandomState(seed)
+    cases = []
+    for _ in range(count):
+        L, P = int(rng.randint(1, 5)), int(rng.randint(1, 6))
+        shapes = [(int(rng.randint(1, 14)), int(rng.randint(1, 14))) for _ in range(L)]
+        D = int(rng.choice([1, 2, 3, 7, 16, 31, 33, 48, 64, 65, 100]))
+        cases.append((int(rng.randint(1, 3)), shapes, int(rng.choice([1, 2, 3, 8])), D, int(rng.choice([1, 9, 40, 130])), P))
+    return cases
+
+
+@pytest.mark.parametrize("idx,case", list(enumerate(_random_generic_geometries(16, 99))))
+def test_random_generic_geometries_match_c_oracle(native, oracle, idx, case):
+    """The generic family (any D; fp32 and fp64) on seeded random geometries."""
+    z = make_case(300 + idx, *case)
+    args = [z["value"], z["shapes"], z["level_start"], z["loc"], z["attn"]]
+    for dtype, tol in ((torch.float32, 2e-5), (torch.float64, 1e-11)):
+        zz = {k: (v.astype(np.float64) if dtype == torch.float64 and v.dtype == np.float32 else v) for k, v in z.items()}
+        a64 = [zz["value"], zz["shapes"], zz["level_start"], zz["loc"], zz["attn"]]
+        out, gv, gl, ga = run_hip(zz, dtype)
+        r_gv, r_gl, r_ga = oracle.backward(zz["grad_out"], *a64)
+        assert rel_err(out, oracle.forward(*a64)) < tol, (case, dtype)
+        assert rel_err(gv, r_gv) < tol and rel_err(ga, r_ga) < tol, (case, dtype)
+        keep = ~near_boundary_mask(zz, tol=1e-5 if dtype == torch.float32 else 1e-12)
+        if keep.any():
+            assert rel_err(gl[keep], r_gl[keep]) < tol, (case, dtype)
+
+
 @pytest.mark.parametrize("spread", [0.0, 0.02, 0.2])
 def test_taps_piled_on_few_pixels(native, oracle, spread):
     """grad_value's counting sort with every sampling point inside a small patch (collisions: thousands of
@@ -455,6 +483,28 @@ def test_bf16_rows_with_fp32_grad_value(native, oracle, name):
     with pytest.raises(RuntimeError, match="bfloat16 rows only"):
         native.ms_deform_attn_backward(dev(z["value"]), dev(z["shapes"]), dev(z["level_start"]), dev(z["loc"]),
                                        dev(z["attn"]), dev(z["grad_out"]), 64, fp32_grad_value=True)
+
+
+@pytest.mark.parametrize("idx,case", list(enumerate(_random_geometries(12, 4242))))
+def test_bf16_random_geometries(native, oracle, idx, case):
+    """bf16 rows on seeded random D=32 geometries (both grad_value variants), same tolerances as above."""
+    z = make_case(500 + idx, *case)
+    z["value"] = _bf16_round(z["value"])
+    z["grad_out"] = _bf16_round(z["grad_out"])
+    args = [z["value"], z["shapes"], z["level_start"], z["loc"], z["attn"]]
+    r_out = oracle.forward(*args)
+    r_gv, r_gl, r_ga = oracle.backward(z["grad_out"], *args)
+    v16, go16 = dev(z["value"]).to(torch.bfloat16), dev(z["grad_out"]).to(torch.bfloat16)
+    s, i, l, a = dev(z["shapes"]), dev(z["level_start"]), dev(z["loc"]), dev(z["attn"])
+    out = native.ms_deform_attn_forward(v16, s, i, l, a, 64)
+    assert rel_err(out.float().cpu().numpy(), r_out) < 4e-3, case
+    keep = ~near_boundary_mask(z, tol=1e-5)
+    for gv32, tol in ((False, 4e-3), (True, 2e-5)):
+        gv, gl, ga = native.ms_deform_attn_backward(v16, s, i, l, a, go16, 64, fp32_grad_value=gv32)
+        assert rel_err(gv.float().cpu().numpy(), r_gv) < tol, (case, gv32)
+        assert rel_err(ga.cpu().numpy(), r_ga) < 2e-5, (case, gv32)
+        if keep.any():
+            assert rel_err(gl.cpu().numpy()[keep], r_gl[keep]) < 2e-5, (case, gv32)
 
 
 def test_bf16_storage_vs_fp32_path_and_errors(native):
