@@ -267,3 +267,38 @@ def test_prologue_random_geometries(idx, geo):
     assert rel_err(out.detach().cpu().numpy(), out_ref.detach().cpu().numpy()) < 2e-5
     for name, g32, t64 in zip(("value", "ref", "projected"), (value.grad, ref.grad, proj.grad), (vd, rd, pd)):
         assert rel_err(g32.cpu().numpy(), t64.grad.cpu().numpy()) < 1e-4, (name, geo)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_module_random_configurations_fused_vs_composed(seed):
+    """MSDeformAttn with random (heads, levels, points, queries, reference-point width, padding mask): the default
+    path (fused prologue, merged projection, masked-row kernels, custom weight gradient) against the same module
+    composing everything in PyTorch around the plain op (fused_prologue = False)."""
+    from uvhand_amd.modules import MSDeformAttn
+    rng = np.random.RandomState(1000 + seed)
+    M, L, P = int(rng.choice([1, 2, 4, 8])), int(rng.choice([1, 2, 3, 4])), int(rng.choice([1, 2, 4]))
+    shapes = [(int(rng.randint(2, 16)), int(rng.randint(2, 16))) for _ in range(L)]
+    N, Lq, width = int(rng.randint(1, 4)), int(rng.choice([1, 3, 50, 300])), int(rng.choice([2, 42]))
+    S, C = sum(h * w for h, w in shapes), 32 * M
+    torch.manual_seed(seed)
+    mod = MSDeformAttn(C, L, M, P).cuda()
+    with torch.no_grad():
+        for p in mod.parameters():
+            p.add_(torch.randn_like(p) * 0.05)
+    sh = torch.tensor(shapes, dtype=torch.long).cuda()
+    lsi = torch.cat((sh.new_zeros(1), sh.prod(1).cumsum(0)[:-1]))
+    query = torch.randn(N, Lq, C).cuda()
+    src = torch.randn(N, S, C).cuda()
+    refp = torch.rand(N, Lq, L, width).cuda()
+    mask = (torch.rand(N, S) < 0.1).cuda() if seed % 2 else None
+    go = torch.randn(N, Lq, C).cuda()
+    res = {}
+    for fused in (True, False):
+        mod.fused_prologue = fused
+        mod.zero_grad()
+        q, s_, r = (t.clone().requires_grad_(True) for t in (query, src, refp))
+        out = mod(q, r, s_, sh, lsi, mask)
+        out.backward(go)
+        res[fused] = [out.detach(), q.grad, s_.grad, r.grad] + [p.grad.clone() for p in mod.parameters()]
+    for x, y in zip(res[True], res[False]):
+        assert rel_err(x.cpu().numpy(), y.cpu().numpy()) < 5e-5, (M, L, P, shapes, N, Lq, width)
