@@ -104,3 +104,25 @@ def test_bracket_linear_masked_equals_linear_then_masked_fill():
     assert rel_err(got[2].cpu().numpy(), lin.bias.grad.cpu().numpy()) < 2e-6
     with torch.no_grad():                                              # preconditions not met -> the reference composition
         assert torch.equal(bracket_linear_masked(x, lin, mask), y_ref)
+
+
+def _random_wgrad_shapes(count, seed):
+    rng = np.random.RandomState(seed)
+    return [(int(rng.choice([1, 2, 31, 64, 65, 257, 1000, 4097, 9000])), 4 * int(rng.randint(1, 100)), 4 * int(rng.randint(1, 100)),
+             float(rng.choice([0.0, 0.0, 0.2, 1.0]))) for _ in range(count)]
+
+
+@pytest.mark.parametrize("M,N,K,frac", _random_wgrad_shapes(20, 5))
+def test_wgrad_random_shapes(M, N, K, frac):
+    """Random row counts (1 ... 9000: one stage, ragged chunks, many splits) and feature counts (multiples of 4, ragged
+    64-wide tiles), with and without a row mask, against fp64."""
+    from uvhand_amd import _native
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    dy, x = torch.randn(M, N, generator=g).cuda(), torch.randn(M, K, generator=g).cuda()
+    mask = (torch.rand(M, generator=g) < frac).cuda() if frac > 0 else None
+    gw, gb = _native.linear_wgrad(dy, x, row_mask=mask)
+    dym = dy if mask is None else dy.masked_fill(mask[:, None], 0.0)
+    ref_w, ref_b = (dym.double().t() @ x.double()).cpu().numpy(), dym.double().sum(0).cpu().numpy()
+    scale_w = max(1.0, float(np.abs(ref_w).max()))
+    assert np.abs(gw.cpu().numpy() - ref_w).max() < 3e-6 * scale_w * max(1.0, np.sqrt(M) / 8)
+    assert np.abs(gb.cpu().numpy() - ref_b).max() < 3e-6 * max(1.0, float(np.abs(ref_b).max())) * max(1.0, np.sqrt(M) / 8)
