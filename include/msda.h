@@ -46,6 +46,11 @@
  * Re-entrant: forward and backward may be called concurrently from different
  * host threads (the backward arrives on PyTorch's autograd thread).
  *
+ * Alignment: tensors obtained from an allocator always qualify.  The D = 32 kernels move rows as 16-byte
+ * (fp32) / 8-byte (bf16) vectors and (x, y) pairs as 8 bytes; an fp32 call whose tensors are only
+ * element-aligned (a contiguous view at an odd offset) is served by the generic kernels, the bf16,
+ * fused-prologue and weight-gradient entry points return MSDA_ERR_ARGUMENT for such pointers.
+ *
  * Errors: every function returns 0 on success, non-zero on failure, in which
  * case msda_last_error() describes it.  Unlike the reference, which only
  * printf()s a failed launch (im2col_cuda.cuh:948-952, 1321-1325), launch errors

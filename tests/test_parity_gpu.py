@@ -145,6 +145,35 @@ def test_random_geometries_match_c_oracle(native, oracle, idx, case):
         assert rel_err(gl[keep], r_gl[keep]) < 2e-5, case
 
 
+def _misaligned_copy(t):
+    """Same values, contiguous, but starting one element into its storage (4-byte aligned for fp32 only)."""
+    buf = torch.empty(t.numel() + 1, dtype=t.dtype, device=t.device)
+    view = buf[1:].view(t.shape)
+    view.copy_(t)
+    return view
+
+
+def test_contiguous_views_at_odd_offsets(native, oracle):
+    """Tensors that are contiguous but not 16-byte aligned (views one element into a buffer): fp32 calls are
+    served by the element-wise generic kernels with the same results; bf16 rows are refused loudly."""
+    z = make_case(21, *ORACLE_CASES["model_small"])
+    s, i = dev(z["shapes"]), dev(z["level_start"])
+    v, l, a, go = (_misaligned_copy(dev(z[k])) for k in ("value", "loc", "attn", "grad_out"))
+    assert v.data_ptr() % 16 != 0 and v.is_contiguous()
+    out = native.ms_deform_attn_forward(v, s, i, l, a, 64)
+    gv, gl, ga = native.ms_deform_attn_backward(v, s, i, l, a, go, 64)
+    args = [z["value"], z["shapes"], z["level_start"], z["loc"], z["attn"]]
+    r_gv, r_gl, r_ga = oracle.backward(z["grad_out"], *args)
+    assert rel_err(out.cpu().numpy(), oracle.forward(*args)) < 5e-6
+    assert rel_err(gv.cpu().numpy(), r_gv) < 2e-5 and rel_err(ga.cpu().numpy(), r_ga) < 2e-5
+    keep = ~near_boundary_mask(z, tol=1e-5)
+    assert rel_err(gl.cpu().numpy()[keep], r_gl[keep]) < 2e-5
+    v16 = _misaligned_copy(dev(z["value"]).to(torch.bfloat16))           # 2-byte aligned
+    with pytest.raises(RuntimeError, match="aligned"):
+        native.ms_deform_attn_forward(v16, s, i, dev(z["loc"]), dev(z["attn"]), 64)
+    assert not native.linear_wgrad_supported(_misaligned_copy(torch.zeros(8, 8, device="cuda")), torch.zeros(8, 8, device="cuda"))
+
+
 def _random_generic_geometries(count, seed):
     rng = np.random.RandomState(seed)
     cases = []

@@ -235,7 +235,8 @@ def linear_wgrad_supported(grad_out, inp):
     return (grad_out.is_cuda and inp.is_cuda and grad_out.dtype == torch.float32 and inp.dtype == torch.float32
             and grad_out.dim() == 2 and inp.dim() == 2 and grad_out.shape[0] == inp.shape[0]
             and grad_out.is_contiguous() and inp.is_contiguous() and grad_out.device == inp.device
-            and grad_out.shape[1] % 4 == 0 and inp.shape[1] % 4 == 0 and inp.shape[0] < (1 << 30))
+            and grad_out.shape[1] % 4 == 0 and inp.shape[1] % 4 == 0 and inp.shape[0] < (1 << 30)
+            and grad_out.data_ptr() % 16 == 0 and inp.data_ptr() % 16 == 0)
 
 
 def _row_mask_ptr(row_mask, rows, device):
@@ -340,6 +341,8 @@ def ms_deform_attn_forward_prologue(value, spatial_shapes, level_start_index, re
             or tuple(reference_points.shape) != (N, Lq, L, 2) or tuple(spatial_shapes.shape) != (L, 2)):
         raise RuntimeError("ms_deform_attn_forward_prologue: inconsistent shapes")
     ld_off, ld_log = _row_stride(sampling_offsets, "sampling_offsets"), _row_stride(attn_logits, "attn_logits")
+    if reference_points.data_ptr() % 8:                      # a contiguous view at an odd element offset
+        reference_points = reference_points.clone()
     step = min(N, int(im2col_step))
     if N > 0 and (step <= 0 or N % step != 0):
         raise RuntimeError("batch(%d) must divide im2col_step(%d)" % (N, step))

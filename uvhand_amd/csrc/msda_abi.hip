@@ -55,6 +55,19 @@ static int check_row_strides(const char *who, int M, int L, int P, const void *o
     return MSDA_OK;
 }
 
+// The D = 32 kernels move rows as 16-byte (fp32) / 8-byte (bf16) vectors and locations as (x, y) pairs.
+// Tensors straight from an allocator always qualify; a contiguous VIEW at an odd element offset does not —
+// fp32 calls then take the generic kernels (element-wise accesses), the others are refused.
+static bool aligned_to(const void *p, size_t bytes) { return ((uintptr_t)p & (bytes - 1)) == 0; }
+
+static int refuse_unaligned(const char *who)
+{
+    char buf[200];
+    std::snprintf(buf, sizeof(buf), "%s: row tensors must be 16-byte (fp32) / 8-byte (bf16) aligned and (x, y) tensors "
+                  "8-byte aligned (a contiguous view at an odd element offset is not)", who);
+    return set_error(MSDA_ERR_ARGUMENT, buf);
+}
+
 static bool use_d32(int N, int S, int M, int D, int L, int Lq, int P)
 {
     const int f = g_force_path.load(std::memory_order_relaxed);
@@ -76,7 +89,8 @@ static int forward_impl(const T *value, const int64_t *shapes, const int64_t *le
         return e == hipSuccess ? MSDA_OK : set_error(MSDA_ERR_LAUNCH, hipGetErrorString(e));
     }
     if constexpr (sizeof(T) == 4) {
-        if (d32) return launch_fwd_d32(value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, out, stream);
+        if (d32 && aligned_to(value, 16) && aligned_to(out, 16) && aligned_to(loc, 8))
+            return launch_fwd_d32(value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, out, stream);
     }
     return launch_fwd_generic<T>(value, shapes, level_start, loc, attn, N, S, M, D, L, Lq, P, out, stream);
 }
@@ -102,8 +116,10 @@ static int backward_impl(const T *grad_out, const T *value, const int64_t *shape
         return e == hipSuccess ? MSDA_OK : set_error(MSDA_ERR_LAUNCH, hipGetErrorString(e));
     }
     if constexpr (sizeof(T) == 4) {
-        if (d32) return launch_bwd_d32(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P,
-                                       grad_value, grad_loc, grad_attn, stream);
+        if (d32 && aligned_to(grad_out, 16) && aligned_to(value, 16) && aligned_to(grad_value, 16) && aligned_to(loc, 8) &&
+            aligned_to(grad_loc, 8))
+            return launch_bwd_d32(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P,
+                                  grad_value, grad_loc, grad_attn, stream);
     }
     return launch_bwd_generic<T>(grad_out, value, shapes, level_start, loc, attn, N, S, M, D, L, Lq, P,
                                  grad_value, grad_loc, grad_attn, stream);
@@ -134,6 +150,9 @@ static int backward_bf16_impl(const uint16_t *grad_out, const uint16_t *value, c
     if (!msda::d32_supported(N, S, M, D, L, Lq, P))
         return msda::set_error(MSDA_ERR_ARGUMENT, "msda bf16: only the D=32 kernel family implements bf16 storage "
                                                   "(needs D == 32, L <= 16, L*P <= 32)");
+    if (!msda::aligned_to(grad_out, 8) || !msda::aligned_to(value, 8) || !msda::aligned_to(grad_value, sizeof(GT) * 4) ||
+        !msda::aligned_to(sampling_loc, 8) || !msda::aligned_to(grad_sampling_loc, 8))
+        return msda::refuse_unaligned("msda_backward_bf16");
     if constexpr (sizeof(GT) == 2)
         return msda::launch_bwd_d32_bf16(grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M,
                                          L, Lq, P, grad_value, grad_sampling_loc, grad_attn_weight, (hipStream_t)stream);
@@ -199,6 +218,8 @@ int msda_forward_bf16(const uint16_t *value, const int64_t *spatial_shapes, cons
     if (!msda::d32_supported(N, S, M, D, L, Lq, P))
         return msda::set_error(MSDA_ERR_ARGUMENT, "msda bf16: only the D=32 kernel family implements bf16 storage "
                                                   "(needs D == 32, L <= 16, L*P <= 32)");
+    if (!msda::aligned_to(value, 8) || !msda::aligned_to(out, 8) || !msda::aligned_to(sampling_loc, 8))
+        return msda::refuse_unaligned("msda_forward_bf16");
     return msda::launch_fwd_d32_bf16(value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M, L, Lq, P,
                                      out, (hipStream_t)stream);
 }
@@ -243,6 +264,9 @@ int msda_forward_prologue_f32(const float *value, const int64_t *spatial_shapes,
     if (!msda_prologue_supported(N, S, M, D, L, Lq, P))
         return msda::set_error(MSDA_ERR_ARGUMENT, "msda_forward_prologue_f32: geometry not supported (msda_prologue_supported)");
     if (int rc = msda::check_row_strides("msda_forward_prologue_f32", M, L, P, sampling_offsets, &ld_offsets, &ld_logits)) return rc;
+    if (!msda::aligned_to(value, 16) || !msda::aligned_to(out, 16) || !msda::aligned_to(reference_points, 8) ||
+        !msda::aligned_to(sampling_loc_out, 8))
+        return msda::refuse_unaligned("msda_forward_prologue_f32");
     msda::g_err[0] = 0;
     return msda::launch_fwd_prologue(value, spatial_shapes, level_start, reference_points, sampling_offsets, attn_logits, N,
                                      S, M, L, Lq, P, ld_offsets, ld_logits, out, sampling_loc_out, attn_weight_out,
@@ -262,6 +286,9 @@ int msda_backward_prologue_f32(const float *grad_out, const float *value, const 
         return msda::set_error(MSDA_ERR_ARGUMENT, "msda_backward_prologue_f32: geometry not supported (msda_prologue_supported)");
     if (int rc = msda::check_row_strides("msda_backward_prologue_f32", M, L, P, grad_sampling_offsets, &ld_grad_offsets,
                                          &ld_grad_logits)) return rc;
+    if (!msda::aligned_to(grad_out, 16) || !msda::aligned_to(value, 16) || !msda::aligned_to(grad_value, 16) ||
+        !msda::aligned_to(sampling_loc, 8) || !msda::aligned_to(grad_reference_points, 8))
+        return msda::refuse_unaligned("msda_backward_prologue_f32");
     msda::g_err[0] = 0;
     return msda::launch_bwd_prologue(grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M, L,
                                      Lq, P, grad_value, ld_grad_offsets, ld_grad_logits, grad_sampling_offsets,
@@ -287,6 +314,8 @@ int msda_linear_wgrad_masked_f32(const float *grad_out, const float *input, cons
         return msda::set_error(MSDA_ERR_ARGUMENT, "msda_linear_wgrad_f32: need N, K > 0 and multiples of 4");
     if (grad_weight == nullptr || (M > 0 && (grad_out == nullptr || input == nullptr)))
         return msda::set_error(MSDA_ERR_ARGUMENT, "msda_linear_wgrad_f32: null device pointer");
+    if (!msda::aligned_to(grad_out, 16) || !msda::aligned_to(input, 16) || !msda::aligned_to(workspace, 16))
+        return msda::set_error(MSDA_ERR_ARGUMENT, "msda_linear_wgrad_f32: grad_out, input and workspace must be 16-byte aligned");
     msda::g_err[0] = 0;
     if (M == 0) {
         hipError_t e = hipMemsetAsync(grad_weight, 0, sizeof(float) * (size_t)N * K, (hipStream_t)stream);
