@@ -13,7 +13,11 @@ exchange), so the scaling is weak and there is no data-path coll
 `value` = samples all ranks processed / max-over-ranks time.
 
 The step is captured once into a HIP graph (two kernel launches + no host work per
-replay) and replayed K times; --no-graph times the eager autograd path instead.
+replay) and replayed K times; --no-graph times the eager autograd path instead.  The K-step
+block (barrier + synchronize on both sides, max over ranks) is repeated --repeats times and the
+MEDIAN block is reported, so a short driver run (--steps 20 = 0.4 ms) is not a single sample;
+the same line also carries `eager_ms_per_step` (plain autograd calls, what a drop-in user of the
+module runs) and `graph1_ms_per_step` (one graph launch per step) next to the headline.
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra
 objects: `roofline` (dominant kernel = backward; algorithmic bytes / HIP-event time
 against the 8 TB/s HBM peak) and `cpu_baseline` (the PyTorch-CPU fallback port timed
@@ -198,6 +202,8 @@ def main():
                     help="steps captured per HIP graph (the timed loop replays it steps/graph-steps times; "
                          "reduced to a divisor of --steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--repeats", type=int, default=50,
+                    help="repetitions of the timed --steps block (each bracketed by barrier + synchronize); the median is reported")
     ap.add_argument("--kernel-iters", type=int, default=200)
     ap.add_argument("--locations", default="uniform", choices=["uniform", "model"],
                     help="sampling-location distribution: uniform in [0,1) (headline) or model-like (SURVEY §8d B)")
@@ -264,14 +270,36 @@ def main():
         def barrier():
             harness.barrier(device)
 
+        def timed_block(call, calls):
+            """EXACTLY `calls` invocations bracketed by barrier + synchronize on both sides (seconds, this rank)."""
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(calls):
+                call()
+            barrier()
+            return time.perf_counter() - t0
+
         for _ in range((args.warmup + per_graph - 1) // per_graph):
             run()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps // per_graph):
-            run()
-        barrier()
-        elapsed = time.perf_counter() - t0
+        blocks = [timed_block(run, args.steps // per_graph) for _ in range(max(1, args.repeats))]
+
+        # the other two launch modes of the same step, for the record (not `value`)
+        side = {}
+        if graph is not None and world == 1:
+            for _ in range(min(args.warmup, 20)):
+                step()
+            n_eager = min(args.steps, 200)
+            side["eager_ms_per_step"] = 1e3 * sorted(timed_block(step, n_eager) for _ in range(5))[2] / n_eager
+            try:
+                g1 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1, stream=stream):
+                    step()
+                for _ in range(10):
+                    g1.replay()
+                n_g1 = min(args.steps, 200)
+                side["graph1_ms_per_step"] = 1e3 * sorted(timed_block(g1.replay, n_g1) for _ in range(5))[2] / n_g1
+            except Exception as exc:
+                print("bench: single-step graph failed (%s)" % exc, file=sys.stderr)
 
         # ---- per-kernel timing for the roofline (HIP events on the launch stream) ----
         vd, ld, ad = value.detach(), loc.detach(), attn.detach()
@@ -300,7 +328,16 @@ def main():
         stream.synchronize()
 
     total_samples = harness.sum_over_ranks(N * args.steps, device)
-    elapsed = harness.max_over_ranks(elapsed, device)
+    # every block: the slowest rank's time (what the whole job waited for); then the median block
+    block_max = sorted(harness.max_over_ranks(t, device) for t in blocks)
+    elapsed = block_max[len(block_max) // 2]
+    ranks_seen = harness.gather_objects({"rank": rank, "local_rank": local_rank, "device": "cuda:%d" % dev_index,
+                                         "device_name": torch.cuda.get_device_name(dev_index), "pid": os.getpid(),
+                                         "seed": harness.rank_seed(1000, rank), "samples": N * args.steps,
+                                         "median_block_s": sorted(blocks)[len(blocks) // 2]})
+    print("bench: rank %d/%d backend=%s device=cuda:%d (%s) pid=%d" % (rank, world, backend if world > 1 else "none",
+                                                                    dev_index, torch.cuda.get_device_name(dev_index), os.getpid()),
+          file=sys.stderr, flush=True)
 
     if rank == 0:
         fwd_b, bwd_b = algorithmic_bytes(N, S, M, D, L, Lq, P, e=esize)
@@ -320,7 +357,13 @@ def main():
                        "step": "MSDeformAttnFunction.apply forward + backward (3 grads)",
                        "launch": ("hipGraph replay, %d step(s) per graph" % per_graph) if graph is not None
                                  else "eager autograd",
-                       "sharding": "batch-sharded, no collective"},
+                       "sharding": "batch-sharded, no collective",
+                       "timing": "median of %d blocks of %d steps, each bracketed by barrier + synchronize; max over ranks "
+                                 "per block (min %.4f / max %.4f ms per step)" % (len(block_max), args.steps,
+                                                                                  1e3 * block_max[0] / args.steps,
+                                                                                  1e3 * block_max[-1] / args.steps),
+                       "backend": backend if world > 1 else None},
+            "ranks": ranks_seen,
             "roofline": {"bound": "hbm", "kernel": "backward: msda::bwd_fused_d32_kernel (grad_value sort+gather "
                                                     "workgroups and grad_loc/grad_attn workgroups in one launch)",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
@@ -329,6 +372,7 @@ def main():
                                 "GBps": fwd_b / (kt["fwd"] * 1e-3) / 1e9},
                         "bwd": {"ms": kt["bwd"], "algorithmic_bytes": bwd_b, "GBps": ach}},
         }
+        result.update(side)
         if world == 1:
             result["roofline"]["copy_GBps_measured"] = copy_bandwidth_gbs(device)
         if world == 1 and not args.no_cpu_baseline:

@@ -39,8 +39,9 @@
  * caller does NOT need to zero out / grad_* beforehand (the reference zero-fills
  * them on the host side, ms_deform_attn_cuda.cu:54,121-123).
  *
- * Ownership: the library allocates nothing and frees nothing and keeps no global
- * mutable state except a thread-local error string.  It never synchronises the
+ * Ownership: the library allocates nothing and frees nothing, reads no environment
+ * variable, and keeps no global mutable state except a thread-local error string
+ * and the test hook msda_force_path().  It never synchronises the
  * device: all work (including the zero-fill of grad_value where a kernel needs
  * it) is enqueued on `stream` (a hipStream_t; NULL = the default stream).
  * Re-entrant: forward and backward may be called concurrently from different
@@ -123,6 +124,42 @@ int msda_backward_bf16_gv32(const uint16_t *grad_out, const uint16_t *value, con
                             msda_stream_t stream);
 int msda_backward_passes(int Lq, int P);
 
+/* ---- Backward with flags and caller-provided scratch (D = 32 family) -----------------------------------
+ * flags = 0: exactly msda_backward_*.
+ * flags & MSDA_FLAG_DETERMINISTIC: grad_value is bitwise reproducible run to run (grad_sampling_loc and
+ * grad_attn_weight always are).  The default kernels order the contributions to a pixel by the rank an LDS
+ * integer atomic returned, the reference by the arrival of its atomicAdds (ms_deform_im2col_cuda.cuh:125-152);
+ * both differ in the last bits between runs.  The deterministic kernels sort whole sampling POINTS by bilinear
+ * cell with a stable counting sort, read each grad_out row once per point, and add the four corner sums of a
+ * cell into an fp32 tile image in LDS, cells of one colour (row parity, column parity) at a time — no two
+ * cells of a colour share a pixel, so no atomics and a fixed summation order (uvhand_amd/csrc/msda_d32_cell.h).
+ * With many sampling points per level and few (batch, head) pairs they also cut a level's queries into
+ * chunks whose partial images go through `workspace` (fp32 slabs) and a fixed-order reduction:
+ * msda_backward_workspace_bytes() says how much scratch such a call can use (0 = none); the caller passes a
+ * 16-byte aligned device buffer of that size (stream-ordered, e.g. torch.empty).  workspace = NULL is
+ * always accepted (same result per tile, less parallelism).  The library still allocates nothing.
+ * Shapes that are inconsistent with S (a level whose pixels do not lie in [0, S)) never cause an
+ * out-of-range access on this path: such a level contributes nothing and pixels no level covers get zeros.
+ * It costs 1.5-3x the default backward (profiles/r02_notes.md).  Replaces the same reference functions as
+ * msda_backward_*. */
+#define MSDA_FLAG_DETERMINISTIC 1u
+unsigned long long msda_backward_workspace_bytes(int N, int S, int M, int D, int L, int Lq, int P, unsigned flags);
+int msda_backward_ws_f32(const float *grad_out, const float *value, const int64_t *spatial_shapes,
+                         const int64_t *level_start, const float *sampling_loc, const float *attn_weight,
+                         int N, int S, int M, int D, int L, int Lq, int P,
+                         float *grad_value, float *grad_sampling_loc, float *grad_attn_weight,
+                         void *workspace, unsigned long long workspace_bytes, unsigned flags, msda_stream_t stream);
+int msda_backward_ws_bf16(const uint16_t *grad_out, const uint16_t *value, const int64_t *spatial_shapes,
+                          const int64_t *level_start, const float *sampling_loc, const float *attn_weight,
+                          int N, int S, int M, int D, int L, int Lq, int P,
+                          uint16_t *grad_value, float *grad_sampling_loc, float *grad_attn_weight,
+                          void *workspace, unsigned long long workspace_bytes, unsigned flags, msda_stream_t stream);
+int msda_backward_ws_bf16_gv32(const uint16_t *grad_out, const uint16_t *value, const int64_t *spatial_shapes,
+                               const int64_t *level_start, const float *sampling_loc, const float *attn_weight,
+                               int N, int S, int M, int D, int L, int Lq, int P,
+                               float *grad_value, float *grad_sampling_loc, float *grad_attn_weight,
+                               void *workspace, unsigned long long workspace_bytes, unsigned flags, msda_stream_t stream);
+
 /* ---- Fused module prologue (fp32, D = 32 family) ---------------------------------
  * The module computes  attn = softmax(logits) over the L*P points of a (query, head)  and
  * sampling_loc = reference_point + offset / (W_l, H_l)  (models/ops/modules/ms_deform_attn.py:101-108,
@@ -151,6 +188,13 @@ int msda_backward_prologue_f32(const float *grad_out, const float *value, const 
                                int N, int S, int M, int D, int L, int Lq, int P, long long ld_grad_offsets,
                                long long ld_grad_logits, float *grad_value, float *grad_sampling_offsets,
                                float *grad_attn_logits, float *grad_reference_points, msda_stream_t stream);
+/* same with flags / scratch (MSDA_FLAG_DETERMINISTIC, msda_backward_workspace_bytes) */
+int msda_backward_prologue_ws_f32(const float *grad_out, const float *value, const int64_t *spatial_shapes,
+                                  const int64_t *level_start, const float *sampling_loc, const float *attn_weight,
+                                  int N, int S, int M, int D, int L, int Lq, int P, long long ld_grad_offsets,
+                                  long long ld_grad_logits, float *grad_value, float *grad_sampling_offsets,
+                                  float *grad_attn_logits, float *grad_reference_points, void *workspace,
+                                  unsigned long long workspace_bytes, unsigned flags, msda_stream_t stream);
 
 /* ---- Bracketing projections ----------------------------------------------------
  * Weight and bias gradient of an fp32 nn.Linear  y[M,N] = x[M,K] . W[N,K]^T + b[N]:

@@ -1,0 +1,158 @@
+"""The deterministic backward (MSDA_FLAG_DETERMINISTIC, include/msda.h; uvhand_amd/csrc/msda_d32_cell.h): parity with
+the C oracle on the same seeded geometries as the default kernels, bitwise reproducibility run to run — which the
+reference's atomicAdd scatter (ms_deform_im2col_cuda.cuh:125-152) and the default kernels do not have — with and
+without the query-chunk workspace, for fp32 and bf16 rows and through the fused-prologue entry point, and memory
+safety on shapes that are inconsistent with S."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import near_boundary_mask, rel_err
+from test_parity_gpu import ORACLE_CASES, _random_geometries, dev, make_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def native():
+    from uvhand_amd import _native
+    _native.load()
+    return _native
+
+
+def _backward(native, z, deterministic=True, dtype=torch.float32):
+    t = {k: dev(z[k], dtype) for k in ("value", "loc", "attn", "grad_out")}
+    gv, gl, ga = native.ms_deform_attn_backward(t["value"], dev(z["shapes"]), dev(z["level_start"]), t["loc"], t["attn"],
+                                                t["grad_out"], 64, deterministic=deterministic)
+    torch.cuda.synchronize()
+    return gv, gl, ga
+
+
+def _check(z, got, oracle, tol=2e-5):
+    gv, gl, ga = (t.float().cpu().numpy() for t in got)
+    args = [z["value"], z["shapes"], z["level_start"], z["loc"], z["attn"]]
+    r_gv, r_gl, r_ga = oracle.backward(z["grad_out"], *args)
+    assert rel_err(gv, r_gv) < tol
+    assert rel_err(ga, r_ga) < 2e-5
+    keep = ~near_boundary_mask(z, tol=1e-5)
+    if keep.any():
+        assert rel_err(gl[keep], r_gl[keep]) < 2e-5
+
+
+D32_CASES = [k for k, c in ORACLE_CASES.items() if c[3] == 32]
+EXTRA = {
+    # the geometries round 1's review singled out: many (batch, head, level) triples on one large level, and a long one
+    "one_big_level": (32, [(40, 48)], 8, 32, 384, 4),
+    "long_level":    (2, [(300, 3), (1, 200)], 4, 32, 77, 2),                  # tiles of 85 x 3 and 1 x 16 pixels
+    "encoder_like":  (1, [(20, 20), (10, 10), (5, 5)], 8, 32, 525, 4),          # Lq*P > one batch per tile
+    "chunked":       (1, [(16, 16), (8, 8)], 2, 32, 4000, 4),                   # few pairs, many points: query chunks + slabs
+}
+
+
+@pytest.mark.parametrize("name", D32_CASES + list(EXTRA))
+def test_deterministic_matches_c_oracle(native, oracle, name):
+    z = make_case(3, *(ORACLE_CASES[name] if name in ORACLE_CASES else EXTRA[name]))
+    _check(z, _backward(native, z), oracle)
+
+
+@pytest.mark.parametrize("idx,case", list(enumerate(_random_geometries(24, 777))))
+def test_deterministic_random_geometries(native, oracle, idx, case):
+    z = make_case(500 + idx, *case)
+    _check(z, _backward(native, z), oracle)
+
+
+def test_chunked_path_uses_the_workspace_and_agrees_without_it(native, oracle):
+    case = EXTRA["chunked"]
+    N, shapes, M, D, Lq, P = case
+    S = sum(h * w for h, w in shapes)
+    lib = native.load()
+    assert lib.msda_backward_workspace_bytes(N, S, M, D, len(shapes), Lq, P, native.FLAG_DETERMINISTIC) > 0
+    assert lib.msda_backward_workspace_bytes(N, S, M, D, len(shapes), Lq, P, 0) == 0
+    assert lib.msda_backward_workspace_bytes(2, 3060, 8, 32, 4, 300, 4, native.FLAG_DETERMINISTIC) == 0   # decoder: no chunks
+    z = make_case(9, *case)
+    with_ws = _backward(native, z)
+    _check(z, with_ws, oracle)
+    # same call with workspace = NULL: one workgroup per (level, tile), no slabs
+    import ctypes
+    t = {k: dev(z[k]) for k in ("value", "loc", "attn", "grad_out")}
+    sh, ls = dev(z["shapes"]), dev(z["level_start"])
+    gv, gl, ga = torch.empty_like(t["value"]), torch.empty_like(t["loc"]), torch.empty_like(t["attn"])
+    fn = lib.msda_backward_ws_f32
+    fn.argtypes = native._BWD_WS_ARGTYPES
+    fn.restype = ctypes.c_int
+    rc = fn(t["grad_out"].data_ptr(), t["value"].data_ptr(), sh.data_ptr(), ls.data_ptr(), t["loc"].data_ptr(),
+            t["attn"].data_ptr(), N, S, M, D, len(shapes), Lq, P, gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), None, 0,
+            native.FLAG_DETERMINISTIC, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    _check(z, (gv, gl, ga), oracle)
+    assert torch.equal(gl, with_ws[1]) and torch.equal(ga, with_ws[2])
+    assert rel_err(gv.cpu().numpy(), with_ws[0].cpu().numpy()) < 1e-5        # chunk partial sums: another association
+
+
+@pytest.mark.parametrize("name,spread", [("cfg2_decoder", None), ("pile_up", 0.02), ("chunked", None)])
+def test_grad_value_is_bitwise_reproducible(native, name, spread):
+    if name == "chunked":
+        z = make_case(5, *EXTRA["chunked"])
+    else:
+        z = make_case(11, 2, [(48, 48), (24, 24), (12, 12), (6, 6)], 8, 32, 300, 4)
+        if spread is not None:
+            g = torch.Generator().manual_seed(12)
+            z["loc"] = (torch.tensor([0.37, 0.61]) + (torch.rand(z["loc"].shape, generator=g) - 0.5) * spread).numpy().astype(np.float32)
+    first = _backward(native, z)
+    # other work in between perturbs the timing of the workgroups
+    noise = torch.randn(1 << 20, device="cuda")
+    for i in range(10):
+        if i % 3 == 0:
+            noise = noise * 1.0001 + 1.0
+        again = _backward(native, z)
+        for a, b in zip(first, again):
+            assert torch.equal(a, b), "run %d differs" % i
+
+
+def test_deterministic_bf16_rows(native, oracle):
+    z = make_case(4, *ORACLE_CASES["many_queries"])
+    for k in ("value", "grad_out"):
+        z[k] = torch.from_numpy(z[k]).to(torch.bfloat16).float().numpy()
+    t = {k: dev(z[k]) for k in ("value", "loc", "attn", "grad_out")}
+    args = (t["value"].to(torch.bfloat16), dev(z["shapes"]), dev(z["level_start"]), t["loc"], t["attn"],
+            t["grad_out"].to(torch.bfloat16), 64)
+    for fp32_gv, tol in ((False, 4e-3), (True, 2e-5)):
+        got = native.ms_deform_attn_backward(*args, fp32_grad_value=fp32_gv, deterministic=True)
+        assert got[0].dtype == (torch.float32 if fp32_gv else torch.bfloat16)
+        _check(z, got, oracle, tol=tol)
+        again = native.ms_deform_attn_backward(*args, fp32_grad_value=fp32_gv, deterministic=True)
+        assert all(torch.equal(a, b) for a, b in zip(got, again))
+
+
+def test_function_and_module_follow_torch_deterministic_switch(native, oracle):
+    from uvhand_amd.functions import MSDeformAttnFunction
+    z = make_case(21, *ORACLE_CASES["model_small"])
+    grads = []
+    prev = torch.are_deterministic_algorithms_enabled()
+    try:
+        torch.use_deterministic_algorithms(True, warn_only=True)
+        assert native.deterministic_requested()
+        for _ in range(3):
+            v, l, a = (dev(z[k]).requires_grad_(True) for k in ("value", "loc", "attn"))
+            MSDeformAttnFunction.apply(v, dev(z["shapes"]), dev(z["level_start"]), l, a, 64).backward(dev(z["grad_out"]))
+            grads.append(v.grad.clone())
+    finally:
+        torch.use_deterministic_algorithms(prev)
+    assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
+    _check(z, (grads[0], l.grad, a.grad), oracle)
+
+
+def test_inconsistent_shapes_are_memory_safe(native):
+    """A level that does not fit in S contributes nothing, pixels no level covers get zeros, nothing faults."""
+    z = make_case(2, 1, [(6, 6), (3, 3)], 8, 32, 40, 4)
+    S = z["value"].shape[1]
+    bad = dict(z)
+    bad["level_start"] = np.asarray([0, S - 4], dtype=np.int64)               # second level would run past S
+    gv, gl, ga = _backward(native, bad)
+    assert torch.isfinite(gv).all() and torch.isfinite(gl).all() and torch.isfinite(ga).all()
+    assert torch.count_nonzero(gv[:, 36:]) == 0                                # rows of the dropped level: zeros
+    short = dict(z)
+    short["shapes"] = np.asarray([(6, 6), (2, 2)], dtype=np.int64)             # covers S - 5 pixels only
+    gv2, _, _ = _backward(native, short)
+    assert torch.count_nonzero(gv2[:, 40:]) == 0

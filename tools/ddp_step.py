@@ -155,12 +155,22 @@ def main():
     elapsed = harness.max_over_ranks(time.perf_counter() - t0, device)
     total = harness.sum_over_ranks(args.window * args.steps, device)
     finite = bool(torch.isfinite(loss.detach()).item())
+    # after the optimizer steps every rank must hold bit-identical parameters: that is what DDP's bucketed
+    # all-reduce around the op's stream-ordered backward guarantees when it really ran (main.py:96-98)
+    with torch.no_grad():
+        flat = torch.cat([p.detach().reshape(-1).float() for p in model.parameters()])
+        digest = [float(flat.double().sum().item()), float(flat.double().abs().sum().item()),
+                  int(flat.view(torch.int32).long().sum().item())]
+    digests = harness.gather_objects({"rank": rank, "device": "cuda:%d" % dev_index, "pid": os.getpid(),
+                                      "loss": float(loss.detach().item()), "params": digest})
+    in_sync = all(d["params"] == digests[0]["params"] for d in digests)
     if rank == 0:
         print(json.dumps({"harness": "ddp_step", "n_gpus": world, "frames_per_s": total / elapsed,
                           "ms_per_step": 1e3 * elapsed / args.steps, "steps": args.steps,
                           "per_rank": {"window": args.window, "S": S, "queries": args.queries, "enc": args.enc,
                                        "dec": args.dec, "ballast_mb": args.ballast_mb, "amp": args.amp or None},
-                          "backend": backend if distributed else None, "loss_finite": finite}))
+                          "backend": backend if distributed else None, "loss_finite": finite,
+                          "params_in_sync": in_sync, "ranks": digests}))
     if distributed:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

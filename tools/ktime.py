@@ -6,6 +6,8 @@ sys.path.insert(0, ROOT)
 import torch
 from bench import make_inputs, algorithmic_bytes, WORKLOADS
 from uvhand_amd import _native
+if any(k.startswith("MSDA_") for k in os.environ):          # A/B knobs live in the diagnostic build only
+    _native.LIB_PATH = os.path.join(ROOT, "uvhand_amd", "libmsda_hip_tuning.so")
 
 def main():
     names = sys.argv[1:] or list(WORKLOADS)
@@ -15,7 +17,8 @@ def main():
         _, d, dims = make_inputs(name, 1000, dev, os.environ.get("KTIME_LOCATIONS", "uniform"))
         fb, bb = algorithmic_bytes(*dims)
         fns = {"fwd": lambda: _native.ms_deform_attn_forward(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], 64),
-               "bwd": lambda: _native.ms_deform_attn_backward(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], d["go"], 64)}
+               "bwd": lambda: _native.ms_deform_attn_backward(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], d["go"], 64,
+                                                              deterministic=os.environ.get("KTIME_DETERMINISTIC", "0") != "0")}
         out = []
         with torch.cuda.stream(st):
             for k, fn in fns.items():

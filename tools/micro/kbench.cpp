@@ -62,6 +62,22 @@ int main(int argc, char **argv)
     unsigned long long *nul = nullptr; CK(hipMemcpyToSymbol(HIP_SYMBOL(msda::msda_stamp_buf), &nul, sizeof(nul)));
     std::vector<unsigned long long> hsb(total);
     CK(hipMemcpy(hsb.data(), sb, total * 8, hipMemcpyDeviceToHost));
+    if (!getenv("MSDA_BWD_MODE") && !(getenv("MSDA_BWD_CELL") && atoi(getenv("MSDA_BWD_CELL")) == 0)) {
+        // cell-sorted role B (msda_d32_cell.h): per-workgroup phase totals
+        double sum[6] = {0, 0, 0, 0, 0, 0}, mx = 0; size_t nb = 0; unsigned long long tmin = ~0ull, tmax = 0, kept = 0, batches = 0;
+        for (size_t b = 0; b < 65536; ++b) {
+            const unsigned long long *t = &hsb[b * 8];
+            if (!t[0] || !t[1]) continue;
+            ++nb; tmin = std::min(tmin, t[0]); tmax = std::max(tmax, t[1]);
+            const double life = (double)(t[1] - t[0]) * 0.01;
+            sum[0] += life; mx = std::max(mx, life);
+            for (int k = 2; k < 6; ++k) sum[k - 1] += (double)t[k] * 0.01;
+            batches += t[6]; kept += t[7];
+        }
+        if (nb) printf("cell role B: %zu workgroups with items, span %.2f us; per workgroup: last item %.2f us (max %.2f), scan %.2f sort %.2f gather %.2f "
+                       "flush %.2f us; batches %.2f, kept points %.1f\n", nb, (double)(tmax - tmin) * 0.01, sum[0] / nb, mx, sum[1] / nb, sum[2] / nb,
+                       sum[3] / nb, sum[4] / nb, (double)batches / nb, (double)kept / nb);
+    }
     struct Reg { const char *name; int nph; const char *ph[5]; };
     const Reg regs[3] = {{"grad_value kernel (role B)", 5, {"loads+zero", "histogram", "prefix sum", "scatter", "gather"}},
                          {"query kernel (role A)", 3, {"prepass", "taps+dots", "write-out", "", ""}},
@@ -70,6 +86,7 @@ int main(int argc, char **argv)
         unsigned long long tmin = ~0ull, tmax = 0, smax = 0; size_t nb = 0;
         double ph[5] = {0, 0, 0, 0, 0}, phmax[5] = {0, 0, 0, 0, 0};
         const int last = regs[rg].nph;
+        if (rg == 0 && !getenv("MSDA_BWD_MODE") && !(getenv("MSDA_BWD_CELL") && atoi(getenv("MSDA_BWD_CELL")) == 0)) continue;
         for (size_t b = 0; b < 65536; ++b) {
             const unsigned long long *t = &hsb[rg * region + b * 8];
             if (!t[0] || !t[last]) continue;

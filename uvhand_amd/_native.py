@@ -23,6 +23,8 @@ _lib = None
 _SYMBOLS = (
     "msda_forward_f32", "msda_backward_f32", "msda_forward_f64", "msda_backward_f64",
     "msda_forward_bf16", "msda_backward_bf16", "msda_backward_bf16_gv32", "msda_backward_passes",
+    "msda_backward_workspace_bytes", "msda_backward_ws_f32", "msda_backward_ws_bf16", "msda_backward_ws_bf16_gv32",
+    "msda_backward_prologue_ws_f32",
     "msda_linear_wgrad_f32", "msda_linear_wgrad_masked_f32", "msda_linear_wgrad_workspace_bytes",
     "msda_zero_masked_rows_f32",
     "msda_prologue_supported", "msda_forward_prologue_f32", "msda_backward_prologue_f32",
@@ -49,6 +51,8 @@ def load():
     lib.msda_force_path.restype = None
     lib.msda_prologue_supported.restype = ctypes.c_int
     lib.msda_prologue_supported.argtypes = [ctypes.c_int] * 7
+    lib.msda_backward_workspace_bytes.restype = ctypes.c_ulonglong
+    lib.msda_backward_workspace_bytes.argtypes = [ctypes.c_int] * 7 + [ctypes.c_uint]
     lib.msda_linear_wgrad_workspace_bytes.restype = ctypes.c_ulonglong
     lib.msda_linear_wgrad_workspace_bytes.argtypes = [ctypes.c_int] * 3
     _lib = lib
@@ -131,6 +135,15 @@ def _raise(lib, rc, what):
 _VP, _CI = ctypes.c_void_p, ctypes.c_int
 _FWD_ARGTYPES = [_VP] * 5 + [_CI] * 7 + [_VP, _VP]
 _BWD_ARGTYPES = [_VP] * 6 + [_CI] * 7 + [_VP] * 4
+_BWD_WS_ARGTYPES = [_VP] * 6 + [_CI] * 7 + [_VP] * 4 + [ctypes.c_ulonglong, ctypes.c_uint, _VP]
+FLAG_DETERMINISTIC = 1                                # MSDA_FLAG_DETERMINISTIC (include/msda.h)
+
+
+def deterministic_requested():
+    """True when grad_value should be bitwise reproducible: torch.use_deterministic_algorithms(True) (the reference
+    sets cudnn.deterministic, main.py:65-66, which does not cover its atomicAdd scatter) or MSDA_DETERMINISTIC=1."""
+    return torch.are_deterministic_algorithms_enabled() or os.environ.get("MSDA_DETERMINISTIC", "0") not in ("", "0")
+
 _entry_cache = {}
 
 
@@ -192,16 +205,27 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     return out
 
 
+def _backward_workspace(lib, N, S, M, D, L, Lq, P, device):
+    """Scratch for the deterministic grad_value path (msda_backward_workspace_bytes, include/msda.h): a stream-ordered
+    torch buffer, or (None, 0) when the call needs none.  The caller keeps it alive until the launch is queued;
+    the caching allocator only hands the block out again to work queued later on the same stream."""
+    nbytes = int(lib.msda_backward_workspace_bytes(N, S, M, D, L, Lq, P, FLAG_DETERMINISTIC))
+    if nbytes == 0:
+        return None, 0
+    return torch.empty((nbytes,), dtype=torch.uint8, device=device), nbytes
+
+
 def backward_passes(Lq, P):
     """Query chunks the D = 32 backward takes for Lq*P sampling points per (batch, head, level); 1 = single pass."""
     return int((_lib or load()).msda_backward_passes(ctypes.c_int(Lq), ctypes.c_int(P)))
 
 
 def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output,
-                            im2col_step, fp32_grad_value=False):
+                            im2col_step, fp32_grad_value=False, deterministic=None):
     """Replaces MSDA.ms_deform_attn_backward (vision.cpp:15).
     Returns (grad_value, grad_sampling_loc, grad_attn_weight).  fp32_grad_value (bf16 rows only): grad_value
-    comes back in float32 (msda_backward_bf16_gv32, include/msda.h)."""
+    comes back in float32 (msda_backward_bf16_gv32, include/msda.h).  deterministic (None = deterministic_requested()):
+    bitwise reproducible grad_value (MSDA_FLAG_DETERMINISTIC; D = 32 kernel family, fp32 / bf16 rows)."""
     lib = _lib or load()
     _check_inputs((("value", value), ("spatial_shapes", spatial_shapes),
                    ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
@@ -217,10 +241,19 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
         grad_value = torch.empty_like(value, dtype=torch.float32) if fp32_grad_value else torch.empty_like(value)
         grad_loc = torch.empty_like(sampling_loc)
         grad_attn = torch.empty_like(attn_weight)
-        rc = _entry(lib, "msda_backward_" + suf + ("_gv32" if fp32_grad_value else ""), _BWD_ARGTYPES)(
-            grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
-            sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P,
-            grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(), _raw_stream(value.device))
+        det = deterministic_requested() if deterministic is None else bool(deterministic)
+        if det and suf != "f64":
+            ws, nbytes = _backward_workspace(lib, N, S, M, D, L, Lq, P, value.device)
+            rc = _entry(lib, "msda_backward_ws_" + suf + ("_gv32" if fp32_grad_value else ""), _BWD_WS_ARGTYPES)(
+                grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P,
+                grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(),
+                ws.data_ptr() if ws is not None else None, nbytes, FLAG_DETERMINISTIC, _raw_stream(value.device))
+        else:
+            rc = _entry(lib, "msda_backward_" + suf + ("_gv32" if fp32_grad_value else ""), _BWD_ARGTYPES)(
+                grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P,
+                grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(), _raw_stream(value.device))
     if rc != 0:
         _raise(lib, rc, "ms_deform_attn_backward")
     return grad_value, grad_loc, grad_attn
@@ -324,6 +357,16 @@ def prologue_geometry_supported(N, S, M, D, L, Lq, P):
     return bool(lib.msda_prologue_supported(N, S, M, D, L, Lq, P))
 
 
+def _check_prologue_dtypes(spatial_shapes, level_start_index, **floats):
+    """The fused-prologue entry points exist for float32 only (include/msda.h); index tensors are int64."""
+    if spatial_shapes.dtype != torch.int64 or level_start_index.dtype != torch.int64:
+        raise RuntimeError("expected scalar type Long for spatial_shapes / level_start_index")
+    for name, t in floats.items():
+        if t.dtype != torch.float32:
+            raise RuntimeError("expected scalar type Float for %s but found %s"
+                               % (name, str(t.dtype).replace("torch.", "").capitalize()))
+
+
 def ms_deform_attn_forward_prologue(value, spatial_shapes, level_start_index, reference_points, sampling_offsets,
                                     attn_logits, im2col_step):
     """Fused-prologue forward (include/msda.h).  Returns (out, sampling_loc, attn_weight); the last two are
@@ -335,11 +378,16 @@ def ms_deform_attn_forward_prologue(value, spatial_shapes, level_start_index, re
     for name, t in (("sampling_offsets", sampling_offsets), ("attn_logits", attn_logits)):
         if not t.is_cuda or t.device != value.device:
             raise RuntimeError("%s must be a CUDA tensor on the device of value" % name)
+    if value.dim() != 4 or sampling_offsets.dim() != 6:
+        raise RuntimeError("ms_deform_attn_forward_prologue: expected value[N,S,M,D] and sampling_offsets[N,Lq,M,L,P,2]")
     N, S, M, D = value.shape
     Lq, L, P = sampling_offsets.shape[1], sampling_offsets.shape[3], sampling_offsets.shape[4]
     if (tuple(sampling_offsets.shape) != (N, Lq, M, L, P, 2) or tuple(attn_logits.shape) != (N, Lq, M, L * P)
-            or tuple(reference_points.shape) != (N, Lq, L, 2) or tuple(spatial_shapes.shape) != (L, 2)):
+            or tuple(reference_points.shape) != (N, Lq, L, 2) or tuple(spatial_shapes.shape) != (L, 2)
+            or tuple(level_start_index.shape) != (L,)):
         raise RuntimeError("ms_deform_attn_forward_prologue: inconsistent shapes")
+    _check_prologue_dtypes(spatial_shapes, level_start_index, value=value, reference_points=reference_points,
+                           sampling_offsets=sampling_offsets, attn_logits=attn_logits)
     ld_off, ld_log = _row_stride(sampling_offsets, "sampling_offsets"), _row_stride(attn_logits, "attn_logits")
     if reference_points.data_ptr() % 8:                      # a contiguous view at an odd element offset
         reference_points = reference_points.clone()
@@ -360,15 +408,19 @@ def ms_deform_attn_forward_prologue(value, spatial_shapes, level_start_index, re
 
 
 def ms_deform_attn_backward_prologue(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output,
-                                     merged=False):
+                                     merged=False, deterministic=None):
     """Returns (grad_value, grad_sampling_offsets, grad_attn_logits[N,Lq,M,L*P], grad_reference_points[N,Lq,L,2]).
     merged=True: the two raw gradients are the column blocks [0, 2*M*L*P) and [2*M*L*P, 3*M*L*P) of ONE
     [N, Lq, 3*M*L*P] tensor — the gradient of a merged offsets+logits projection — returned as a fifth value."""
     lib = _lib or load()
     _check_inputs((("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
                    ("sampling_loc", sampling_loc), ("attn_weight", attn_weight), ("grad_output", grad_output)))
-    N, S, M, D = value.shape
-    Lq, L, P = sampling_loc.shape[1], sampling_loc.shape[3], sampling_loc.shape[4]
+    # same checks as the plain backward (the kernels reinterpret device memory: a wrong dtype is silent garbage)
+    N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, max(1, value.shape[0]))
+    _check_prologue_dtypes(spatial_shapes, level_start_index, value=value, sampling_loc=sampling_loc,
+                           attn_weight=attn_weight, grad_output=grad_output)
+    if grad_output.numel() != N * Lq * M * D:
+        raise RuntimeError("ms_deform_attn_backward_prologue: grad_output must be float32[%d,%d,%d]" % (N, Lq, M * D))
     mlp = M * L * P
     with _DeviceGuard(value.device):
         gv = torch.empty_like(value)
@@ -382,10 +434,14 @@ def ms_deform_attn_backward_prologue(value, spatial_shapes, level_start_index, s
             glog = torch.empty((N, Lq, M, L * P), dtype=torch.float32, device=value.device)
             ld_off = ld_log = 0
         gref = torch.empty((N, Lq, L, 2), dtype=torch.float32, device=value.device)
-        rc = _entry(lib, "msda_backward_prologue_f32", [_VP] * 6 + [_CI] * 7 + [_LL] * 2 + [_VP] * 5)(
+        det = deterministic_requested() if deterministic is None else bool(deterministic)
+        ws, nbytes = _backward_workspace(lib, N, S, M, D, L, Lq, P, value.device) if det else (None, 0)
+        rc = _entry(lib, "msda_backward_prologue_ws_f32",
+                    [_VP] * 6 + [_CI] * 7 + [_LL] * 2 + [_VP] * 5 + [ctypes.c_ulonglong, ctypes.c_uint, _VP])(
             grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
             sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P, ld_off, ld_log, gv.data_ptr(),
-            goff.data_ptr(), glog.data_ptr(), gref.data_ptr(), _raw_stream(value.device))
+            goff.data_ptr(), glog.data_ptr(), gref.data_ptr(), ws.data_ptr() if ws is not None else None, nbytes,
+            FLAG_DETERMINISTIC if det else 0, _raw_stream(value.device))
     if rc != 0:
         _raise(lib, rc, "ms_deform_attn_backward_prologue")
     return (gv, goff, glog, gref, both) if merged else (gv, goff, glog, gref)

@@ -17,6 +17,14 @@ int set_error(int code, const char *msg)
     return code;
 }
 
+// Start of every entry point that enqueues work: forget this thread's previous message and any sticky
+// error an unrelated earlier HIP call left behind, so that check_launch() reports THIS call's launch only.
+static void begin_call()
+{
+    g_err[0] = 0;
+    (void)hipGetLastError();
+}
+
 int check_launch(const char *what)
 {
     const hipError_t e = hipGetLastError();
@@ -82,7 +90,7 @@ static int forward_impl(const T *value, const int64_t *shapes, const int64_t *le
 {
     const void *ptrs[] = {value, shapes, level_start, loc, attn, out};
     if (int rc = check_args(ptrs, 6, N, S, M, D, L, Lq, P)) return rc;
-    g_err[0] = 0;
+    begin_call();
     if (N == 0 || Lq == 0) return MSDA_OK;                          // empty output
     if (S == 0) {                                                   // no pixels: every tap is outside
         const hipError_t e = hipMemsetAsync(out, 0, sizeof(T) * (size_t)N * Lq * M * D, stream);
@@ -99,11 +107,11 @@ template <typename T>
 static int backward_impl(const T *grad_out, const T *value, const int64_t *shapes,
                          const int64_t *level_start, const T *loc, const T *attn, int N, int S, int M,
                          int D, int L, int Lq, int P, T *grad_value, T *grad_loc, T *grad_attn,
-                         hipStream_t stream, bool d32)
+                         hipStream_t stream, bool d32, void *workspace = nullptr, size_t ws_bytes = 0, unsigned flags = 0)
 {
     const void *ptrs[] = {grad_out, value, shapes, level_start, loc, attn, grad_value, grad_loc, grad_attn};
     if (int rc = check_args(ptrs, 9, N, S, M, D, L, Lq, P)) return rc;
-    g_err[0] = 0;
+    begin_call();
     if (N == 0) return MSDA_OK;
     if (Lq == 0 || S == 0) {                                        // no contributions at all
         hipError_t e = hipSuccess;
@@ -119,7 +127,8 @@ static int backward_impl(const T *grad_out, const T *value, const int64_t *shape
         if (d32 && aligned_to(grad_out, 16) && aligned_to(value, 16) && aligned_to(grad_value, 16) && aligned_to(loc, 8) &&
             aligned_to(grad_loc, 8))
             return launch_bwd_d32(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P,
-                                  grad_value, grad_loc, grad_attn, stream);
+                                  grad_value, grad_loc, grad_attn, stream, workspace, ws_bytes,
+                                  (flags & MSDA_FLAG_DETERMINISTIC) != 0);
     }
     return launch_bwd_generic<T>(grad_out, value, shapes, level_start, loc, attn, N, S, M, D, L, Lq, P,
                                  grad_value, grad_loc, grad_attn, stream);
@@ -131,12 +140,13 @@ template <typename GT>
 static int backward_bf16_impl(const uint16_t *grad_out, const uint16_t *value, const int64_t *spatial_shapes,
                               const int64_t *level_start, const float *sampling_loc, const float *attn_weight, int N,
                               int S, int M, int D, int L, int Lq, int P, GT *grad_value, float *grad_sampling_loc,
-                              float *grad_attn_weight, msda_stream_t stream)
+                              float *grad_attn_weight, msda_stream_t stream, void *workspace = nullptr, size_t ws_bytes = 0,
+                              unsigned flags = 0)
 {
     const void *ptrs[] = {grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, grad_value,
                           grad_sampling_loc, grad_attn_weight};
     if (int rc = msda::check_args(ptrs, 9, N, S, M, D, L, Lq, P)) return rc;
-    msda::g_err[0] = 0;
+    msda::begin_call();
     if (N == 0) return MSDA_OK;
     if (Lq == 0 || S == 0) {
         hipError_t e = hipSuccess;
@@ -155,11 +165,12 @@ static int backward_bf16_impl(const uint16_t *grad_out, const uint16_t *value, c
         return msda::refuse_unaligned("msda_backward_bf16");
     if constexpr (sizeof(GT) == 2)
         return msda::launch_bwd_d32_bf16(grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M,
-                                         L, Lq, P, grad_value, grad_sampling_loc, grad_attn_weight, (hipStream_t)stream);
+                                         L, Lq, P, grad_value, grad_sampling_loc, grad_attn_weight, (hipStream_t)stream,
+                                         workspace, ws_bytes, (flags & MSDA_FLAG_DETERMINISTIC) != 0);
     else
         return msda::launch_bwd_d32_bf16_gv32(grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S,
                                               M, L, Lq, P, grad_value, grad_sampling_loc, grad_attn_weight,
-                                              (hipStream_t)stream);
+                                              (hipStream_t)stream, workspace, ws_bytes, (flags & MSDA_FLAG_DETERMINISTIC) != 0);
 }
 
 extern "C" {
@@ -209,7 +220,7 @@ int msda_forward_bf16(const uint16_t *value, const int64_t *spatial_shapes, cons
 {
     const void *ptrs[] = {value, spatial_shapes, level_start, sampling_loc, attn_weight, out};
     if (int rc = msda::check_args(ptrs, 6, N, S, M, D, L, Lq, P)) return rc;
-    msda::g_err[0] = 0;
+    msda::begin_call();
     if (N == 0 || Lq == 0) return MSDA_OK;
     if (S == 0) {
         const hipError_t e = hipMemsetAsync(out, 0, 2 * (size_t)N * Lq * M * D, (hipStream_t)stream);
@@ -244,6 +255,47 @@ int msda_backward_bf16_gv32(const uint16_t *grad_out, const uint16_t *value, con
 
 int msda_backward_passes(int Lq, int P) { return (Lq > 0 && P > 0) ? msda::backward_passes(Lq, P) : 0; }
 
+unsigned long long msda_backward_workspace_bytes(int N, int S, int M, int D, int L, int Lq, int P, unsigned flags)
+{
+    if (N <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Lq <= 0 || P <= 0) return 0;
+    if (!(flags & MSDA_FLAG_DETERMINISTIC)) return 0;                   // only the deterministic path chunks queries
+    if (msda::g_force_path.load(std::memory_order_relaxed) == MSDA_PATH_GENERIC) return 0;
+    return (unsigned long long)msda::backward_workspace_bytes(N, S, M, D, L, Lq, P);
+}
+
+int msda_backward_ws_f32(const float *grad_out, const float *value, const int64_t *spatial_shapes,
+                         const int64_t *level_start, const float *sampling_loc, const float *attn_weight,
+                         int N, int S, int M, int D, int L, int Lq, int P, float *grad_value,
+                         float *grad_sampling_loc, float *grad_attn_weight, void *workspace,
+                         unsigned long long workspace_bytes, unsigned flags, msda_stream_t stream)
+{
+    return msda::backward_impl<float>(grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M, D,
+                                      L, Lq, P, grad_value, grad_sampling_loc, grad_attn_weight, (hipStream_t)stream,
+                                      msda::use_d32(N, S, M, D, L, Lq, P), workspace, (size_t)workspace_bytes, flags);
+}
+
+int msda_backward_ws_bf16(const uint16_t *grad_out, const uint16_t *value, const int64_t *spatial_shapes,
+                          const int64_t *level_start, const float *sampling_loc, const float *attn_weight, int N,
+                          int S, int M, int D, int L, int Lq, int P, uint16_t *grad_value, float *grad_sampling_loc,
+                          float *grad_attn_weight, void *workspace, unsigned long long workspace_bytes,
+                          unsigned flags, msda_stream_t stream)
+{
+    return backward_bf16_impl<uint16_t>(grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M, D,
+                                        L, Lq, P, grad_value, grad_sampling_loc, grad_attn_weight, stream, workspace,
+                                        (size_t)workspace_bytes, flags);
+}
+
+int msda_backward_ws_bf16_gv32(const uint16_t *grad_out, const uint16_t *value, const int64_t *spatial_shapes,
+                               const int64_t *level_start, const float *sampling_loc, const float *attn_weight, int N,
+                               int S, int M, int D, int L, int Lq, int P, float *grad_value, float *grad_sampling_loc,
+                               float *grad_attn_weight, void *workspace, unsigned long long workspace_bytes,
+                               unsigned flags, msda_stream_t stream)
+{
+    return backward_bf16_impl<float>(grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M, D, L,
+                                     Lq, P, grad_value, grad_sampling_loc, grad_attn_weight, stream, workspace,
+                                     (size_t)workspace_bytes, flags);
+}
+
 
 
 int msda_prologue_supported(int N, int S, int M, int D, int L, int Lq, int P)
@@ -267,7 +319,7 @@ int msda_forward_prologue_f32(const float *value, const int64_t *spatial_shapes,
     if (!msda::aligned_to(value, 16) || !msda::aligned_to(out, 16) || !msda::aligned_to(reference_points, 8) ||
         !msda::aligned_to(sampling_loc_out, 8))
         return msda::refuse_unaligned("msda_forward_prologue_f32");
-    msda::g_err[0] = 0;
+    msda::begin_call();
     return msda::launch_fwd_prologue(value, spatial_shapes, level_start, reference_points, sampling_offsets, attn_logits, N,
                                      S, M, L, Lq, P, ld_offsets, ld_logits, out, sampling_loc_out, attn_weight_out,
                                      (hipStream_t)stream);
@@ -279,6 +331,18 @@ int msda_backward_prologue_f32(const float *grad_out, const float *value, const 
                                long long ld_grad_logits, float *grad_value, float *grad_sampling_offsets,
                                float *grad_attn_logits, float *grad_reference_points, msda_stream_t stream)
 {
+    return msda_backward_prologue_ws_f32(grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M, D,
+                                         L, Lq, P, ld_grad_offsets, ld_grad_logits, grad_value, grad_sampling_offsets,
+                                         grad_attn_logits, grad_reference_points, nullptr, 0, 0, stream);
+}
+
+int msda_backward_prologue_ws_f32(const float *grad_out, const float *value, const int64_t *spatial_shapes,
+                                  const int64_t *level_start, const float *sampling_loc, const float *attn_weight, int N,
+                                  int S, int M, int D, int L, int Lq, int P, long long ld_grad_offsets,
+                                  long long ld_grad_logits, float *grad_value, float *grad_sampling_offsets,
+                                  float *grad_attn_logits, float *grad_reference_points, void *workspace,
+                                  unsigned long long workspace_bytes, unsigned flags, msda_stream_t stream)
+{
     const void *ptrs[] = {grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, grad_value,
                           grad_sampling_offsets, grad_attn_logits, grad_reference_points};
     if (int rc = msda::check_args(ptrs, 10, N, S, M, D, L, Lq, P)) return rc;
@@ -289,10 +353,11 @@ int msda_backward_prologue_f32(const float *grad_out, const float *value, const 
     if (!msda::aligned_to(grad_out, 16) || !msda::aligned_to(value, 16) || !msda::aligned_to(grad_value, 16) ||
         !msda::aligned_to(sampling_loc, 8) || !msda::aligned_to(grad_reference_points, 8))
         return msda::refuse_unaligned("msda_backward_prologue_f32");
-    msda::g_err[0] = 0;
+    msda::begin_call();
     return msda::launch_bwd_prologue(grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M, L,
                                      Lq, P, grad_value, ld_grad_offsets, ld_grad_logits, grad_sampling_offsets,
-                                     grad_attn_logits, grad_reference_points, (hipStream_t)stream);
+                                     grad_attn_logits, grad_reference_points, (hipStream_t)stream, workspace,
+                                     (size_t)workspace_bytes, (flags & MSDA_FLAG_DETERMINISTIC) != 0);
 }
 
 unsigned long long msda_linear_wgrad_workspace_bytes(int M, int N, int K)
@@ -316,7 +381,7 @@ int msda_linear_wgrad_masked_f32(const float *grad_out, const float *input, cons
         return msda::set_error(MSDA_ERR_ARGUMENT, "msda_linear_wgrad_f32: null device pointer");
     if (!msda::aligned_to(grad_out, 16) || !msda::aligned_to(input, 16) || !msda::aligned_to(workspace, 16))
         return msda::set_error(MSDA_ERR_ARGUMENT, "msda_linear_wgrad_f32: grad_out, input and workspace must be 16-byte aligned");
-    msda::g_err[0] = 0;
+    msda::begin_call();
     if (M == 0) {
         hipError_t e = hipMemsetAsync(grad_weight, 0, sizeof(float) * (size_t)N * K, (hipStream_t)stream);
         if (e == hipSuccess && grad_bias) e = hipMemsetAsync(grad_bias, 0, sizeof(float) * (size_t)N, (hipStream_t)stream);
@@ -334,7 +399,7 @@ int msda_zero_masked_rows_f32(float *x, const uint8_t *row_mask, long long rows,
     if (rows > 0 && (x == nullptr || row_mask == nullptr))
         return msda::set_error(MSDA_ERR_ARGUMENT, "msda_zero_masked_rows_f32: null device pointer");
     if (rows > 4LL * 0x7fffffffLL) return msda::set_error(MSDA_ERR_ARGUMENT, "msda_zero_masked_rows_f32: too many rows");
-    msda::g_err[0] = 0;
+    msda::begin_call();
     return msda::launch_zero_masked_rows(x, row_mask, rows, cols, (hipStream_t)stream);
 }
 

@@ -51,6 +51,14 @@ __device__ __forceinline__ PointGeom<F> point_geom(F loc_x, F loc_y, int H, int 
     return g;
 }
 
+// A level is usable only if its H*W pixels lie inside the S pixel rows of a batch element.  Every kernel treats the
+// points of a level that does not fit as outside the map, so nothing is ever read or written beyond the tensors,
+// whatever spatial_shapes / level_start_index hold (the reference trusts them: ms_deform_im2col_cuda.cuh:274-283).
+__device__ __forceinline__ bool level_fits(long long H, long long W, long long start, int S)
+{
+    return H > 0 && W > 0 && start >= 0 && H <= (long long)S && W <= (long long)S && start + H * W <= (long long)S;
+}
+
 // Sum over the 64 lanes of a wavefront; every lane gets the total.
 template <typename F>
 __device__ __forceinline__ F wave_sum(F x)

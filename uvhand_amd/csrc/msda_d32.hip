@@ -233,7 +233,7 @@ __global__ __launch_bounds__(kBlock) void fwd_d32_kernel(
                 pro.attn_out[e] = a;
             }
             const PointGeom<float> g = point_geom<float>(xy.x, xy.y, li.H, li.W);
-            if (g.inside) {
+            if (g.inside && level_fits(shapes[2 * l], shapes[2 * l + 1], level_start[l], S)) {
                 tap_offsets(g, li, b, m, S, M, r.off);
                 const float hh = 1.f - g.lh, hw = 1.f - g.lw;
                 r.w[0] = hh * hw * a; r.w[1] = hh * g.lw * a;
@@ -342,7 +342,7 @@ __device__ __forceinline__ void bwd_query_body(
             LevelInfo li;
             li.H = (int)shapes[2 * l]; li.W = (int)shapes[2 * l + 1]; li.start = (int)level_start[l]; li.pad = 0;
             const PointGeom<float> g = point_geom<float>(xy.x, xy.y, li.H, li.W);
-            if (g.inside) {
+            if (g.inside && level_fits(shapes[2 * l], shapes[2 * l + 1], level_start[l], S)) {
                 int b, m;
                 item_bm(il, b0, r0, m0, LqM, M, m_shift, b, m);
                 tap_offsets(g, li, b, m, S, M, r.off);
@@ -629,8 +629,21 @@ __device__ __forceinline__ void bwd_value_body(
     const int HW = H * Wd;
     const int px0 = (int)((unsigned)(ti * HW) / (unsigned)W), px1 = (int)((unsigned)((ti + 1) * HW) / (unsigned)W);
     const int npx = px1 - px0;
-    if (npx <= 0 || npx > tp_cap) return;                                    // empty range (uniform)
     const int b = pr / M, m = pr - b * M;
+    if (l == 0 && ti == 0) {
+        // pixels past the last level that fits (inconsistent shapes only) get zeros; with level_start the running
+        // sum of H*W, as the reference's callers build it (models/arctic_transformer.py:176-177), there are none
+        long long cover = 0;
+        for (int k = 0; k < L; ++k)
+            if (level_fits(shapes[2 * k], shapes[2 * k + 1], level_start[k], S))
+                cover = max(cover, (long long)level_start[k] + shapes[2 * k] * shapes[2 * k + 1]);
+        for (int i = threadIdx.x; i < (S - (int)cover) * 8; i += kSBlock)
+            Row<GT>::store(grad_value + ((long long)(b * S + (int)cover + (i >> 3)) * M + m) * kD + (i & 7) * 4,
+                           make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+    // empty range, or a level that does not fit in S (then nothing of it is touched).  A level that fits has
+    // npx <= tp_cap by construction of the ranges (plan_value: tp_cap = ceil(S / W) >= ceil(H*W / W_l)).
+    if (npx <= 0 || npx > tp_cap || !level_fits(shapes[2 * l], shapes[2 * l + 1], level_start[l], S)) return;
     const int NP = Lq * P;
     const long long item_base = (long long)b * Lq * M + m;                   // item(q) = item_base + q*M
     const int row_stride = M * kD;
@@ -851,6 +864,35 @@ __global__ __launch_bounds__(kSBlock) void bwd_fused_d32_kernel(
     }
 }
 
+}  // namespace msda
+#include "msda_d32_cell.h"
+namespace msda {
+
+// The whole backward in ONE launch, second generation: the first nB workgroups are role B on the cell-sorted
+// path (msda_d32_cell.h; slot `bid % G` of pair `bid / G`), the rest role A.  The two roles share no data.
+template <int SPLIT, typename VT, bool FUSED, typename GT>
+__global__ __launch_bounds__(kCBlock, (128 * 8) / kCBlock >= 4 ? 4 : 2) void bwd_cell_fused_d32_kernel(
+    const VT *__restrict__ grad_out, const VT *__restrict__ value,
+    const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
+    const float *__restrict__ loc, const float *__restrict__ attn, int S, int M, int L, int Lq,
+    int P, int items, int p_shift, int lp_shift, int m_shift, int nB, const CellPlan plan,
+    GT *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attn,
+    const PrologueOut pro, int xcd)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int bid = (int)blockIdx.x;
+    if (bid < nB) {
+        if (xcd) bid = xcd_block(bid, nB);
+        const int pr = bid / plan.slots;
+        bwd_cell_body<VT, GT>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, grad_value, plan, pr,
+                              bid - pr * plan.slots, smem);
+    } else {
+        bwd_query_body<SPLIT, false, kCBlock, VT, FUSED>(grad_out, value, shapes, level_start, loc, attn, S, M, L, Lq, P,
+                                                     items, p_shift, lp_shift, m_shift, static_cast<VT *>(nullptr), grad_loc, grad_attn,
+                                                     xcd ? xcd_block(bid - nB, (int)gridDim.x - nB) : bid - nB, smem, pro);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
@@ -864,11 +906,7 @@ bool d32_supported(int N, int S, int M, int D, int L, int Lq, int P)
     return true;
 }
 
-static int env_int(const char *name, int dflt)
-{
-    const char *v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
-}
+static int env_int(const char *name, int dflt) { return tuning_int(name, dflt); }   // diagnostic builds only (msda_launch.h)
 
 static int bwd_target_wgs()
 {
@@ -982,20 +1020,114 @@ static FusedPlan plan_fused(int items, int LP, int split, long long nB, int acc,
     return fp;
 }
 
+// ---- role B on the cell-sorted path (msda_d32_cell.h): host plan --------------------------------------------
+// The host knows S, L and Lq*P but not the level shapes (they live on the device), so it sizes the launch from
+// bounds: `slots` workgroup slots per (batch, head) pair (a slot loops over the pair's items slot, slot + G, ...:
+// the count only affects balance, never the result), and — when Lq*P is large and there are few pairs — up to
+// c_max query chunks per (level, tile), whose partial images go through `slabs` and slab_reduce_kernel.
+constexpr int kCellChunkPoints = 2048;
+static int cell_cmax(int N, int S, int M, int L, int Lq, int P)
+{
+    static const int target = [] { int t = env_int("MSDA_CELL_ITEMS", 1024); return t < 1 ? 1 : t; }();
+    if ((long long)Lq * P <= kCellChunkPoints) return 1;                   // a (level, tile) keeps few points anyway
+    const long long base_items = (long long)N * M * (S / 192 + L);          // ~ (pairs) x (tiles per pair)
+    long long c = (target + base_items - 1) / base_items;
+    return (int)(c < 1 ? 1 : c > 8 ? 8 : c);
+}
+
+size_t backward_workspace_bytes(int N, int S, int M, int D, int L, int Lq, int P)
+{
+    if (!d32_supported(N, S, M, D, L, Lq, P)) return 0;
+    const int c = cell_cmax(N, S, M, L, Lq, P);
+    return c > 1 ? (size_t)N * M * c * S * kD * sizeof(float) : 0;
+}
+
+struct CellLaunch { CellPlan pl; long long nB; };
+static CellLaunch plan_cells(int N, int S, int M, int L, int Lq, int P, void *workspace, size_t ws_bytes)
+{
+    CellLaunch cl;
+    const long long pairs = (long long)N * M, NP = (long long)Lq * P;
+    cl.pl.k_chunk = kCellChunkPoints;
+    cl.pl.c_max = 1; cl.pl.slab_rows = 0; cl.pl.slabs = nullptr;
+    const int c = cell_cmax(N, S, M, L, Lq, P);
+    if (c > 1 && workspace != nullptr && ((uintptr_t)workspace & 15) == 0) {
+        const long long rows = (long long)(ws_bytes / (kD * sizeof(float))) / pairs;
+        if (rows >= 2) {
+            cl.pl.c_max = c;
+            cl.pl.slab_rows = (int)(rows < (long long)c * S ? rows : (long long)c * S);
+            cl.pl.slabs = static_cast<float *>(workspace);
+        }
+    }
+    long long slots = 2LL * ceil_div(S, kTileRows) + L;
+    if (cl.pl.c_max > 1) {
+        const long long by_points = (long long)L * ((NP + kCellChunkPoints - 1) / kCellChunkPoints);
+        const long long by_cmax = slots * (cl.pl.c_max - 1);
+        slots += by_points < by_cmax ? by_points : by_cmax;
+    }
+    while (slots > 1 && slots * pairs > 0x3fffffffLL) slots = (slots + 1) / 2;   // slots only affect balance
+    cl.pl.slots = (int)slots;
+    cl.nB = slots * pairs;
+    return cl;
+}
+
+template <typename VT, typename GT, bool FUSED>
+static int launch_bwd_cells_t(const VT *grad_out, const VT *value, const int64_t *shapes, const int64_t *level_start,
+                              const float *loc, const float *attn, int N, int S, int M, int L, int Lq, int P,
+                              GT *grad_value, float *grad_loc, float *grad_attn, const PrologueOut pro, void *workspace,
+                              size_t ws_bytes, hipStream_t stream)
+{
+    const int items = N * Lq * M, LP = L * P;
+    const int item_stride = LP * kRecBytes + kItemPad;
+    const int ps = pow2_shift(P), lps = pow2_shift(LP), ms = pow2_shift(M);
+    const int xcd = xcd_remap();
+    const CellLaunch cl = plan_cells(N, S, M, L, Lq, P, workspace, ws_bytes);
+    int split = pick_split(items, LP);
+    // small launches: all of role B and role A resident at once when role A takes fewer, larger workgroups
+    auto n_a = [&](int sp) { const int ipw = kCWaves * 8 / sp; return (long long)((items + ipw - 1) / ipw); };
+    if (split == 4 && cl.nB + n_a(4) > 512 && cl.nB + n_a(2) <= 512 && (!FUSED || (kCWaves * 8 / 2) % M == 0)) split = 2;
+    static const int skip_a = env_int("MSDA_CELL_SKIP_A", 0), skip_b = env_int("MSDA_CELL_SKIP_B", 0);   // measurement only
+    const int ipw = kCWaves * 8 / split;
+    const size_t lds_a = (size_t)ipw * item_stride + (size_t)ipw * LP * 16;
+    const long long nA = skip_a ? 0 : n_a(split);
+    CellLaunch clm = cl;
+    if (skip_b) clm.nB = 0;
+    if (clm.nB + nA > 0x7fffffffLL) return set_error(MSDA_ERR_ARGUMENT, "msda backward (d32): too many workgroups");
+    const size_t lds = kCellLdsBytes > lds_a ? kCellLdsBytes : lds_a;
+    const dim3 grid((unsigned)(clm.nB + nA));
+#define MSDA_LAUNCH_C(SP)                                                                              \
+    do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_cell_fused_d32_kernel<SP, VT, FUSED, GT>), lds)) return rc; \
+         hipLaunchKernelGGL((bwd_cell_fused_d32_kernel<SP, VT, FUSED, GT>), grid, dim3(kCBlock), lds, stream, grad_out, value,     \
+                            shapes, level_start, loc, attn, S, M, L, Lq, P, items, ps, lps, ms, (int)clm.nB, cl.pl, grad_value,      \
+                            grad_loc, grad_attn, pro, xcd); } while (0)
+    if (split == 4) MSDA_LAUNCH_C(4); else if (split == 2) MSDA_LAUNCH_C(2); else MSDA_LAUNCH_C(1);
+#undef MSDA_LAUNCH_C
+    if (int rc = check_launch("msda backward (d32, cells + query-major)")) return rc;
+    if (cl.pl.c_max > 1) {
+        const int row_blocks = ceil_div(S, 32);
+        hipLaunchKernelGGL((slab_reduce_kernel<GT>), dim3((unsigned)((long long)N * M * row_blocks)), dim3(256), 0, stream, shapes,
+                           level_start, S, M, L, Lq, P, grad_value, cl.pl, row_blocks);
+        return check_launch("msda backward (d32, slab reduce)");
+    }
+    return MSDA_OK;
+}
+
 // VT = storage of value / grad_out, GT = storage of grad_value (VT, or float for bf16 rows)
 template <typename VT, typename GT = VT>
 static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *shapes,
                             const int64_t *level_start, const float *loc, const float *attn, int N, int S,
                             int M, int L, int Lq, int P, GT *grad_value, float *grad_loc, float *grad_attn,
-                            hipStream_t stream)
+                            hipStream_t stream, void *workspace = nullptr, size_t ws_bytes = 0, bool deterministic = false)
 {
     const int items = N * Lq * M, LP = L * P;
     const int item_stride = LP * kRecBytes + kItemPad;
+    if (deterministic)
+        return launch_bwd_cells_t<VT, GT, false>(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, grad_value,
+                                                 grad_loc, grad_attn, PrologueOut{nullptr, 0, 0}, workspace, ws_bytes, stream);
     // tuning / A-B knobs, read once per process: MSDA_BWD_MODE=atomic selects the v1 global-atomic
     // scatter (fp32 only), =split launches role B and role A as two kernels; MSDA_BWD_WGS is the number
     // of role-B workgroups to aim for on small problems.
     static const int bwd_mode_env = [] {                   // 0 fused (default), 1 split launches, 2 v1 atomics
-        const char *v = getenv("MSDA_BWD_MODE");
+        const char *v = tuning_str("MSDA_BWD_MODE");
         return (v && !strcmp(v, "atomic")) ? 2 : (v && !strcmp(v, "split")) ? 1 : 0; }();
     const int bwd_mode = (bwd_mode_env == 2 && sizeof(VT) != 4) ? 0 : bwd_mode_env;
     const int target_wgs = bwd_target_wgs();
@@ -1003,10 +1135,13 @@ static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *
     const int ps = pow2_shift(P), lps = pow2_shift(LP), ms = pow2_shift(M);
     const int xcd = xcd_remap();
 
+#ifdef MSDA_TUNING
     if (bwd_mode == 2) {
         hipError_t e = hipMemsetAsync(grad_value, 0, sizeof(GT) * (size_t)N * S * M * kD, stream);
         if (e != hipSuccess) return set_error(MSDA_ERR_LAUNCH, hipGetErrorString(e));
-    } else {
+    } else
+#endif
+    {
         const ValuePlan pl = plan_value<GT>(N, S, M, L, Lq, P, target_wgs);
         const long long nB = (long long)pl.W * N * M * L;
         // ---- whole backward in one launch when role A's workgroups can share the CUs (LDS) ----
@@ -1019,9 +1154,10 @@ static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *
                 const dim3 fgrid((unsigned)(nB + nA));
                 const size_t flds = pl.lds > lds_a ? pl.lds : lds_a;
 #define MSDA_LAUNCH_F(SP, AC, FX)                                                                      \
+                do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_fused_d32_kernel<SP, AC, VT, false, GT, FX>), flds)) return rc; \
                 hipLaunchKernelGGL((bwd_fused_d32_kernel<SP, AC, VT, false, GT, FX>), fgrid, dim3(kSBlock), flds, stream,  \
                                    grad_out, value, shapes, level_start, loc, attn, S, M, L, Lq, P, items, ps, lps, ms,  \
-                                   pl.tp_cap, pl.W, (int)nB, grad_value, grad_loc, grad_attn, PrologueOut{nullptr, 0, 0}, xcd)
+                                   pl.tp_cap, pl.W, (int)nB, grad_value, grad_loc, grad_attn, PrologueOut{nullptr, 0, 0}, xcd); } while (0)
                 if (fp.fixed)                { if (fp.split == 4) MSDA_LAUNCH_F(4, kAccNone, true); else if (fp.split == 2) MSDA_LAUNCH_F(2, kAccNone, true); else MSDA_LAUNCH_F(1, kAccNone, true); }
                 else if (pl.acc == kAccNone) { if (fp.split == 4) MSDA_LAUNCH_F(4, kAccNone, false); else if (fp.split == 2) MSDA_LAUNCH_F(2, kAccNone, false); else MSDA_LAUNCH_F(1, kAccNone, false); }
                 else                         { if (fp.split == 4) MSDA_LAUNCH_F(4, kAccRmw, false); else if (fp.split == 2) MSDA_LAUNCH_F(2, kAccRmw, false); else MSDA_LAUNCH_F(1, kAccRmw, false); }
@@ -1052,8 +1188,11 @@ static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *
                            level_start, loc, attn, S, M, L, Lq, P, items, ps, lps, ms, gv_atomic, grad_loc, grad_attn, xcd)
         VT *gv_atomic = nullptr;                                        // only the v1 atomic scatter writes grad_value here
         if constexpr (sizeof(VT) == sizeof(GT)) gv_atomic = grad_value;
+#ifdef MSDA_TUNING
         if (bwd_mode == 2) { if (split == 4) MSDA_LAUNCH_A(4, true); else if (split == 2) MSDA_LAUNCH_A(2, true); else MSDA_LAUNCH_A(1, true); }
-        else               { if (split == 4) MSDA_LAUNCH_A(4, false); else if (split == 2) MSDA_LAUNCH_A(2, false); else MSDA_LAUNCH_A(1, false); }
+        else
+#endif
+        { if (split == 4) MSDA_LAUNCH_A(4, false); else if (split == 2) MSDA_LAUNCH_A(2, false); else MSDA_LAUNCH_A(1, false); }
 #undef MSDA_LAUNCH_A
     }
     return check_launch("msda backward (d32, query-major)");
@@ -1066,8 +1205,8 @@ bool prologue_supported(int N, int S, int M, int D, int L, int Lq, int P)
     const int LP = L * P;
     if (pow2_shift(LP) < 0 || pow2_shift(P) < 0 || LP > 64) return false;     // lane-group reductions
     const int split = pick_split(N * Lq * M, LP);
-    if ((kSWaves * 8 / split) % M != 0) return false;                           // whole queries per role-A workgroup
-    static const bool plain_modes = [] { const char *v = getenv("MSDA_BWD_MODE"); return v && *v; }();
+    if ((kSWaves * 8 / split) % M != 0 || (kCWaves * 8 / split) % M != 0) return false;   // whole queries per role-A workgroup
+    static const bool plain_modes = tuning_str("MSDA_BWD_MODE") != nullptr;
     return !plain_modes;                                                        // A/B knobs select the unfused kernels
 }
 
@@ -1095,10 +1234,14 @@ int launch_fwd_prologue(const float *value, const int64_t *shapes, const int64_t
 int launch_bwd_prologue(const float *grad_out, const float *value, const int64_t *shapes, const int64_t *level_start,
                         const float *loc, const float *attn, int N, int S, int M, int L, int Lq, int P, float *grad_value,
                         long long ld_grad_offsets, long long ld_grad_logits, float *grad_offsets, float *grad_logits,
-                        float *grad_ref, hipStream_t stream)
+                        float *grad_ref, hipStream_t stream, void *workspace, size_t ws_bytes, bool deterministic)
 {
     const int items = N * Lq * M, LP = L * P;
     const int item_stride = LP * kRecBytes + kItemPad;
+    const PrologueOut pro_c{grad_ref, (int)((ld_grad_offsets - 2LL * M * LP) / 2), (int)(ld_grad_logits - (long long)M * LP)};
+    if (deterministic)
+        return launch_bwd_cells_t<float, float, true>(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P,
+                                                      grad_value, grad_offsets, grad_logits, pro_c, workspace, ws_bytes, stream);
     const int split = pick_split(items, LP);
     const int ps = pow2_shift(P), lps = pow2_shift(LP), ms = pow2_shift(M);
     const ValuePlan pl = plan_value<float>(N, S, M, L, Lq, P, bwd_target_wgs());
@@ -1113,9 +1256,10 @@ int launch_bwd_prologue(const float *grad_out, const float *value, const int64_t
     const size_t flds = pl.lds > lds_a ? pl.lds : lds_a;
     const PrologueOut pro{grad_ref, (int)((ld_grad_offsets - 2LL * M * LP) / 2), (int)(ld_grad_logits - (long long)M * LP)};
 #define MSDA_LAUNCH_BP(SP, AC, FX)                                                                     \
+    do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_fused_d32_kernel<SP, AC, float, true, float, FX>), flds)) return rc; \
     hipLaunchKernelGGL((bwd_fused_d32_kernel<SP, AC, float, true, float, FX>), fgrid, dim3(kSBlock), flds, stream, grad_out, \
                        value, shapes, level_start, loc, attn, S, M, L, Lq, P, items, ps, lps, ms, pl.tp_cap, pl.W, (int)nB,  \
-                       grad_value, grad_offsets, grad_logits, pro, xcd_remap())
+                       grad_value, grad_offsets, grad_logits, pro, xcd_remap()); } while (0)
     if (fp.fixed)                { if (fp.split == 4) MSDA_LAUNCH_BP(4, kAccNone, true); else if (fp.split == 2) MSDA_LAUNCH_BP(2, kAccNone, true); else MSDA_LAUNCH_BP(1, kAccNone, true); }
     else if (pl.acc == kAccNone) { if (fp.split == 4) MSDA_LAUNCH_BP(4, kAccNone, false); else if (fp.split == 2) MSDA_LAUNCH_BP(2, kAccNone, false); else MSDA_LAUNCH_BP(1, kAccNone, false); }
     else                         { if (fp.split == 4) MSDA_LAUNCH_BP(4, kAccRmw, false); else if (fp.split == 2) MSDA_LAUNCH_BP(2, kAccRmw, false); else MSDA_LAUNCH_BP(1, kAccRmw, false); }
@@ -1130,10 +1274,11 @@ int launch_fwd_d32(const float *value, const int64_t *shapes, const int64_t *lev
 }
 int launch_bwd_d32(const float *grad_out, const float *value, const int64_t *shapes, const int64_t *level_start,
                    const float *loc, const float *attn, int N, int S, int M, int L, int Lq, int P,
-                   float *grad_value, float *grad_loc, float *grad_attn, hipStream_t stream)
+                   float *grad_value, float *grad_loc, float *grad_attn, hipStream_t stream, void *workspace, size_t ws_bytes,
+                   bool deterministic)
 {
     return launch_bwd_d32_t<float>(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, grad_value,
-                                   grad_loc, grad_attn, stream);
+                                   grad_loc, grad_attn, stream, workspace, ws_bytes, deterministic);
 }
 int launch_fwd_d32_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *level_start, const float *loc,
                         const float *attn, int N, int S, int M, int L, int Lq, int P, uint16_t *out,
@@ -1143,17 +1288,19 @@ int launch_fwd_d32_bf16(const uint16_t *value, const int64_t *shapes, const int6
 }
 int launch_bwd_d32_bf16(const uint16_t *grad_out, const uint16_t *value, const int64_t *shapes,
                         const int64_t *level_start, const float *loc, const float *attn, int N, int S, int M, int L,
-                        int Lq, int P, uint16_t *grad_value, float *grad_loc, float *grad_attn, hipStream_t stream)
+                        int Lq, int P, uint16_t *grad_value, float *grad_loc, float *grad_attn, hipStream_t stream,
+                        void *workspace, size_t ws_bytes, bool deterministic)
 {
     return launch_bwd_d32_t<bf16_t>(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, grad_value,
-                                    grad_loc, grad_attn, stream);
+                                    grad_loc, grad_attn, stream, workspace, ws_bytes, deterministic);
 }
 int launch_bwd_d32_bf16_gv32(const uint16_t *grad_out, const uint16_t *value, const int64_t *shapes,
                              const int64_t *level_start, const float *loc, const float *attn, int N, int S, int M, int L,
-                             int Lq, int P, float *grad_value, float *grad_loc, float *grad_attn, hipStream_t stream)
+                             int Lq, int P, float *grad_value, float *grad_loc, float *grad_attn, hipStream_t stream,
+                             void *workspace, size_t ws_bytes, bool deterministic)
 {
     return launch_bwd_d32_t<bf16_t, float>(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, grad_value,
-                                           grad_loc, grad_attn, stream);
+                                           grad_loc, grad_attn, stream, workspace, ws_bytes, deterministic);
 }
 
 int backward_passes(int Lq, int P) { return (Lq * P + kSingleMaxPoints - 1) / kSingleMaxPoints; }

@@ -42,6 +42,7 @@ __global__ __launch_bounds__(kGenericBlock) void fwd_generic_kernel(
         T acc = 0;
         for (int l = 0; l < L; ++l) {
             const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+            if (!level_fits(shapes[2 * l], shapes[2 * l + 1], level_start[l], S)) continue;
             const T *v = value + ((b * S + level_start[l]) * M + m) * D + (live ? c : 0);
             for (int p = 0; p < P; ++p) {
                 const int k = l * P + p;
@@ -94,11 +95,12 @@ __global__ __launch_bounds__(kGenericBlock) void bwd_generic_kernel(
     for (int l = 0; l < L; ++l) {
         const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
         const long long lvl = ((b * S + level_start[l]) * M + m) * D;
+        const bool fits = level_fits(shapes[2 * l], shapes[2 * l + 1], level_start[l], S);
         for (int p = 0; p < P; ++p) {
             const int k = l * P + p;
             const PointGeom<T> g = point_geom<T>(lp[2 * k], lp[2 * k + 1], H, W);
             T s_attn = 0, s_x = 0, s_y = 0;
-            if (g.inside) {
+            if (g.inside && fits) {
                 const T a = ap[k];
                 const T hh = 1 - g.lh, hw = 1 - g.lw;
                 const T k1 = hh * hw, k2 = hh * g.lw, k3 = g.lh * hw, k4 = g.lh * g.lw;

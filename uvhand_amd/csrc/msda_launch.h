@@ -3,10 +3,22 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "msda.h"
 
 namespace msda {
+
+// Tuning / A-B knobs (MSDA_SPLIT, MSDA_XCD, MSDA_BWD_MODE, MSDA_BWD_WGS, ... tools/README.md) exist only in DIAGNOSTIC
+// builds (-DMSDA_TUNING: `make -C uvhand_amd/csrc tuning`, tools/micro/kbench.cpp).  The shipped library reads no
+// environment variable and keeps no process-wide state: these helpers then return the default.
+#ifdef MSDA_TUNING
+#include <cstdlib>
+inline const char *tuning_str(const char *name) { const char *v = getenv(name); return (v && *v) ? v : nullptr; }
+#else
+inline const char *tuning_str(const char *) { return nullptr; }
+#endif
+inline int tuning_int(const char *name, int dflt) { const char *v = tuning_str(name); return v ? atoi(v) : dflt; }
 
 // Records `msg` for msda_last_error() on this thread and returns `code`.
 int set_error(int code, const char *msg);
@@ -32,7 +44,9 @@ int launch_fwd_d32(const float *value, const int64_t *shapes, const int64_t *lev
 int launch_bwd_d32(const float *grad_out, const float *value, const int64_t *shapes,
                    const int64_t *level_start, const float *loc, const float *attn, int N, int S,
                    int M, int L, int Lq, int P, float *grad_value, float *grad_loc, float *grad_attn,
-                   hipStream_t stream);
+                   hipStream_t stream, void *workspace = nullptr, size_t ws_bytes = 0, bool deterministic = false);
+// scratch the D = 32 backward can use to cut long levels into query chunks (0 = none needed); see msda.h
+size_t backward_workspace_bytes(int N, int S, int M, int D, int L, int Lq, int P);
 
 // bf16 storage (uint16_t bits) of value / out / grad_out / grad_value; loc, attn and their gradients fp32.
 int launch_fwd_d32_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *level_start,
@@ -41,13 +55,14 @@ int launch_fwd_d32_bf16(const uint16_t *value, const int64_t *shapes, const int6
 int launch_bwd_d32_bf16(const uint16_t *grad_out, const uint16_t *value, const int64_t *shapes,
                         const int64_t *level_start, const float *loc, const float *attn, int N, int S,
                         int M, int L, int Lq, int P, uint16_t *grad_value, float *grad_loc, float *grad_attn,
-                        hipStream_t stream);
+                        hipStream_t stream, void *workspace = nullptr, size_t ws_bytes = 0, bool deterministic = false);
 
 // bf16 rows in, fp32 grad_value out: nothing is rounded between the passes of a multi-pass backward (and a
 // caller whose value tensor is fp32 needs no conversion of the result)
 int launch_bwd_d32_bf16_gv32(const uint16_t *grad_out, const uint16_t *value, const int64_t *shapes,
                              const int64_t *level_start, const float *loc, const float *attn, int N, int S, int M, int L,
-                             int Lq, int P, float *grad_value, float *grad_loc, float *grad_attn, hipStream_t stream);
+                             int Lq, int P, float *grad_value, float *grad_loc, float *grad_attn, hipStream_t stream,
+                             void *workspace = nullptr, size_t ws_bytes = 0, bool deterministic = false);
 // number of query chunks ("passes") role B of the D = 32 backward takes for Lq*P sampling points per (b, m, l)
 int backward_passes(int Lq, int P);
 
@@ -62,7 +77,7 @@ int launch_fwd_prologue(const float *value, const int64_t *shapes, const int64_t
 int launch_bwd_prologue(const float *grad_out, const float *value, const int64_t *shapes, const int64_t *level_start,
                         const float *loc, const float *attn, int N, int S, int M, int L, int Lq, int P, float *grad_value,
                         long long ld_grad_offsets, long long ld_grad_logits, float *grad_offsets, float *grad_logits,
-                        float *grad_ref, hipStream_t stream);
+                        float *grad_ref, hipStream_t stream, void *workspace = nullptr, size_t ws_bytes = 0, bool deterministic = false);
 
 // ---- weight / bias gradient of the bracketing nn.Linear layers (msda_linear.hip) -----------------
 size_t linear_wgrad_workspace_bytes(int M, int N, int K);

@@ -224,18 +224,13 @@ int launch_zero_masked_rows(float *x, const uint8_t *mask, long long rows, int c
     return check_launch("msda zero masked rows");
 }
 
-static int env_knob(const char *name, int dflt)
-{
-    const char *v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
-}
 
 // Number of M-splits: enough workgroups to fill the chip (a few per CU: the kernel hides its barriers and
 // LDS round trips behind other wavefronts' MFMAs), at least two stages per chunk, and — when there are 8 or
 // more — a multiple of 8 so that whole splits go to one XCD (tile_and_split).
 static int wgrad_splits(int M, int N, int K)
 {
-    static const int target = env_knob("MSDA_WGRAD_WGS", 768);
+    static const int target = tuning_int("MSDA_WGRAD_WGS", 768);
     const int tiles = ((N + kWgTile - 1) / kWgTile) * ((K + kWgTile - 1) / kWgTile);
     int splits = (target + tiles - 1) / tiles;
     const int max_splits = (M + 2 * kWgStage - 1) / (2 * kWgStage);

@@ -78,7 +78,12 @@ class _MaskedBracketLinearFn(Function):
             grad_x = MSDA.zero_masked_rows_(gx2, mask).view_as(x)
         if need_w or (need_b and ctx.has_bias):
             x2 = x.reshape(-1, x.shape[-1]).contiguous()
-            grad_w, grad_b = MSDA.linear_wgrad(go2, x2, want_bias=ctx.has_bias and need_b, row_mask=mask)
+            if MSDA.linear_wgrad_supported(go2, x2):
+                grad_w, grad_b = MSDA.linear_wgrad(go2, x2, want_bias=ctx.has_bias and need_b, row_mask=mask)
+            else:                                                   # same escape as _BracketLinearFn (odd view offset, huge M)
+                gom = go2.masked_fill(mask[:, None], 0)
+                grad_w = gom.t() @ x2
+                grad_b = gom.sum(0) if (ctx.has_bias and need_b) else None
             if not need_w:
                 grad_w = None
         return grad_x, grad_w, grad_b, None

@@ -79,3 +79,12 @@ def sum_over_ranks(value, device=None):
 def job_throughput(samples_this_rank, seconds_this_rank, device=None):
     """Whole-job samples/s: all ranks' samples over the slowest rank's time."""
     return sum_over_ranks(samples_this_rank, device) / max_over_ranks(seconds_this_rank, device)
+
+
+def gather_objects(obj):
+    """[obj of rank 0, obj of rank 1, ...] on every rank (a one-element list without a process group)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out

@@ -20,6 +20,7 @@ stay ``nn.Linear`` (hipBLASLt / MFMA on ROCm), as north_star prescribes.
 """
 import math
 import warnings
+import weakref
 
 import torch
 import torch.nn.functional as F
@@ -31,20 +32,37 @@ from ..functions import (MSDeformAttnBF16Function, MSDeformAttnFunction, MSDefor
 from ..functions.linear_func import bracket_linear, bracket_linear_masked, bracket_linear_wb
 
 
-# (data_ptr, version, Len_in) of spatial_shapes tensors whose H*W sum was already verified: the
-# reference's assert (:93) costs a device->host sync on every call of every layer; checking each
-# distinct shapes tensor once keeps the check without stalling the launch queue 12x per step.
-_verified_shapes = set()
+# The reference asserts sum_l H_l*W_l == Len_in on every call of every layer (:93) — a device->host sync
+# 12x per training step.  Here each distinct spatial_shapes tensor OBJECT is read back once (the models hand
+# the same tensor to all their layers, models/arctic_transformer.py:176-179,293,382); the entry is keyed on the
+# object's identity and dropped when the tensor dies, so a recycled address or id can never vouch for other
+# contents.  Tensors that track in-place versions are re-checked when modified; inference tensors (no version
+# counter) are keyed on identity alone.  During HIP-graph capture nothing may synchronise: the check is skipped
+# there — the kernels themselves never touch memory outside [0, S) whatever the shapes say (include/msda.h).
+_verified_shapes = {}
+
+
+def _shapes_version(t):
+    try:
+        return t._version
+    except RuntimeError:                      # "Inference tensors do not track version counter"
+        return None
 
 
 def _check_shapes_sum(spatial_shapes, len_in):
-    key = (spatial_shapes.data_ptr(), spatial_shapes._version, tuple(spatial_shapes.shape), int(len_in))
-    if key in _verified_shapes:
+    key = id(spatial_shapes)
+    entry = _verified_shapes.get(key)
+    want = (_shapes_version(spatial_shapes), tuple(spatial_shapes.shape), int(len_in))
+    if entry is not None and entry[0]() is spatial_shapes and entry[1] == want:
+        return
+    if spatial_shapes.is_cuda and torch.cuda.is_current_stream_capturing():
         return
     assert (spatial_shapes[:, 0] * spatial_shapes[:, 1]).sum() == len_in
-    if len(_verified_shapes) > 4096:
-        _verified_shapes.clear()
-    _verified_shapes.add(key)
+    try:
+        ref = weakref.ref(spatial_shapes, lambda _r, k=key: _verified_shapes.pop(k, None))
+    except TypeError:                         # not weak-referenceable: just do not cache
+        return
+    _verified_shapes[key] = (ref, want)
 
 
 def _is_power_of_2(n):
@@ -130,6 +148,8 @@ class MSDeformAttn(nn.Module):
         if (self.fused_prologue and self.merged_projection and not self.bf16_storage and ref_dim in (2, 42)
                 and value.is_cuda and value.dtype == torch.float32 and query.dtype == torch.float32
                 and reference_points.dtype == torch.float32 and not torch.is_autocast_enabled()
+                # the kernels move (x, y) pairs as 8 bytes: the offsets block starts every 3*M*L*P floats
+                and (self.n_heads * self.n_levels * self.n_points) % 2 == 0
                 and _native.prologue_geometry_supported(N, Len_in, self.n_heads, self.d_model // self.n_heads,
                                                         self.n_levels, Len_q, self.n_points)):
             centre = reference_points if ref_dim == 2 else torch.stack(
