@@ -221,6 +221,22 @@ int msda_linear_wgrad_masked_f32(const float *grad_out, const float *input, cons
 int msda_zero_masked_rows_f32(float *x, const uint8_t *row_mask, long long rows, int cols, msda_stream_t stream);
 
 /* Thread-local description of the last failure on the calling thread ("" if none). */
+/* ---- Residual add + LayerNorm of the layers around the op --------------------------
+ * y = LayerNorm(x + residual) * gamma + beta over rows of width d (fp32, d a multiple of 4, <= 1024) — the
+ * `x = x + dropout(x2); x = norm(x)` pairs of the reference's encoder / decoder layers
+ * (models/arctic_transformer.py:279-282, 294-295, 366-368, 377-378, 385-386) as one pass instead of an add kernel
+ * and a LayerNorm kernel; `residual` may be NULL (plain LayerNorm).  The forward also returns mean[rows] and
+ * rstd[rows]; the backward recomputes x + residual, writes grad_sum[rows, d] (the gradient of x and of residual
+ * alike) and grad_gamma / grad_beta through per-workgroup partial sums in `workspace`
+ * (msda_add_layernorm_workspace_bytes) combined in a fixed order — reproducible, no float atomics.  Dropout is not
+ * part of it: the caller applies the framework's dropout to `residual` first, so its random stream is untouched. */
+unsigned long long msda_add_layernorm_workspace_bytes(long long rows, int d);
+int msda_add_layernorm_forward_f32(const float *x, const float *residual, const float *gamma, const float *beta, long long rows,
+                                   int d, float eps, float *y, float *mean, float *rstd, msda_stream_t stream);
+int msda_add_layernorm_backward_f32(const float *grad_y, const float *x, const float *residual, const float *gamma,
+                                    const float *mean, const float *rstd, long long rows, int d, float *grad_sum,
+                                    float *grad_gamma, float *grad_beta, void *workspace, msda_stream_t stream);
+
 const char *msda_last_error(void);
 
 /* Library/ABI version (major*100 + minor) and the kernel family a geometry maps to. */

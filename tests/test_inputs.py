@@ -65,3 +65,45 @@ def test_decoder_reference_points_2d_and_42d():
     assert torch.equal(out42[2, 5, 1, 1::2], p42[2, 5, 1::2] * valid[2, 1, 1])     # y coordinates with h
     with pytest.raises(ValueError):
         decoder_reference_points(torch.rand(N, 7, 4), valid)
+
+
+# ---------------------------------------------------------------------------------------------
+# callers.npz: the flatten block of DeformableTransformer.forward (models/arctic_transformer.py:157-177) and the
+# per-layer reference points of DeformableTransformerDecoder.forward (:413-419), EXECUTED from the reference file
+# by tests/golden/gen_golden_r02.py
+# ---------------------------------------------------------------------------------------------
+def _callers(device):
+    z = load_golden("callers")
+    L = z["shapes_in"].shape[0]
+    to = lambda a: torch.from_numpy(a).to(device)
+    srcs = [to(z["src%d" % i]) for i in range(L)]
+    poss = [to(z["pos%d" % i]) for i in range(L)]
+    masks = [to(z["mask%d" % i]) for i in range(L)]
+    return z, srcs, masks, poss, to(z["level_embed"])
+
+
+def _check_flatten(device):
+    z, srcs, masks, poss, level_embed = _callers(device)
+    src, mask, pos, ss, lsi, valid = flatten_feature_levels(srcs, masks, poss, level_embed)
+    assert ss.device.type == device and ss.dtype == torch.int64 and lsi.dtype == torch.int64
+    assert np.array_equal(src.cpu().numpy(), z["src_flatten"])
+    assert np.array_equal(mask.cpu().numpy(), z["mask_flatten"])
+    assert np.array_equal(pos.cpu().numpy(), z["lvl_pos_embed_flatten"])
+    assert np.array_equal(ss.cpu().numpy(), z["spatial_shapes"])
+    assert np.array_equal(lsi.cpu().numpy(), z["level_start_index"])
+    # integer / copy outputs are exact everywhere; the fp32 divisions behind the valid ratios are correctly rounded
+    # on the CPU (bit-equal to the reference's run) and within one ulp on the device
+    same = np.array_equal if device == "cpu" else (lambda a, b: np.allclose(a, b, rtol=2e-7, atol=0))
+    assert same(valid.cpu().numpy(), z["valid_ratios"])
+    for width in (2, 42):
+        out = decoder_reference_points(torch.from_numpy(z["dec_ref%d" % width]).to(device), valid)
+        assert same(out.cpu().numpy(), z["dec_ref%d_input" % width])
+
+
+def test_flatten_and_decoder_reference_points_match_the_reference():
+    _check_flatten("cpu")
+
+
+@pytest.mark.gpu
+def test_flatten_and_decoder_reference_points_match_the_reference_on_device():
+    _check_flatten("cuda")

@@ -1,0 +1,37 @@
+"""CPU-side checks of the f2 layers: names, state_dict keys and seeded construction follow the reference's classes
+(models/arctic_transformer.py:261-300, :334-391; fixtures from tests/golden/gen_golden_r02.py), and the fused add+LayerNorm
+wrapper falls back to the framework's layers where the kernel does not apply."""
+import torch
+from torch import nn
+
+from conftest import load_golden
+
+
+def test_layer_state_dict_keys_match_the_reference():
+    from uvhand_amd.modules import DeformableTransformerDecoderLayer, DeformableTransformerEncoderLayer
+    for cls, fixture in ((DeformableTransformerEncoderLayer, "layer_encoder"), (DeformableTransformerDecoderLayer, "layer_decoder_2d")):
+        z = load_golden(fixture)
+        ref_keys = [k[len("state."):] for k in z if k.startswith("state.")]
+        layer = cls(64, 128, 0.0, "relu", 4, 2, 4)
+        assert list(layer.state_dict().keys()) == ref_keys
+        for k, v in layer.state_dict().items():
+            assert tuple(v.shape) == z["state." + k].shape, k
+        layer.load_state_dict({k: torch.from_numpy(z["state." + k]) for k in ref_keys}, strict=True)
+
+
+def test_decoder_layer_module_names():
+    from uvhand_amd.modules import DeformableTransformerDecoderLayer
+    layer = DeformableTransformerDecoderLayer()
+    names = [n for n, _ in layer.named_children()]
+    assert names == ["cross_attn", "dropout1", "norm1", "self_attn", "dropout2", "norm2", "linear1", "dropout3", "linear2",
+                     "dropout4", "norm3", "inter_rp", "attn_matrix"]
+    assert isinstance(layer.self_attn, nn.MultiheadAttention) and layer.self_attn.num_heads == 8
+    assert layer.linear1.out_features == 1024 and layer.dropout1.p == 0.1
+
+
+def test_add_layer_norm_falls_back_on_cpu():
+    from uvhand_amd.functions.layernorm_func import add_layer_norm
+    norm = nn.LayerNorm(12)
+    x, r = torch.randn(5, 12), torch.randn(5, 12)
+    assert torch.equal(add_layer_norm(x, r, norm), norm(x + r))
+    assert torch.equal(add_layer_norm(x, None, norm), norm(x))

@@ -37,6 +37,26 @@ def test_module_forward_backward_match_reference(case):
         assert rel_err(p.grad.cpu().numpy(), z["pgrad." + name]) < 3e-4, name
 
 
+def test_module_4d_branch_matches_the_dn_dab_reference_module():
+    """models/dn_dab_dino_deformable_detr/ops/modules/ms_deform_attn.py:105-108, imported and run by
+    tests/golden/gen_golden_r02.py with the shared module_state weights."""
+    z = load_golden("module_4d")
+    mod = _module()
+    query = torch.from_numpy(z["query"]).cuda().requires_grad_(True)
+    src = torch.from_numpy(z["src"]).cuda().requires_grad_(True)
+    refp = torch.from_numpy(z["refp"]).cuda().requires_grad_(True)
+    out = mod(query, refp, src, torch.from_numpy(z["shapes"]).cuda(), torch.from_numpy(z["level_start"]).cuda(),
+              torch.from_numpy(z["mask"]).cuda())
+    out.backward(torch.from_numpy(z["gout"]).cuda())
+    torch.cuda.synchronize()
+    assert rel_err(out.detach().cpu().numpy(), z["out"]) < 1e-4
+    assert rel_err(query.grad.cpu().numpy(), z["grad_query"]) < 2e-4
+    assert rel_err(src.grad.cpu().numpy(), z["grad_src"]) < 2e-4
+    assert rel_err(refp.grad.cpu().numpy(), z["grad_refp"]) < 2e-4
+    for name, p in mod.named_parameters():
+        assert rel_err(p.grad.cpu().numpy(), z["pgrad." + name]) < 3e-4, name
+
+
 def test_module_4d_reference_boxes_run_and_are_finite():
     """The upstream box branch (dn_dab copy, ops/modules/ms_deform_attn.py:106-108)."""
     mod = _module()

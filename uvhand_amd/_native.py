@@ -25,6 +25,7 @@ _SYMBOLS = (
     "msda_forward_bf16", "msda_backward_bf16", "msda_backward_bf16_gv32", "msda_backward_passes",
     "msda_backward_workspace_bytes", "msda_backward_ws_f32", "msda_backward_ws_bf16", "msda_backward_ws_bf16_gv32",
     "msda_backward_prologue_ws_f32",
+    "msda_add_layernorm_workspace_bytes", "msda_add_layernorm_forward_f32", "msda_add_layernorm_backward_f32",
     "msda_linear_wgrad_f32", "msda_linear_wgrad_masked_f32", "msda_linear_wgrad_workspace_bytes",
     "msda_zero_masked_rows_f32",
     "msda_prologue_supported", "msda_forward_prologue_f32", "msda_backward_prologue_f32",
@@ -53,6 +54,8 @@ def load():
     lib.msda_prologue_supported.argtypes = [ctypes.c_int] * 7
     lib.msda_backward_workspace_bytes.restype = ctypes.c_ulonglong
     lib.msda_backward_workspace_bytes.argtypes = [ctypes.c_int] * 7 + [ctypes.c_uint]
+    lib.msda_add_layernorm_workspace_bytes.restype = ctypes.c_ulonglong
+    lib.msda_add_layernorm_workspace_bytes.argtypes = [ctypes.c_longlong, ctypes.c_int]
     lib.msda_linear_wgrad_workspace_bytes.restype = ctypes.c_ulonglong
     lib.msda_linear_wgrad_workspace_bytes.argtypes = [ctypes.c_int] * 3
     _lib = lib
@@ -445,6 +448,54 @@ def ms_deform_attn_backward_prologue(value, spatial_shapes, level_start_index, s
     if rc != 0:
         _raise(lib, rc, "ms_deform_attn_backward_prologue")
     return (gv, goff, glog, gref, both) if merged else (gv, goff, glog, gref)
+
+
+def add_layernorm_supported(x, residual, weight, bias):
+    """fp32 CUDA rows of a width the kernels take (multiple of 4, <= 1024), contiguous, 16-byte aligned."""
+    d = x.shape[-1] if x.dim() else 0
+    ts = [x, weight, bias] + ([residual] if residual is not None else [])
+    return (x.dim() >= 1 and d % 4 == 0 and 0 < d <= 1024 and weight is not None and bias is not None
+            and tuple(weight.shape) == (d,) and tuple(bias.shape) == (d,)
+            and (residual is None or residual.shape == x.shape)
+            and all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() % 16 == 0
+                    and t.device == x.device for t in ts))
+
+
+def add_layernorm_forward(x, residual, weight, bias, eps):
+    """(y, mean, rstd) = LayerNorm(x + residual) — msda_add_layernorm_forward_f32 (include/msda.h)."""
+    lib = _lib or load()
+    d = x.shape[-1]
+    rows = x.numel() // d
+    with _DeviceGuard(x.device):
+        y = torch.empty_like(x)
+        mean = torch.empty((rows,), dtype=torch.float32, device=x.device)
+        rstd = torch.empty((rows,), dtype=torch.float32, device=x.device)
+        rc = _entry(lib, "msda_add_layernorm_forward_f32", [_VP] * 4 + [_LL, _CI, ctypes.c_float] + [_VP] * 4)(
+            x.data_ptr(), residual.data_ptr() if residual is not None else None, weight.data_ptr(), bias.data_ptr(), rows, d,
+            float(eps), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _raw_stream(x.device))
+    if rc != 0:
+        _raise(lib, rc, "add_layernorm_forward")
+    return y, mean, rstd
+
+
+def add_layernorm_backward(grad_y, x, residual, weight, mean, rstd):
+    """(grad_sum, grad_weight, grad_bias) — msda_add_layernorm_backward_f32; grad_sum is d/dx and d/dresidual."""
+    lib = _lib or load()
+    d = x.shape[-1]
+    rows = x.numel() // d
+    with _DeviceGuard(x.device):
+        gs = torch.empty_like(x)
+        gw = torch.empty((d,), dtype=torch.float32, device=x.device)
+        gb = torch.empty((d,), dtype=torch.float32, device=x.device)
+        nbytes = max(16, int(lib.msda_add_layernorm_workspace_bytes(rows, d)))
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+        rc = _entry(lib, "msda_add_layernorm_backward_f32", [_VP] * 6 + [_LL, _CI] + [_VP] * 5)(
+            grad_y.data_ptr(), x.data_ptr(), residual.data_ptr() if residual is not None else None, weight.data_ptr(),
+            mean.data_ptr(), rstd.data_ptr(), rows, d, gs.data_ptr(), gw.data_ptr(), gb.data_ptr(), ws.data_ptr(),
+            _raw_stream(x.device))
+    if rc != 0:
+        _raise(lib, rc, "add_layernorm_backward")
+    return gs, gw, gb
 
 
 def path_for(elem_bytes, M, D, L, P):

@@ -403,6 +403,57 @@ int msda_zero_masked_rows_f32(float *x, const uint8_t *row_mask, long long rows,
     return msda::launch_zero_masked_rows(x, row_mask, rows, cols, (hipStream_t)stream);
 }
 
+static int check_layernorm_args(const char *who, long long rows, int d, const void *const *ptrs, int n)
+{
+    char buf[200];
+    if (rows < 0 || d <= 0 || (d & 3) || d > 1024) {
+        std::snprintf(buf, sizeof(buf), "%s: need rows >= 0 and a row width that is a multiple of 4 in [4, 1024]", who);
+        return msda::set_error(MSDA_ERR_ARGUMENT, buf);
+    }
+    for (int i = 0; i < n; ++i)
+        if (rows > 0 && (ptrs[i] == nullptr || ((uintptr_t)ptrs[i] & 15))) {
+            std::snprintf(buf, sizeof(buf), "%s: null or not 16-byte aligned device pointer", who);
+            return msda::set_error(MSDA_ERR_ARGUMENT, buf);
+        }
+    return MSDA_OK;
+}
+
+unsigned long long msda_add_layernorm_workspace_bytes(long long rows, int d)
+{
+    return (rows > 0 && d > 0) ? (unsigned long long)msda::add_layernorm_workspace_bytes(rows, d) : 0;
+}
+
+int msda_add_layernorm_forward_f32(const float *x, const float *residual, const float *gamma, const float *beta, long long rows,
+                                   int d, float eps, float *y, float *mean, float *rstd, msda_stream_t stream)
+{
+    const void *ptrs[] = {x, gamma, beta, y};
+    if (int rc = check_layernorm_args("msda_add_layernorm_forward_f32", rows, d, ptrs, 4)) return rc;
+    if (rows > 0 && (mean == nullptr || rstd == nullptr || (residual && ((uintptr_t)residual & 15))))
+        return msda::set_error(MSDA_ERR_ARGUMENT, "msda_add_layernorm_forward_f32: null mean / rstd or misaligned residual");
+    msda::begin_call();
+    if (rows == 0) return MSDA_OK;
+    return msda::launch_add_layernorm_fwd(x, residual, gamma, beta, rows, d, eps, y, mean, rstd, (hipStream_t)stream);
+}
+
+int msda_add_layernorm_backward_f32(const float *grad_y, const float *x, const float *residual, const float *gamma,
+                                    const float *mean, const float *rstd, long long rows, int d, float *grad_sum,
+                                    float *grad_gamma, float *grad_beta, void *workspace, msda_stream_t stream)
+{
+    const void *ptrs[] = {grad_y, x, gamma, grad_sum, workspace};
+    if (int rc = check_layernorm_args("msda_add_layernorm_backward_f32", rows, d, ptrs, 5)) return rc;
+    if (grad_gamma == nullptr || grad_beta == nullptr || (rows > 0 && (mean == nullptr || rstd == nullptr)) ||
+        (residual && ((uintptr_t)residual & 15)))
+        return msda::set_error(MSDA_ERR_ARGUMENT, "msda_add_layernorm_backward_f32: null pointer or misaligned residual");
+    msda::begin_call();
+    if (rows == 0) {
+        hipError_t e = hipMemsetAsync(grad_gamma, 0, sizeof(float) * (size_t)d, (hipStream_t)stream);
+        if (e == hipSuccess) e = hipMemsetAsync(grad_beta, 0, sizeof(float) * (size_t)d, (hipStream_t)stream);
+        return e == hipSuccess ? MSDA_OK : msda::set_error(MSDA_ERR_LAUNCH, hipGetErrorString(e));
+    }
+    return msda::launch_add_layernorm_bwd(grad_y, x, residual, gamma, mean, rstd, rows, d, grad_sum, grad_gamma, grad_beta,
+                                          static_cast<float *>(workspace), (hipStream_t)stream);
+}
+
 const char *msda_last_error(void) { return msda::g_err; }
 
 int msda_version(void) { return 101; }

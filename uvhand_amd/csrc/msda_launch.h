@@ -86,4 +86,12 @@ int launch_linear_wgrad(const float *dY, const float *X, const uint8_t *row_mask
                         float *workspace, hipStream_t stream);
 int launch_zero_masked_rows(float *x, const uint8_t *mask, long long rows, int cols, hipStream_t stream);
 
+// ---- residual add + LayerNorm of the layers around the op (msda_layernorm.hip) ---------------------
+size_t add_layernorm_workspace_bytes(long long rows, int d);
+int launch_add_layernorm_fwd(const float *x, const float *res, const float *gamma, const float *beta, long long rows, int d,
+                             float eps, float *y, float *mean, float *rstd, hipStream_t stream);
+int launch_add_layernorm_bwd(const float *dy, const float *x, const float *res, const float *gamma, const float *mean,
+                             const float *rstd, long long rows, int d, float *ds, float *dgamma, float *dbeta, float *workspace,
+                             hipStream_t stream);
+
 }  // namespace msda
