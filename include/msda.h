@@ -140,6 +140,8 @@ int msda_backward_passes(int Lq, int P);
  * always accepted (same result per tile, less parallelism).  The library still allocates nothing.
  * Shapes that are inconsistent with S (a level whose pixels do not lie in [0, S)) never cause an
  * out-of-range access on this path: such a level contributes nothing and pixels no level covers get zeros.
+ * The flag concerns the D = 32 kernel family (the models' shape); the generic family (any D, fp64) keeps its
+ * global float atomics for grad_value and ignores it.
  * It costs 1.5-3x the default backward (profiles/r02_notes.md).  Replaces the same reference functions as
  * msda_backward_*. */
 #define MSDA_FLAG_DETERMINISTIC 1u

@@ -93,7 +93,7 @@ def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "uvhand_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".hip", ".h")):
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
                 assert "torch_fallback" not in text and "grid_sample" not in text, f
@@ -154,3 +154,13 @@ def test_module_argument_errors():
     # the product path needs the GPU: on CPU tensors it raises, it does not fall back
     with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
         mod(q, torch.rand(1, 3, 2, 2), src, shapes, lsi)
+
+
+def test_torch_extension_loads_and_matches_the_library(native):
+    """uvhand_amd/_msda_torch.so (csrc/torch_ext): built by build(), linked against libmsda_hip.so, same ABI version."""
+    from uvhand_amd import _ext
+    mod = _ext.get()
+    assert mod is not None
+    assert mod.abi_version() == native.load().msda_version()
+    for name in ("ms_deform_attn_forward", "ms_deform_attn_backward", "apply"):
+        assert callable(getattr(mod, name))

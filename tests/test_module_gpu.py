@@ -322,3 +322,60 @@ def test_module_random_configurations_fused_vs_composed(seed):
         res[fused] = [out.detach(), q.grad, s_.grad, r.grad] + [p.grad.clone() for p in mod.parameters()]
     for x, y in zip(res[True], res[False]):
         assert rel_err(x.cpu().numpy(), y.cpu().numpy()) < 5e-5, (M, L, P, shapes, N, Lq, width)
+
+
+def test_whole_module_forward_backward_in_a_hip_graph():
+    """One MSDeformAttn forward + backward (projections, fused prologue, kernels, weight gradients) captured into a HIP
+    graph and replayed on new data: nothing in the module or the library synchronises, allocates outside the capture
+    pool or reads spatial_shapes back (the shapes-sum assert is skipped during capture — modules/ms_deform_attn.py)."""
+    z = load_golden("module_2d")
+    mod = _module()
+    shapes, lsi = torch.from_numpy(z["shapes"]).cuda(), torch.from_numpy(z["level_start"]).cuda()
+    mask = torch.from_numpy(z["mask"]).cuda()
+    query = torch.zeros_like(torch.from_numpy(z["query"])).cuda().requires_grad_(True)
+    src = torch.zeros_like(torch.from_numpy(z["src"])).cuda().requires_grad_(True)
+    refp = torch.zeros_like(torch.from_numpy(z["refp"])).cuda()
+    gout = torch.zeros_like(torch.from_numpy(z["gout"])).cuda()
+
+    def step():
+        for t in (query, src, *mod.parameters()):
+            t.grad = None
+        out = mod(query, refp, src, shapes, lsi, mask)
+        out.backward(gout)
+        return out
+
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        for _ in range(3):                      # warm-up on the side stream (allocator, hipBLASLt workspaces)
+            step()
+        stream.synchronize()
+        fresh_shapes = shapes.clone()           # a shapes tensor the module has never seen: no read-back during capture
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            for t in (query, src, *mod.parameters()):
+                t.grad = None
+            out = mod(query, refp, src, fresh_shapes, lsi, mask)
+            out.backward(gout)
+        with torch.no_grad():                   # new data into the captured buffers
+            query.copy_(torch.from_numpy(z["query"])); src.copy_(torch.from_numpy(z["src"]))
+            refp.copy_(torch.from_numpy(z["refp"])); gout.copy_(torch.from_numpy(z["gout"]))
+        graph.replay()
+        graph.replay()
+    torch.cuda.synchronize()
+    assert rel_err(out.detach().cpu().numpy(), z["out"]) < 1e-4
+    assert rel_err(query.grad.cpu().numpy(), z["grad_query"]) < 2e-4
+    assert rel_err(src.grad.cpu().numpy(), z["grad_src"]) < 2e-4
+    for name, p in mod.named_parameters():
+        assert rel_err(p.grad.cpu().numpy(), z["pgrad." + name]) < 3e-4, name
+
+
+def test_module_under_inference_mode():
+    """The reference module has no restriction under torch.inference_mode(); the shapes check must not need a version
+    counter (inference tensors have none)."""
+    z = load_golden("module_2d")
+    mod = _module().eval()
+    with torch.inference_mode():
+        args = [torch.from_numpy(z[k]).cuda() for k in ("query", "refp", "src", "shapes", "level_start", "mask")]
+        out = mod(*args)
+        out2 = mod(*args)
+    assert rel_err(out.cpu().numpy(), z["out"]) < 1e-4 and torch.equal(out, out2)

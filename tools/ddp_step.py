@@ -36,38 +36,22 @@ from uvhand_amd.modules import MSDeformAttn         # noqa: E402
 from uvhand_amd.utils import encoder_reference_points  # noqa: E402
 
 
-class EncoderLayer(nn.Module):
-    def __init__(self, d=256, ffn=1024, levels=4, heads=8, points=4):
-        super().__init__()
-        self.self_attn = MSDeformAttn(d, levels, heads, points)
-        self.norm1, self.norm2 = nn.LayerNorm(d), nn.LayerNorm(d)
-        self.linear1, self.linear2 = nn.Linear(d, ffn), nn.Linear(ffn, d)
-
-    def forward(self, src, pos, ref, shapes, lsi):
-        src = self.norm1(src + self.self_attn(src + pos, ref, src, shapes, lsi))
-        return self.norm2(src + self.linear2(torch.relu(self.linear1(src))))
-
-
-class DecoderLayer(nn.Module):
-    def __init__(self, d=256, ffn=1024, levels=4, heads=8, points=4):
-        super().__init__()
-        self.cross_attn = MSDeformAttn(d, levels, heads, points)
-        self.self_attn = nn.MultiheadAttention(d, heads, batch_first=True)
-        self.norm1, self.norm2, self.norm3 = nn.LayerNorm(d), nn.LayerNorm(d), nn.LayerNorm(d)
-        self.linear1, self.linear2 = nn.Linear(d, ffn), nn.Linear(ffn, d)
-
-    def forward(self, tgt, qpos, ref, memory, shapes, lsi):
-        q = tgt + qpos
-        tgt = self.norm2(tgt + self.self_attn(q, q, tgt, need_weights=False)[0])
-        tgt = self.norm1(tgt + self.cross_attn(tgt + qpos, ref, memory, shapes, lsi))
-        return self.norm3(tgt + self.linear2(torch.relu(self.linear1(tgt))))
+def _layer_classes(plain):
+    """The drop-in layers of this package; plain=True swaps their fused add+LayerNorm and the MFMA
+    weight-gradient path of the FFN back to stock PyTorch ops for an A/B run (the attention module stays this package's)."""
+    from uvhand_amd.modules import deformable_layers as dl
+    if plain:
+        dl.add_layer_norm = lambda x, r, norm: norm(x if r is None else x + r)
+        dl.bracket_linear = lambda x, layer: layer(x)
+    return dl.DeformableTransformerEncoderLayer, dl.DeformableTransformerDecoderLayer
 
 
 class SyntheticDeformableStack(nn.Module):
-    def __init__(self, enc, dec, queries, ballast_mb, d=256):
+    def __init__(self, enc, dec, queries, ballast_mb, d=256, dropout=0.1, plain_layers=False):
         super().__init__()
-        self.enc = nn.ModuleList(EncoderLayer(d) for _ in range(enc))
-        self.dec = nn.ModuleList(DecoderLayer(d) for _ in range(dec))
+        EncoderLayer, DecoderLayer = _layer_classes(plain_layers)
+        self.enc = nn.ModuleList(EncoderLayer(d, 1024, dropout) for _ in range(enc))
+        self.dec = nn.ModuleList(DecoderLayer(d, 1024, dropout) for _ in range(dec))
         self.query_embed = nn.Embedding(queries, 2 * d)
         self.ref_head = nn.Linear(d, 2)
         self.out_head = nn.Linear(d, 64)
@@ -100,6 +84,9 @@ def main():
     ap.add_argument("--dec", type=int, default=6)
     ap.add_argument("--ballast-mb", type=float, default=0.0)
     ap.add_argument("--levels", default="28,14,7,4")
+    ap.add_argument("--dropout", type=float, default=0.1, help="util/settings.py:113")
+    ap.add_argument("--plain-layers", action="store_true",
+                    help="A/B: stock add + LayerNorm and stock FFN weight gradients inside the layers")
     ap.add_argument("--amp", default="", choices=["", "bf16"],
                     help="bf16: torch.autocast(bfloat16) around the forward + bf16 row storage in the op (BASELINE config 3)")
     args = ap.parse_args()
@@ -112,7 +99,8 @@ def main():
     distributed = harness.init_process_group(backend, device)
 
     torch.manual_seed(harness.rank_seed(0, 0))                  # identical initial weights on every rank
-    model = SyntheticDeformableStack(args.enc, args.dec, args.queries, args.ballast_mb).to(device)
+    model = SyntheticDeformableStack(args.enc, args.dec, args.queries, args.ballast_mb, dropout=args.dropout,
+                                     plain_layers=args.plain_layers).to(device)
     if distributed:
         model = nn.parallel.DistributedDataParallel(model, device_ids=[dev_index] if backend == "nccl" else None,
                                                     gradient_as_bucket_view=True)
@@ -168,7 +156,8 @@ def main():
         print(json.dumps({"harness": "ddp_step", "n_gpus": world, "frames_per_s": total / elapsed,
                           "ms_per_step": 1e3 * elapsed / args.steps, "steps": args.steps,
                           "per_rank": {"window": args.window, "S": S, "queries": args.queries, "enc": args.enc,
-                                       "dec": args.dec, "ballast_mb": args.ballast_mb, "amp": args.amp or None},
+                                       "dec": args.dec, "ballast_mb": args.ballast_mb, "amp": args.amp or None,
+                                       "dropout": args.dropout, "layers": "plain" if args.plain_layers else "fused"},
                           "backend": backend if distributed else None, "loss_finite": finite,
                           "params_in_sync": in_sync, "ranks": digests}))
     if distributed:

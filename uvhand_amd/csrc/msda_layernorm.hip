@@ -142,20 +142,29 @@ __global__ __launch_bounds__(kLnBlock) void add_layernorm_bwd_kernel(
     }
 }
 
-// dgamma[c] / dbeta[c] = sum over the workgroups' partials, 4 independent chains per column combined in a fixed order.
+// dgamma[c] / dbeta[c] = sum over the workgroups' partials: a 256-thread workgroup takes 16 columns, 16 threads per
+// column each summing every 16th partial (independent load chains), combined through LDS in a fixed order.
 __global__ __launch_bounds__(256) void layernorm_param_reduce_kernel(const float *__restrict__ partial, int nwg, int d,
                                                                     float *__restrict__ dgamma, float *__restrict__ dbeta)
 {
-    __shared__ float red[4][64];
-    const int col = (int)blockIdx.x * 64 + ((int)threadIdx.x & 63), part = (int)threadIdx.x >> 6;
-    const int which = (int)blockIdx.y;
-    float t = 0.f;
-    if (col < d)
-        for (int w = part; w < nwg; w += 4) t += partial[((long long)w * 2 + which) * d + col];
-    red[part][threadIdx.x & 63] = t;
+    __shared__ float red[16][17];
+    const int cl = (int)threadIdx.x & 15, part = (int)threadIdx.x >> 4;
+    const int col = (int)blockIdx.x * 16 + cl, which = (int)blockIdx.y;
+    float t0 = 0.f, t1 = 0.f;
+    if (col < d) {
+        int w = part;
+        for (; w + 16 < nwg; w += 32) {
+            t0 += partial[((long long)w * 2 + which) * d + col];
+            t1 += partial[((long long)(w + 16) * 2 + which) * d + col];
+        }
+        if (w < nwg) t0 += partial[((long long)w * 2 + which) * d + col];
+    }
+    red[part][cl] = t0 + t1;
     __syncthreads();
     if (part == 0 && col < d) {
-        const float s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += red[k][cl];
         (which ? dbeta : dgamma)[col] = s;
     }
 }
@@ -189,7 +198,7 @@ int launch_add_layernorm_bwd(const float *dy, const float *x, const float *res, 
     if (d <= 256) MSDA_LN_B(1); else if (d <= 512) MSDA_LN_B(2); else MSDA_LN_B(4);
 #undef MSDA_LN_B
     if (int rc = check_launch("msda add+layernorm backward")) return rc;
-    hipLaunchKernelGGL(layernorm_param_reduce_kernel, dim3((d + 63) / 64, 2), dim3(256), 0, stream, workspace, nwg, d, dgamma, dbeta);
+    hipLaunchKernelGGL(layernorm_param_reduce_kernel, dim3((d + 15) / 16, 2), dim3(256), 0, stream, workspace, nwg, d, dgamma, dbeta);
     return check_launch("msda layernorm parameter gradients");
 }
 

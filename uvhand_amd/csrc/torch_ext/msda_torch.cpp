@@ -1,0 +1,149 @@
+// _msda_torch — the thin torch extension over the C ABI (include/msda.h) that SURVEY.md §7 step 2 / §8b allow next to
+// the ctypes binding: the same two entry points as the reference's pybind module (UVHand models/ops/src/vision.cpp:13-16,
+// host checks of models/ops/src/cuda/ms_deform_attn_cuda.cu:28-52, 93-117) plus the autograd Function of
+// models/ops/functions/ms_deform_attn_func.py:21-39 as a C++ node, so that an eager forward+backward costs PyTorch's
+// engine and two kernel launches instead of Python-side marshalling (bench.py `eager_ms_per_step`).
+//
+// No kernels here and no torch types beyond this file: every call ends in msda_forward_* / msda_backward_ws_* of
+// libmsda_hip.so with raw device pointers, sizes and the current HIP stream.
+#include <torch/extension.h>
+
+// PyTorch-ROCm presents its HIP devices as DeviceType::CUDA: the guard and the stream are the "masquerading" ones
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+
+#include "msda.h"
+
+namespace {
+
+struct Dims { int N, S, M, D, L, Lq, P; };
+
+void check_inputs(std::initializer_list<std::pair<const char *, const at::Tensor *>> named)
+{
+    const at::Tensor &value = *named.begin()->second;
+    TORCH_CHECK(value.is_cuda(), "Not implemented on the CPU");                          // ms_deform_attn.h:38,60
+    for (auto &nt : named) TORCH_CHECK(nt.second->is_contiguous(), nt.first, " tensor has to be contiguous");
+    for (auto &nt : named) TORCH_CHECK(nt.second->is_cuda(), nt.first, " must be a CUDA tensor");
+    for (auto &nt : named)
+        TORCH_CHECK(nt.second->device() == value.device(), nt.first, " must be on the same device as value (", nt.second->device(),
+                    " vs ", value.device(), ")");
+}
+
+Dims dims(const at::Tensor &value, const at::Tensor &shapes, const at::Tensor &lsi, const at::Tensor &loc, const at::Tensor &attn,
+          int64_t im2col_step)
+{
+    TORCH_CHECK(value.dim() == 4 && loc.dim() == 6 && attn.dim() == 5,
+                "ms_deform_attn: expected value[N,S,M,D], sampling_loc[N,Lq,M,L,P,2], attn_weight[N,Lq,M,L,P]");
+    Dims d;
+    d.N = (int)value.size(0); d.S = (int)value.size(1); d.M = (int)value.size(2); d.D = (int)value.size(3);
+    d.L = (int)shapes.size(0); d.Lq = (int)loc.size(1); d.P = (int)loc.size(4);
+    TORCH_CHECK(loc.sizes() == at::IntArrayRef({d.N, d.Lq, d.M, d.L, d.P, 2}) && attn.sizes() == at::IntArrayRef({d.N, d.Lq, d.M, d.L, d.P}),
+                "ms_deform_attn: sampling_loc ", loc.sizes(), " / attn_weight ", attn.sizes(), " do not match value ", value.sizes(),
+                " and ", d.L, " levels");
+    TORCH_CHECK(shapes.scalar_type() == at::kLong && lsi.scalar_type() == at::kLong,
+                "expected scalar type Long for spatial_shapes / level_start_index");
+    TORCH_CHECK(shapes.dim() == 2 && shapes.size(1) == 2 && lsi.dim() == 1 && lsi.size(0) == d.L,
+                "ms_deform_attn: spatial_shapes must be [L,2] and level_start_index [L]");
+    const int64_t step = std::min<int64_t>(d.N, im2col_step);                            // ms_deform_attn_cuda.cu:50-52
+    TORCH_CHECK(d.N == 0 || (step > 0 && d.N % step == 0), "batch(", d.N, ") must divide im2col_step(", step, ")");
+    TORCH_CHECK(loc.scalar_type() == attn.scalar_type(), "expected sampling_loc and attn_weight to have the same dtype");
+    TORCH_CHECK(value.scalar_type() == loc.scalar_type() && (value.scalar_type() == at::kFloat || value.scalar_type() == at::kDouble),
+                "_msda_torch serves float32 / float64 tensors of one dtype (other cases go through uvhand_amd._native)");
+    return d;
+}
+
+void raise_if(int rc, const char *what)
+{
+    TORCH_CHECK(rc == 0, what, " failed (code ", rc, "): ", msda_last_error());
+}
+
+at::Tensor forward(const at::Tensor &value, const at::Tensor &shapes, const at::Tensor &lsi, const at::Tensor &loc,
+                   const at::Tensor &attn, int64_t im2col_step)
+{
+    check_inputs({{"value", &value}, {"spatial_shapes", &shapes}, {"level_start_index", &lsi}, {"sampling_loc", &loc},
+                  {"attn_weight", &attn}});
+    const Dims d = dims(value, shapes, lsi, loc, attn, im2col_step);
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(value.device());
+    auto out = at::empty({d.N, d.Lq, (int64_t)d.M * d.D}, value.options());
+    auto stream = (msda_stream_t)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(value.device().index()).stream();
+    int rc;
+    if (value.scalar_type() == at::kFloat)
+        rc = msda_forward_f32(value.data_ptr<float>(), shapes.data_ptr<int64_t>(), lsi.data_ptr<int64_t>(), loc.data_ptr<float>(),
+                              attn.data_ptr<float>(), d.N, d.S, d.M, d.D, d.L, d.Lq, d.P, out.data_ptr<float>(), stream);
+    else
+        rc = msda_forward_f64(value.data_ptr<double>(), shapes.data_ptr<int64_t>(), lsi.data_ptr<int64_t>(), loc.data_ptr<double>(),
+                              attn.data_ptr<double>(), d.N, d.S, d.M, d.D, d.L, d.Lq, d.P, out.data_ptr<double>(), stream);
+    raise_if(rc, "ms_deform_attn_forward");
+    return out;
+}
+
+std::vector<at::Tensor> backward(const at::Tensor &value, const at::Tensor &shapes, const at::Tensor &lsi, const at::Tensor &loc,
+                                 const at::Tensor &attn, const at::Tensor &grad_out_in, int64_t im2col_step, bool deterministic)
+{
+    const at::Tensor grad_out = grad_out_in.contiguous();       // the reference asserts it (ms_deform_attn_cuda.cu:98)
+    check_inputs({{"value", &value}, {"spatial_shapes", &shapes}, {"level_start_index", &lsi}, {"sampling_loc", &loc},
+                  {"attn_weight", &attn}, {"grad_output", &grad_out}});
+    const Dims d = dims(value, shapes, lsi, loc, attn, im2col_step);
+    TORCH_CHECK(grad_out.scalar_type() == value.scalar_type() && grad_out.numel() == (int64_t)d.N * d.Lq * d.M * d.D,
+                "ms_deform_attn_backward: grad_output must be ", value.scalar_type(), "[", d.N, ",", d.Lq, ",", d.M * d.D, "]");
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(value.device());
+    auto gv = at::empty_like(value), gl = at::empty_like(loc), ga = at::empty_like(attn);
+    auto stream = (msda_stream_t)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(value.device().index()).stream();
+    int rc;
+    if (value.scalar_type() == at::kFloat) {
+        const unsigned flags = deterministic ? MSDA_FLAG_DETERMINISTIC : 0u;
+        at::Tensor ws;
+        unsigned long long nbytes = flags ? msda_backward_workspace_bytes(d.N, d.S, d.M, d.D, d.L, d.Lq, d.P, flags) : 0;
+        if (nbytes) ws = at::empty({(int64_t)nbytes}, value.options().dtype(at::kByte));
+        rc = msda_backward_ws_f32(grad_out.data_ptr<float>(), value.data_ptr<float>(), shapes.data_ptr<int64_t>(),
+                                  lsi.data_ptr<int64_t>(), loc.data_ptr<float>(), attn.data_ptr<float>(), d.N, d.S, d.M, d.D, d.L,
+                                  d.Lq, d.P, gv.data_ptr<float>(), gl.data_ptr<float>(), ga.data_ptr<float>(),
+                                  nbytes ? ws.data_ptr() : nullptr, nbytes, flags, stream);
+    } else {
+        rc = msda_backward_f64(grad_out.data_ptr<double>(), value.data_ptr<double>(), shapes.data_ptr<int64_t>(),
+                               lsi.data_ptr<int64_t>(), loc.data_ptr<double>(), attn.data_ptr<double>(), d.N, d.S, d.M, d.D, d.L,
+                               d.Lq, d.P, gv.data_ptr<double>(), gl.data_ptr<double>(), ga.data_ptr<double>(), stream);
+    }
+    raise_if(rc, "ms_deform_attn_backward");
+    return {gv, gl, ga};
+}
+
+// models/ops/functions/ms_deform_attn_func.py:21-39 as a C++ autograd node (value cast to the compute dtype in both
+// directions, the un-cast inputs saved, gradients for value / sampling_locations / attention_weights only).
+class MSDAFunction : public torch::autograd::Function<MSDAFunction> {
+public:
+    static at::Tensor forward(torch::autograd::AutogradContext *ctx, const at::Tensor &value, const at::Tensor &shapes,
+                              const at::Tensor &lsi, const at::Tensor &loc, const at::Tensor &attn, int64_t im2col_step,
+                              bool deterministic)
+    {
+        ctx->saved_data["step"] = im2col_step;
+        ctx->saved_data["det"] = deterministic;
+        ctx->save_for_backward({value, shapes, lsi, loc, attn});
+        return ::forward(value.to(loc.scalar_type()), shapes, lsi, loc, attn, im2col_step);
+    }
+
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext *ctx, torch::autograd::variable_list grads)
+    {
+        const auto saved = ctx->get_saved_variables();
+        const auto g = ::backward(saved[0].to(saved[3].scalar_type()), saved[1], saved[2], saved[3], saved[4], grads[0],
+                                  ctx->saved_data["step"].toInt(), ctx->saved_data["det"].toBool());
+        return {g[0], at::Tensor(), at::Tensor(), g[1], g[2], at::Tensor(), at::Tensor()};
+    }
+};
+
+at::Tensor apply(const at::Tensor &value, const at::Tensor &shapes, const at::Tensor &lsi, const at::Tensor &loc,
+                 const at::Tensor &attn, int64_t im2col_step, bool deterministic)
+{
+    return MSDAFunction::apply(value, shapes, lsi, loc, attn, im2col_step, deterministic);
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
+{
+    m.doc() = "torch extension over libmsda_hip.so (C ABI include/msda.h)";
+    m.def("ms_deform_attn_forward", &forward, "replaces MSDA.ms_deform_attn_forward (vision.cpp:14)");
+    m.def("ms_deform_attn_backward", &backward, "replaces MSDA.ms_deform_attn_backward (vision.cpp:15)");
+    m.def("apply", &apply, "MSDeformAttnFunction.apply as a C++ autograd node");
+    m.def("abi_version", [] { return msda_version(); });
+}

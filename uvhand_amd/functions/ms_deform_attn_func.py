@@ -22,10 +22,29 @@ import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
+from .. import _ext
 from .. import _native as MSDA
+
+_EXT_DTYPES = (torch.float32, torch.float64)
 
 
 class MSDeformAttnFunction(Function):
+    @classmethod
+    def apply(cls, value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights,
+              im2col_step):
+        """Same node, two hosts: when the torch extension is built (``_ext``) and the tensors are the common case —
+        CUDA, one floating dtype — the forward/backward pair below runs as a C++ autograd node that calls the same
+        C ABI; otherwise (bf16/fp16 value, CPU tensors -> the reference's error, extension not built) this Python class."""
+        ext = _ext.get()
+        if (ext is not None and torch.is_tensor(value) and value.is_cuda and value.dtype in _EXT_DTYPES
+                and torch.is_tensor(sampling_locations) and sampling_locations.dtype == value.dtype
+                and torch.is_tensor(attention_weights) and attention_weights.dtype == value.dtype
+                and not torch.is_autocast_enabled()):
+            return ext.apply(value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights,
+                             int(im2col_step), MSDA.deterministic_requested())
+        return super().apply(value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights,
+                             im2col_step)
+
     @staticmethod
     def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations,
                 attention_weights, im2col_step):
