@@ -198,6 +198,20 @@ int msda_backward_prologue_ws_f32(const float *grad_out, const float *value, con
                                   float *grad_attn_logits, float *grad_reference_points, void *workspace,
                                   unsigned long long workspace_bytes, unsigned flags, msda_stream_t stream);
 
+/* bf16 rows through the fused prologue (value / out / grad_out in bf16; offsets, logits, reference points and EVERY
+ * gradient in fp32 — grad_value too: its passes accumulate in fp32 and a caller whose value_proj runs in fp32 wants it so).
+ * Same geometry rule (msda_prologue_supported), same row strides, same flags / workspace as the f32 entry points. */
+int msda_forward_prologue_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                               const float *reference_points, const float *sampling_offsets, const float *attn_logits,
+                               int N, int S, int M, int D, int L, int Lq, int P, long long ld_offsets, long long ld_logits,
+                               uint16_t *out, float *sampling_loc_out, float *attn_weight_out, msda_stream_t stream);
+int msda_backward_prologue_bf16_gv32(const uint16_t *grad_out, const uint16_t *value, const int64_t *spatial_shapes,
+                                     const int64_t *level_start, const float *sampling_loc, const float *attn_weight,
+                                     int N, int S, int M, int D, int L, int Lq, int P, long long ld_grad_offsets,
+                                     long long ld_grad_logits, float *grad_value, float *grad_sampling_offsets,
+                                     float *grad_attn_logits, float *grad_reference_points, void *workspace,
+                                     unsigned long long workspace_bytes, unsigned flags, msda_stream_t stream);
+
 /* ---- Bracketing projections ----------------------------------------------------
  * Weight and bias gradient of an fp32 nn.Linear  y[M,N] = x[M,K] . W[N,K]^T + b[N]:
  *     grad_weight[N,K] = grad_out[M,N]^T . input[M,K]        grad_bias[N] = sum_m grad_out[m,:]

@@ -89,17 +89,56 @@ def test_module_runs_under_autocast_like_reference():
     assert rel_err(out.float().detach().cpu().numpy(), ref.detach().cpu().numpy()) < 2e-2
 
 
-def test_module_bf16_storage_option():
-    mod = _module()
+@pytest.mark.parametrize("autocast", [False, True])
+def test_module_bf16_storage_takes_the_fused_path_and_tracks_fp32(autocast, monkeypatch):
+    """bf16_storage keeps the fast module path (fused prologue on bf16 rows + merged projection, msda_*_prologue_bf16*):
+    forward and EVERY gradient within bf16 tolerance of the fp32 module (2e-2 of each tensor's max: one rounding of value,
+    of the sampled output and of grad_out to 8 significant bits; locations, weights and accumulation stay fp32)."""
+    from uvhand_amd import _native
+    calls = {"fwd": 0, "bwd": 0}
+    for name, key in (("ms_deform_attn_forward_prologue", "fwd"), ("ms_deform_attn_backward_prologue", "bwd")):
+        orig = getattr(_native, name)
+
+        def wrapped(*a, _o=orig, _k=key, **kw):
+            assert a[0].dtype == torch.bfloat16                      # rows really are bf16
+            calls[_k] += 1
+            return _o(*a, **kw)
+        monkeypatch.setattr(_native, name, wrapped)
     z = load_golden("module_2d")
-    args = [torch.from_numpy(z[k]).cuda() for k in ("query", "refp", "src", "shapes", "level_start")]
-    ref = mod(*args)
-    mod.bf16_storage = True
-    q = args[0].clone().requires_grad_(True)
-    out = mod(q, *args[1:])
-    out.sum().backward()
-    assert out.dtype == torch.float32 and torch.isfinite(q.grad).all()
-    assert rel_err(out.detach().cpu().numpy(), ref.detach().cpu().numpy()) < 1e-2
+    tensors = lambda: [torch.from_numpy(z[k]).cuda() for k in ("query", "refp", "src", "shapes", "level_start", "mask")]
+
+    def run(bf16):
+        mod = _module()
+        mod.bf16_storage = bf16
+        a = tensors()
+        a[0].requires_grad_(True); a[2].requires_grad_(True)
+        if bf16 and autocast:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = mod(*a)
+        else:
+            out = mod(*a)
+        out.float().backward(torch.from_numpy(z["gout"]).cuda())
+        return out.float().detach(), a[0].grad, a[2].grad, {n: p.grad for n, p in mod.named_parameters()}
+
+    monkeypatch.undo()
+    ref = run(False)
+    for name, key in (("ms_deform_attn_forward_prologue", "fwd"), ("ms_deform_attn_backward_prologue", "bwd")):
+        orig = getattr(_native, name)
+
+        def wrapped(*a, _o=orig, _k=key, **kw):
+            assert a[0].dtype == torch.bfloat16
+            calls[_k] += 1
+            return _o(*a, **kw)
+        monkeypatch.setattr(_native, name, wrapped)
+    got = run(True)
+    assert calls == {"fwd": 1, "bwd": 1}
+    tol = 4e-2 if autocast else 2e-2                                 # autocast also runs the value / output GEMMs in bf16
+    assert rel_err(got[0].cpu().numpy(), ref[0].cpu().numpy()) < tol
+    assert rel_err(got[1].cpu().numpy(), ref[1].cpu().numpy()) < tol
+    assert rel_err(got[2].cpu().numpy(), ref[2].cpu().numpy()) < tol
+    for n in ref[3]:
+        assert got[3][n].dtype == torch.float32
+        assert rel_err(got[3][n].cpu().numpy(), ref[3][n].cpu().numpy()) < tol, n
 
 
 # ---------------------------------------------------------------------------------------------

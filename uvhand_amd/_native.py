@@ -24,7 +24,7 @@ _SYMBOLS = (
     "msda_forward_f32", "msda_backward_f32", "msda_forward_f64", "msda_backward_f64",
     "msda_forward_bf16", "msda_backward_bf16", "msda_backward_bf16_gv32", "msda_backward_passes",
     "msda_backward_workspace_bytes", "msda_backward_ws_f32", "msda_backward_ws_bf16", "msda_backward_ws_bf16_gv32",
-    "msda_backward_prologue_ws_f32",
+    "msda_backward_prologue_ws_f32", "msda_forward_prologue_bf16", "msda_backward_prologue_bf16_gv32",
     "msda_add_layernorm_workspace_bytes", "msda_add_layernorm_forward_f32", "msda_add_layernorm_backward_f32",
     "msda_linear_wgrad_f32", "msda_linear_wgrad_masked_f32", "msda_linear_wgrad_workspace_bytes",
     "msda_zero_masked_rows_f32",
@@ -389,8 +389,9 @@ def ms_deform_attn_forward_prologue(value, spatial_shapes, level_start_index, re
             or tuple(reference_points.shape) != (N, Lq, L, 2) or tuple(spatial_shapes.shape) != (L, 2)
             or tuple(level_start_index.shape) != (L,)):
         raise RuntimeError("ms_deform_attn_forward_prologue: inconsistent shapes")
-    _check_prologue_dtypes(spatial_shapes, level_start_index, value=value, reference_points=reference_points,
-                           sampling_offsets=sampling_offsets, attn_logits=attn_logits)
+    bf16 = value.dtype == torch.bfloat16
+    _check_prologue_dtypes(spatial_shapes, level_start_index, reference_points=reference_points,
+                           sampling_offsets=sampling_offsets, attn_logits=attn_logits, **({} if bf16 else {"value": value}))
     ld_off, ld_log = _row_stride(sampling_offsets, "sampling_offsets"), _row_stride(attn_logits, "attn_logits")
     if reference_points.data_ptr() % 8:                      # a contiguous view at an odd element offset
         reference_points = reference_points.clone()
@@ -398,10 +399,10 @@ def ms_deform_attn_forward_prologue(value, spatial_shapes, level_start_index, re
     if N > 0 and (step <= 0 or N % step != 0):
         raise RuntimeError("batch(%d) must divide im2col_step(%d)" % (N, step))
     with _DeviceGuard(value.device):
-        out = torch.empty((N, Lq, M * D), dtype=torch.float32, device=value.device)
+        out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
         loc = torch.empty((N, Lq, M, L, P, 2), dtype=torch.float32, device=value.device)
         attn = torch.empty((N, Lq, M, L, P), dtype=torch.float32, device=value.device)
-        rc = _entry(lib, "msda_forward_prologue_f32", [_VP] * 6 + [_CI] * 7 + [_LL] * 2 + [_VP] * 4)(
+        rc = _entry(lib, "msda_forward_prologue_" + ("bf16" if bf16 else "f32"), [_VP] * 6 + [_CI] * 7 + [_LL] * 2 + [_VP] * 4)(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), reference_points.data_ptr(),
             sampling_offsets.data_ptr(), attn_logits.data_ptr(), N, S, M, D, L, Lq, P, ld_off, ld_log, out.data_ptr(),
             loc.data_ptr(), attn.data_ptr(), _raw_stream(value.device))
@@ -412,7 +413,8 @@ def ms_deform_attn_forward_prologue(value, spatial_shapes, level_start_index, re
 
 def ms_deform_attn_backward_prologue(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output,
                                      merged=False, deterministic=None):
-    """Returns (grad_value, grad_sampling_offsets, grad_attn_logits[N,Lq,M,L*P], grad_reference_points[N,Lq,L,2]).
+    """Returns (grad_value (float32, also for bf16 rows), grad_sampling_offsets, grad_attn_logits[N,Lq,M,L*P],
+    grad_reference_points[N,Lq,L,2]).
     merged=True: the two raw gradients are the column blocks [0, 2*M*L*P) and [2*M*L*P, 3*M*L*P) of ONE
     [N, Lq, 3*M*L*P] tensor — the gradient of a merged offsets+logits projection — returned as a fifth value."""
     lib = _lib or load()
@@ -420,13 +422,16 @@ def ms_deform_attn_backward_prologue(value, spatial_shapes, level_start_index, s
                    ("sampling_loc", sampling_loc), ("attn_weight", attn_weight), ("grad_output", grad_output)))
     # same checks as the plain backward (the kernels reinterpret device memory: a wrong dtype is silent garbage)
     N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, max(1, value.shape[0]))
-    _check_prologue_dtypes(spatial_shapes, level_start_index, value=value, sampling_loc=sampling_loc,
-                           attn_weight=attn_weight, grad_output=grad_output)
+    bf16 = value.dtype == torch.bfloat16
+    _check_prologue_dtypes(spatial_shapes, level_start_index, sampling_loc=sampling_loc, attn_weight=attn_weight,
+                           **({} if bf16 else {"value": value, "grad_output": grad_output}))
+    if bf16 and grad_output.dtype != torch.bfloat16:
+        raise RuntimeError("expected scalar type BFloat16 for grad_output (bf16 rows)")
     if grad_output.numel() != N * Lq * M * D:
         raise RuntimeError("ms_deform_attn_backward_prologue: grad_output must be float32[%d,%d,%d]" % (N, Lq, M * D))
     mlp = M * L * P
     with _DeviceGuard(value.device):
-        gv = torch.empty_like(value)
+        gv = torch.empty_like(value, dtype=torch.float32)          # fp32 also for bf16 rows (msda_backward_prologue_bf16_gv32)
         if merged:
             both = torch.empty((N, Lq, 3 * mlp), dtype=torch.float32, device=value.device)
             goff, glog = both[..., :2 * mlp].view(N, Lq, M, L, P, 2), both[..., 2 * mlp:].view(N, Lq, M, L * P)
@@ -439,7 +444,7 @@ def ms_deform_attn_backward_prologue(value, spatial_shapes, level_start_index, s
         gref = torch.empty((N, Lq, L, 2), dtype=torch.float32, device=value.device)
         det = deterministic_requested() if deterministic is None else bool(deterministic)
         ws, nbytes = _backward_workspace(lib, N, S, M, D, L, Lq, P, value.device) if det else (None, 0)
-        rc = _entry(lib, "msda_backward_prologue_ws_f32",
+        rc = _entry(lib, "msda_backward_prologue_bf16_gv32" if bf16 else "msda_backward_prologue_ws_f32",
                     [_VP] * 6 + [_CI] * 7 + [_LL] * 2 + [_VP] * 5 + [ctypes.c_ulonglong, ctypes.c_uint, _VP])(
             grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
             sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P, ld_off, ld_log, gv.data_ptr(),

@@ -360,6 +360,50 @@ int msda_backward_prologue_ws_f32(const float *grad_out, const float *value, con
                                      (size_t)workspace_bytes, (flags & MSDA_FLAG_DETERMINISTIC) != 0);
 }
 
+int msda_forward_prologue_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                               const float *reference_points, const float *sampling_offsets, const float *attn_logits,
+                               int N, int S, int M, int D, int L, int Lq, int P, long long ld_offsets, long long ld_logits,
+                               uint16_t *out, float *sampling_loc_out, float *attn_weight_out, msda_stream_t stream)
+{
+    const void *ptrs[] = {value, spatial_shapes, level_start, reference_points, sampling_offsets, attn_logits, out,
+                          sampling_loc_out, attn_weight_out};
+    if (int rc = msda::check_args(ptrs, 9, N, S, M, D, L, Lq, P)) return rc;
+    if (!msda_prologue_supported(N, S, M, D, L, Lq, P))
+        return msda::set_error(MSDA_ERR_ARGUMENT, "msda_forward_prologue_bf16: geometry not supported (msda_prologue_supported)");
+    if (int rc = msda::check_row_strides("msda_forward_prologue_bf16", M, L, P, sampling_offsets, &ld_offsets, &ld_logits)) return rc;
+    if (!msda::aligned_to(value, 8) || !msda::aligned_to(out, 8) || !msda::aligned_to(reference_points, 8) ||
+        !msda::aligned_to(sampling_loc_out, 8))
+        return msda::refuse_unaligned("msda_forward_prologue_bf16");
+    msda::begin_call();
+    return msda::launch_fwd_prologue_bf16(value, spatial_shapes, level_start, reference_points, sampling_offsets, attn_logits,
+                                          N, S, M, L, Lq, P, ld_offsets, ld_logits, out, sampling_loc_out, attn_weight_out,
+                                          (hipStream_t)stream);
+}
+
+int msda_backward_prologue_bf16_gv32(const uint16_t *grad_out, const uint16_t *value, const int64_t *spatial_shapes,
+                                     const int64_t *level_start, const float *sampling_loc, const float *attn_weight, int N,
+                                     int S, int M, int D, int L, int Lq, int P, long long ld_grad_offsets,
+                                     long long ld_grad_logits, float *grad_value, float *grad_sampling_offsets,
+                                     float *grad_attn_logits, float *grad_reference_points, void *workspace,
+                                     unsigned long long workspace_bytes, unsigned flags, msda_stream_t stream)
+{
+    const void *ptrs[] = {grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, grad_value,
+                          grad_sampling_offsets, grad_attn_logits, grad_reference_points};
+    if (int rc = msda::check_args(ptrs, 10, N, S, M, D, L, Lq, P)) return rc;
+    if (!msda_prologue_supported(N, S, M, D, L, Lq, P))
+        return msda::set_error(MSDA_ERR_ARGUMENT, "msda_backward_prologue_bf16_gv32: geometry not supported (msda_prologue_supported)");
+    if (int rc = msda::check_row_strides("msda_backward_prologue_bf16_gv32", M, L, P, grad_sampling_offsets, &ld_grad_offsets,
+                                         &ld_grad_logits)) return rc;
+    if (!msda::aligned_to(grad_out, 8) || !msda::aligned_to(value, 8) || !msda::aligned_to(grad_value, 16) ||
+        !msda::aligned_to(sampling_loc, 8) || !msda::aligned_to(grad_reference_points, 8))
+        return msda::refuse_unaligned("msda_backward_prologue_bf16_gv32");
+    msda::begin_call();
+    return msda::launch_bwd_prologue_bf16(grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M, L,
+                                          Lq, P, grad_value, ld_grad_offsets, ld_grad_logits, grad_sampling_offsets,
+                                          grad_attn_logits, grad_reference_points, (hipStream_t)stream, workspace,
+                                          (size_t)workspace_bytes, (flags & MSDA_FLAG_DETERMINISTIC) != 0);
+}
+
 unsigned long long msda_linear_wgrad_workspace_bytes(int M, int N, int K)
 {
     if (M <= 0 || N <= 0 || K <= 0) return 0;

@@ -1210,10 +1210,11 @@ bool prologue_supported(int N, int S, int M, int D, int L, int Lq, int P)
     return !plain_modes;                                                        // A/B knobs select the unfused kernels
 }
 
-int launch_fwd_prologue(const float *value, const int64_t *shapes, const int64_t *level_start, const float *ref,
-                        const float *offsets, const float *logits, int N, int S, int M, int L, int Lq, int P,
-                        long long ld_offsets, long long ld_logits, float *out, float *loc_out, float *attn_out,
-                        hipStream_t stream)
+template <typename VT>
+static int launch_fwd_prologue_t(const VT *value, const int64_t *shapes, const int64_t *level_start, const float *ref,
+                                 const float *offsets, const float *logits, int N, int S, int M, int L, int Lq, int P,
+                                 long long ld_offsets, long long ld_logits, VT *out, float *loc_out, float *attn_out,
+                                 hipStream_t stream)
 {
     const int items = N * Lq * M, LP = L * P;
     const int item_stride = LP * kRecBytes + kItemPad;
@@ -1224,24 +1225,26 @@ int launch_fwd_prologue(const float *value, const int64_t *shapes, const int64_t
     const PrologueIn pro{ref, loc_out, attn_out, (int)((ld_offsets - 2LL * M * LP) / 2), (int)(ld_logits - (long long)M * LP)};
     const int xcd = xcd_remap();
 #define MSDA_LAUNCH_FP(SP)                                                                             \
-    hipLaunchKernelGGL((fwd_d32_kernel<SP, float, true>), grid, block, lds, stream, value, shapes, level_start, offsets, \
+    hipLaunchKernelGGL((fwd_d32_kernel<SP, VT, true>), grid, block, lds, stream, value, shapes, level_start, offsets, \
                        logits, S, M, L, Lq, P, items, pow2_shift(P), pow2_shift(LP), pow2_shift(M), out, pro, xcd)
     if (split == 4) MSDA_LAUNCH_FP(4); else if (split == 2) MSDA_LAUNCH_FP(2); else MSDA_LAUNCH_FP(1);
 #undef MSDA_LAUNCH_FP
     return check_launch("msda forward (d32, fused prologue)");
 }
 
-int launch_bwd_prologue(const float *grad_out, const float *value, const int64_t *shapes, const int64_t *level_start,
-                        const float *loc, const float *attn, int N, int S, int M, int L, int Lq, int P, float *grad_value,
-                        long long ld_grad_offsets, long long ld_grad_logits, float *grad_offsets, float *grad_logits,
-                        float *grad_ref, hipStream_t stream, void *workspace, size_t ws_bytes, bool deterministic)
+// VT = storage of grad_out / value; grad_value is fp32 for both (bf16 rows: nothing rounded between passes)
+template <typename VT>
+static int launch_bwd_prologue_t(const VT *grad_out, const VT *value, const int64_t *shapes, const int64_t *level_start,
+                                 const float *loc, const float *attn, int N, int S, int M, int L, int Lq, int P, float *grad_value,
+                                 long long ld_grad_offsets, long long ld_grad_logits, float *grad_offsets, float *grad_logits,
+                                 float *grad_ref, hipStream_t stream, void *workspace, size_t ws_bytes, bool deterministic)
 {
     const int items = N * Lq * M, LP = L * P;
     const int item_stride = LP * kRecBytes + kItemPad;
     const PrologueOut pro_c{grad_ref, (int)((ld_grad_offsets - 2LL * M * LP) / 2), (int)(ld_grad_logits - (long long)M * LP)};
     if (deterministic)
-        return launch_bwd_cells_t<float, float, true>(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P,
-                                                      grad_value, grad_offsets, grad_logits, pro_c, workspace, ws_bytes, stream);
+        return launch_bwd_cells_t<VT, float, true>(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P,
+                                                   grad_value, grad_offsets, grad_logits, pro_c, workspace, ws_bytes, stream);
     const int split = pick_split(items, LP);
     const int ps = pow2_shift(P), lps = pow2_shift(LP), ms = pow2_shift(M);
     const ValuePlan pl = plan_value<float>(N, S, M, L, Lq, P, bwd_target_wgs());
@@ -1256,8 +1259,8 @@ int launch_bwd_prologue(const float *grad_out, const float *value, const int64_t
     const size_t flds = pl.lds > lds_a ? pl.lds : lds_a;
     const PrologueOut pro{grad_ref, (int)((ld_grad_offsets - 2LL * M * LP) / 2), (int)(ld_grad_logits - (long long)M * LP)};
 #define MSDA_LAUNCH_BP(SP, AC, FX)                                                                     \
-    do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_fused_d32_kernel<SP, AC, float, true, float, FX>), flds)) return rc; \
-    hipLaunchKernelGGL((bwd_fused_d32_kernel<SP, AC, float, true, float, FX>), fgrid, dim3(kSBlock), flds, stream, grad_out, \
+    do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_fused_d32_kernel<SP, AC, VT, true, float, FX>), flds)) return rc; \
+    hipLaunchKernelGGL((bwd_fused_d32_kernel<SP, AC, VT, true, float, FX>), fgrid, dim3(kSBlock), flds, stream, grad_out, \
                        value, shapes, level_start, loc, attn, S, M, L, Lq, P, items, ps, lps, ms, pl.tp_cap, pl.W, (int)nB,  \
                        grad_value, grad_offsets, grad_logits, pro, xcd_remap()); } while (0)
     if (fp.fixed)                { if (fp.split == 4) MSDA_LAUNCH_BP(4, kAccNone, true); else if (fp.split == 2) MSDA_LAUNCH_BP(2, kAccNone, true); else MSDA_LAUNCH_BP(1, kAccNone, true); }
@@ -1265,6 +1268,41 @@ int launch_bwd_prologue(const float *grad_out, const float *value, const int64_t
     else                         { if (fp.split == 4) MSDA_LAUNCH_BP(4, kAccRmw, false); else if (fp.split == 2) MSDA_LAUNCH_BP(2, kAccRmw, false); else MSDA_LAUNCH_BP(1, kAccRmw, false); }
 #undef MSDA_LAUNCH_BP
     return check_launch("msda backward (d32, fused prologue)");
+}
+
+int launch_fwd_prologue(const float *value, const int64_t *shapes, const int64_t *level_start, const float *ref,
+                        const float *offsets, const float *logits, int N, int S, int M, int L, int Lq, int P,
+                        long long ld_offsets, long long ld_logits, float *out, float *loc_out, float *attn_out,
+                        hipStream_t stream)
+{
+    return launch_fwd_prologue_t<float>(value, shapes, level_start, ref, offsets, logits, N, S, M, L, Lq, P, ld_offsets, ld_logits,
+                                        out, loc_out, attn_out, stream);
+}
+int launch_fwd_prologue_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *level_start, const float *ref,
+                             const float *offsets, const float *logits, int N, int S, int M, int L, int Lq, int P,
+                             long long ld_offsets, long long ld_logits, uint16_t *out, float *loc_out, float *attn_out,
+                             hipStream_t stream)
+{
+    return launch_fwd_prologue_t<bf16_t>(value, shapes, level_start, ref, offsets, logits, N, S, M, L, Lq, P, ld_offsets, ld_logits,
+                                         out, loc_out, attn_out, stream);
+}
+int launch_bwd_prologue(const float *grad_out, const float *value, const int64_t *shapes, const int64_t *level_start,
+                        const float *loc, const float *attn, int N, int S, int M, int L, int Lq, int P, float *grad_value,
+                        long long ld_grad_offsets, long long ld_grad_logits, float *grad_offsets, float *grad_logits,
+                        float *grad_ref, hipStream_t stream, void *workspace, size_t ws_bytes, bool deterministic)
+{
+    return launch_bwd_prologue_t<float>(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, grad_value,
+                                        ld_grad_offsets, ld_grad_logits, grad_offsets, grad_logits, grad_ref, stream, workspace,
+                                        ws_bytes, deterministic);
+}
+int launch_bwd_prologue_bf16(const uint16_t *grad_out, const uint16_t *value, const int64_t *shapes, const int64_t *level_start,
+                             const float *loc, const float *attn, int N, int S, int M, int L, int Lq, int P, float *grad_value,
+                             long long ld_grad_offsets, long long ld_grad_logits, float *grad_offsets, float *grad_logits,
+                             float *grad_ref, hipStream_t stream, void *workspace, size_t ws_bytes, bool deterministic)
+{
+    return launch_bwd_prologue_t<bf16_t>(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, grad_value,
+                                         ld_grad_offsets, ld_grad_logits, grad_offsets, grad_logits, grad_ref, stream, workspace,
+                                         ws_bytes, deterministic);
 }
 
 int launch_fwd_d32(const float *value, const int64_t *shapes, const int64_t *level_start, const float *loc,

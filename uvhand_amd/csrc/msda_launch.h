@@ -79,6 +79,17 @@ int launch_bwd_prologue(const float *grad_out, const float *value, const int64_t
                         long long ld_grad_offsets, long long ld_grad_logits, float *grad_offsets, float *grad_logits,
                         float *grad_ref, hipStream_t stream, void *workspace = nullptr, size_t ws_bytes = 0, bool deterministic = false);
 
+// bf16 rows (value, out, grad_out); offsets / logits / reference points and every gradient fp32 (grad_value included)
+int launch_fwd_prologue_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *level_start, const float *ref,
+                             const float *offsets, const float *logits, int N, int S, int M, int L, int Lq, int P,
+                             long long ld_offsets, long long ld_logits, uint16_t *out, float *loc_out, float *attn_out,
+                             hipStream_t stream);
+int launch_bwd_prologue_bf16(const uint16_t *grad_out, const uint16_t *value, const int64_t *shapes, const int64_t *level_start,
+                             const float *loc, const float *attn, int N, int S, int M, int L, int Lq, int P, float *grad_value,
+                             long long ld_grad_offsets, long long ld_grad_logits, float *grad_offsets, float *grad_logits,
+                             float *grad_ref, hipStream_t stream, void *workspace = nullptr, size_t ws_bytes = 0,
+                             bool deterministic = false);
+
 // ---- weight / bias gradient of the bracketing nn.Linear layers (msda_linear.hip) -----------------
 size_t linear_wgrad_workspace_bytes(int M, int N, int K);
 // row_mask (may be null): one byte per row of dY, non-zero = that row counts as zero

@@ -146,33 +146,40 @@ class MSDeformAttnMergedPrologueFunction(Function):
     read the same ``query``):
 
         out = apply(value, spatial_shapes, level_start_index, reference_points[N,Lq,L,2],
-                    projected[N,Lq,3*M*L*P], im2col_step, M, L, P)
+                    projected[N,Lq,3*M*L*P], im2col_step, M, L, P, bf16_rows=False)
 
     ``projected[..., :2*M*L*P]`` are the raw offsets ([M,L,P,2] order), the rest the logits ([M,L*P]); the
     kernels read both in place (row stride 3*M*L*P) and the backward writes their gradients into one tensor
     of the same layout, so the projection's backward is one input-gradient GEMM and one weight-gradient GEMM
-    instead of two of each plus an add."""
+    instead of two of each plus an add.
+
+    ``bf16_rows`` (BASELINE config 3; no reference counterpart): ``value`` is rounded to bfloat16 here (or taken as it
+    is if already bfloat16, e.g. under autocast), the sampled output comes back in bfloat16, the backward reads
+    bfloat16 rows and returns ``grad_value`` in float32 — accumulated in float32, rounded nowhere — cast to
+    ``value``'s dtype only if that was bfloat16.  Offsets, logits, reference points and their gradients stay float32."""
 
     @staticmethod
     def forward(ctx, value, value_spatial_shapes, value_level_start_index, reference_points, projected, im2col_step,
-                n_heads, n_levels, n_points):
+                n_heads, n_levels, n_points, bf16_rows=False):
         N, Lq, width = projected.shape
         mlp = n_heads * n_levels * n_points
         if width != 3 * mlp:
             raise RuntimeError("projected tensor must hold 2*M*L*P offsets and M*L*P logits per query (got %d, "
                                "expected %d)" % (width, 3 * mlp))
         projected = projected.contiguous()
+        rows = value.to(torch.bfloat16) if bf16_rows else value
         out, loc, attn = MSDA.ms_deform_attn_forward_prologue(
-            value, value_spatial_shapes, value_level_start_index, reference_points.contiguous(),
+            rows, value_spatial_shapes, value_level_start_index, reference_points.contiguous(),
             projected[..., :2 * mlp].view(N, Lq, n_heads, n_levels, n_points, 2),
             projected[..., 2 * mlp:].view(N, Lq, n_heads, n_levels * n_points), im2col_step)
-        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, loc, attn)
+        ctx.save_for_backward(rows, value_spatial_shapes, value_level_start_index, loc, attn)
+        ctx.value_dtype = value.dtype
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_output):
-        value, value_spatial_shapes, value_level_start_index, loc, attn = ctx.saved_tensors
+        rows, value_spatial_shapes, value_level_start_index, loc, attn = ctx.saved_tensors
         gv, _, _, gref, gproj = MSDA.ms_deform_attn_backward_prologue(
-            value, value_spatial_shapes, value_level_start_index, loc, attn, grad_output.contiguous(), merged=True)
-        return gv, None, None, gref, gproj, None, None, None, None
+            rows, value_spatial_shapes, value_level_start_index, loc, attn, grad_output.to(rows.dtype).contiguous(), merged=True)
+        return gv.to(ctx.value_dtype), None, None, gref, gproj, None, None, None, None, None

@@ -145,21 +145,29 @@ class MSDeformAttn(nn.Module):
         value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
         ref_dim = reference_points.shape[-1]
 
-        if (self.fused_prologue and self.merged_projection and not self.bf16_storage and ref_dim in (2, 42)
-                and value.is_cuda and value.dtype == torch.float32 and query.dtype == torch.float32
-                and reference_points.dtype == torch.float32 and not torch.is_autocast_enabled()
+        if (self.fused_prologue and self.merged_projection and ref_dim in (2, 42) and value.is_cuda
+                # fp32 throughout, or bf16 rows (then also under autocast: the query projection is pinned to fp32 below)
+                and ((value.dtype == torch.float32 and query.dtype == torch.float32
+                      and reference_points.dtype == torch.float32 and not torch.is_autocast_enabled())
+                     or (self.bf16_storage and value.dtype in (torch.float32, torch.bfloat16)))
                 # the kernels move (x, y) pairs as 8 bytes: the offsets block starts every 3*M*L*P floats
                 and (self.n_heads * self.n_levels * self.n_points) % 2 == 0
                 and _native.prologue_geometry_supported(N, Len_in, self.n_heads, self.d_model // self.n_heads,
                                                         self.n_levels, Len_q, self.n_points)):
-            centre = reference_points if ref_dim == 2 else torch.stack(
-                [reference_points[..., 0::2].mean(-1), reference_points[..., 1::2].mean(-1)], -1)
-            projected = bracket_linear_wb(
-                query, torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0),
-                torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0))
-            output = MSDeformAttnMergedPrologueFunction.apply(
-                value, input_spatial_shapes, input_level_start_index, centre, projected, self.im2col_step,
-                self.n_heads, self.n_levels, self.n_points)
+            autocast = torch.is_autocast_enabled()
+            with torch.autocast("cuda", enabled=False):
+                # sampling offsets, logits and reference points stay float32 whatever the rows are stored as: a bf16
+                # location has a resolution of 0.2 pixel on a 48-pixel map
+                ref32 = reference_points.float()
+                centre = ref32 if ref_dim == 2 else torch.stack([ref32[..., 0::2].mean(-1), ref32[..., 1::2].mean(-1)], -1)
+                projected = bracket_linear_wb(
+                    query.float(), torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0).float(),
+                    torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0).float())
+                output = MSDeformAttnMergedPrologueFunction.apply(
+                    value, input_spatial_shapes, input_level_start_index, centre, projected, self.im2col_step,
+                    self.n_heads, self.n_levels, self.n_points, self.bf16_storage)
+            if self.bf16_storage and not autocast:
+                output = output.to(self.output_proj.weight.dtype)
             return bracket_linear(output, self.output_proj)
 
         sampling_offsets = bracket_linear(query, self.sampling_offsets).view(
