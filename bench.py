@@ -367,7 +367,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "backward: msda::bwd_fused_d32_kernel (grad_value sort+gather "
                                                     "workgroups and grad_loc/grad_attn workgroups in one launch)",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(args.workload, "bwd") if not bf16 else None, "algorithmic_bytes": bwd_b, "ms": kt["bwd"]},
+                         "traffic": pmc_traffic(args.workload + ("_bf16" if bf16 else ""), "bwd"), "algorithmic_bytes": bwd_b,
+                         "ms": kt["bwd"]},
             "kernels": {"fwd": {"ms": kt["fwd"], "algorithmic_bytes": fwd_b,
                                 "GBps": fwd_b / (kt["fwd"] * 1e-3) / 1e9},
                         "bwd": {"ms": kt["bwd"], "algorithmic_bytes": bwd_b, "GBps": ach}},

@@ -1,6 +1,6 @@
 // Standalone kernel harness for the D=32 kernels (diagnostic; not part of the library).
 // Unity build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -DMSDA_STAMPS \
-//                 -Iinclude -Iuvhand_amd/csrc tools/micro/kbench.cpp -o tools/micro/kbench
+//                 -DMSDA_TUNING -Iinclude -Iuvhand_amd/csrc tools/micro/kbench.cpp -o tools/micro/kbench
 // Usage: kbench <workload: c2d|c2e|c4d|c4e> [iters]
 // Prints HIP-event time per call of forward / backward and, for the grad_value kernel, the
 // per-phase breakdown from in-kernel s_memrealtime stamps (100 MHz) of one extra launch.
