@@ -8,6 +8,7 @@
 #include "../../uvhand_amd/csrc/msda_generic.hip"
 #include "../../uvhand_amd/csrc/msda_d32.hip"
 #include "../../uvhand_amd/csrc/msda_linear.hip"
+#include "../../uvhand_amd/csrc/msda_layernorm.hip"
 
 #include <algorithm>
 #include <cstdio>
@@ -44,7 +45,21 @@ int main(int argc, char **argv)
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     auto fwd = [&] { return msda_forward_f32(v, ds, dl, loc, at, N, S, M, D, L, Lq, P, out, st); };
-    auto bwd = [&] { return msda_backward_f32(go, v, ds, dl, loc, at, N, S, M, D, L, Lq, P, gv, gl, ga, st); };
+    // KB_DET=1: the deterministic (cell-sorted) backward with its query-chunk workspace
+    const bool det = getenv("KB_DET") && atoi(getenv("KB_DET")) != 0;
+    void *ws = nullptr; unsigned long long ws_bytes = 0;
+    if (det) {
+        ws_bytes = msda_backward_workspace_bytes(N, S, M, D, L, Lq, P, MSDA_FLAG_DETERMINISTIC);
+        if (ws_bytes) CK(hipMalloc(&ws, ws_bytes));
+        printf("deterministic backward, workspace %.1f MB\n", ws_bytes / 1e6);
+        int occ = -1;
+        hipFuncSetAttribute(reinterpret_cast<const void *>(msda::bwd_cell_d32_kernel<float, float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)msda::kCellLdsBytes);
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, msda::bwd_cell_d32_kernel<float, float>, msda::kCBlock, msda::kCellLdsBytes);
+        printf("bwd_cell_d32_kernel: %d workgroups of %d threads per CU with %zu B of LDS\n", occ, msda::kCBlock, msda::kCellLdsBytes);
+    }
+    auto bwd = [&] { return det ? msda_backward_ws_f32(go, v, ds, dl, loc, at, N, S, M, D, L, Lq, P, gv, gl, ga, ws, ws_bytes,
+                                                       MSDA_FLAG_DETERMINISTIC, st)
+                                : msda_backward_f32(go, v, ds, dl, loc, at, N, S, M, D, L, Lq, P, gv, gl, ga, st); };
     for (int which = 0; which < 2; ++which) {
         for (int i = 0; i < 5; ++i) if ((which ? bwd() : fwd()) != 0) { printf("launch failed: %s\n", msda_last_error()); return 1; }
         CK(hipStreamSynchronize(st));
@@ -62,7 +77,7 @@ int main(int argc, char **argv)
     unsigned long long *nul = nullptr; CK(hipMemcpyToSymbol(HIP_SYMBOL(msda::msda_stamp_buf), &nul, sizeof(nul)));
     std::vector<unsigned long long> hsb(total);
     CK(hipMemcpy(hsb.data(), sb, total * 8, hipMemcpyDeviceToHost));
-    if (!getenv("MSDA_BWD_MODE") && !(getenv("MSDA_BWD_CELL") && atoi(getenv("MSDA_BWD_CELL")) == 0)) {
+    if (det) {
         // cell-sorted role B (msda_d32_cell.h): per-workgroup phase totals
         double sum[6] = {0, 0, 0, 0, 0, 0}, mx = 0; size_t nb = 0; unsigned long long tmin = ~0ull, tmax = 0, kept = 0, batches = 0;
         for (size_t b = 0; b < 65536; ++b) {
@@ -86,7 +101,7 @@ int main(int argc, char **argv)
         unsigned long long tmin = ~0ull, tmax = 0, smax = 0; size_t nb = 0;
         double ph[5] = {0, 0, 0, 0, 0}, phmax[5] = {0, 0, 0, 0, 0};
         const int last = regs[rg].nph;
-        if (rg == 0 && !getenv("MSDA_BWD_MODE") && !(getenv("MSDA_BWD_CELL") && atoi(getenv("MSDA_BWD_CELL")) == 0)) continue;
+        if (rg == 0 && det) continue;
         for (size_t b = 0; b < 65536; ++b) {
             const unsigned long long *t = &hsb[rg * region + b * 8];
             if (!t[0] || !t[last]) continue;

@@ -444,18 +444,18 @@ __device__ __forceinline__ void bwd_query_body(
     MSDA_STAMP_AT(1, 3);
 }
 
-template <int SPLIT, bool ATOMIC, typename VT>
+template <int SPLIT, bool ATOMIC, typename VT, bool FUSED = false>
 __global__ __launch_bounds__(kBlock) void bwd_query_d32_kernel(
     const VT *__restrict__ grad_out, const VT *__restrict__ value,
     const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
     const float *__restrict__ loc, const float *__restrict__ attn, int S, int M, int L, int Lq,
     int P, int items, int p_shift, int lp_shift, int m_shift, VT *__restrict__ grad_value,
-    float *__restrict__ grad_loc, float *__restrict__ grad_attn, int xcd)
+    float *__restrict__ grad_loc, float *__restrict__ grad_attn, int xcd, const PrologueOut pro = PrologueOut{nullptr, 0, 0})
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    bwd_query_body<SPLIT, ATOMIC, kBlock, VT>(grad_out, value, shapes, level_start, loc, attn, S, M, L, Lq, P, items,
-                                          p_shift, lp_shift, m_shift, grad_value, grad_loc, grad_attn,
-                                          xcd ? xcd_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x, smem);
+    bwd_query_body<SPLIT, ATOMIC, kBlock, VT, FUSED>(grad_out, value, shapes, level_start, loc, attn, S, M, L, Lq, P, items,
+                                                 p_shift, lp_shift, m_shift, grad_value, grad_loc, grad_attn,
+                                                 xcd ? xcd_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x, smem, pro);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -868,6 +868,24 @@ __global__ __launch_bounds__(kSBlock) void bwd_fused_d32_kernel(
 #include "msda_d32_cell.h"
 namespace msda {
 
+// Role B alone on the cell-sorted path (large problems: role A then runs as its own 256-thread kernel with its own,
+// smaller LDS and register footprint — inside one launch it would inherit role B's and lose a third of its occupancy).
+template <typename VT, typename GT>
+__global__ __launch_bounds__(kCBlock, (128 * 8) / kCBlock >= 4 ? 4 : 2) void bwd_cell_d32_kernel(
+    const VT *__restrict__ grad_out, const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
+    const float *__restrict__ loc, const float *__restrict__ attn, int S, int M, int L, int Lq, int P, int p_shift,
+    const CellPlan plan, GT *__restrict__ grad_value, int xcd)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // pair-major numbering, whole pairs per XCD: the items of a (batch, head) pair run at the same time on one XCD and
+    // share its grad_out rows in that L2 (slot-major — every pair's heaviest item first — was measured: cfg-4 encoder role B
+    // 264 -> 371 us, the pair's rows no longer survive in L2 between its items)
+    const int bid = xcd ? xcd_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+    const int pr = bid / plan.slots;
+    bwd_cell_body<VT, GT>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, grad_value, plan, pr,
+                          bid - pr * plan.slots, smem);
+}
+
 // The whole backward in ONE launch, second generation: the first nB workgroups are role B on the cell-sorted
 // path (msda_d32_cell.h; slot `bid % G` of pair `bid / G`), the rest role A.  The two roles share no data.
 template <int SPLIT, typename VT, bool FUSED, typename GT>
@@ -1032,6 +1050,7 @@ static int cell_cmax(int N, int S, int M, int L, int Lq, int P)
     if ((long long)Lq * P <= kCellChunkPoints) return 1;                   // a (level, tile) keeps few points anyway
     const long long base_items = (long long)N * M * (S / 192 + L);          // ~ (pairs) x (tiles per pair)
     long long c = (target + base_items - 1) / base_items;
+    // (forcing >= 2 chunks so that one-tile levels are not the launch's tail was measured: cfg-4 encoder role B 264 -> 317 us)
     return (int)(c < 1 ? 1 : c > 8 ? 8 : c);
 }
 
@@ -1058,12 +1077,11 @@ static CellLaunch plan_cells(int N, int S, int M, int L, int Lq, int P, void *wo
             cl.pl.slabs = static_cast<float *>(workspace);
         }
     }
-    long long slots = 2LL * ceil_div(S, kTileRows) + L;
-    if (cl.pl.c_max > 1) {
-        const long long by_points = (long long)L * ((NP + kCellChunkPoints - 1) / kCellChunkPoints);
-        const long long by_cmax = slots * (cl.pl.c_max - 1);
-        slots += by_points < by_cmax ? by_points : by_cmax;
-    }
+    // slots per pair = the item count of a typical pyramid (a level of H*W pixels has about H*W/256 tiles, one more
+    // level-sized tile per extra level, c_max - 1 more chunks per level): a pair with more items has some slots loop,
+    // a pair with fewer leaves workgroups that exit after the level walk — each costs a few us of a CU slot
+    long long slots = (long long)ceil_div(S, kTileRows) + L - 1 + (long long)L * (cl.pl.c_max - 1);
+    (void)NP;
     while (slots > 1 && slots * pairs > 0x3fffffffLL) slots = (slots + 1) / 2;   // slots only affect balance
     cl.pl.slots = (int)slots;
     cl.nB = slots * pairs;
@@ -1088,6 +1106,35 @@ static int launch_bwd_cells_t(const VT *grad_out, const VT *value, const int64_t
     static const int skip_a = env_int("MSDA_CELL_SKIP_A", 0), skip_b = env_int("MSDA_CELL_SKIP_B", 0);   // measurement only
     const int ipw = kCWaves * 8 / split;
     const size_t lds_a = (size_t)ipw * item_stride + (size_t)ipw * LP * 16;
+    // Large problems: two launches (role B cells, role A query-major), each with its own occupancy.
+    if ((long long)Lq * P > kCellChunkPoints || cl.nB + n_a(split) > 1024) {
+        if (!skip_b) {
+            if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_cell_d32_kernel<VT, GT>), kCellLdsBytes)) return rc;
+            hipLaunchKernelGGL((bwd_cell_d32_kernel<VT, GT>), dim3((unsigned)cl.nB), dim3(kCBlock), kCellLdsBytes, stream, grad_out,
+                               shapes, level_start, loc, attn, S, M, L, Lq, P, ps, cl.pl, grad_value, xcd);
+            if (int rc = check_launch("msda backward (d32, cells)")) return rc;
+            if (cl.pl.c_max > 1) {
+                const int row_blocks = ceil_div(S, 32);
+                hipLaunchKernelGGL((slab_reduce_kernel<GT>), dim3((unsigned)((long long)N * M * row_blocks)), dim3(256), 0, stream,
+                                   shapes, level_start, S, M, L, Lq, P, grad_value, cl.pl, row_blocks);
+                if (int rc = check_launch("msda backward (d32, slab reduce)")) return rc;
+            }
+        }
+        if (!skip_a) {
+            const int sp = pick_split(items, LP);
+            const int ipw_a = 32 / sp;
+            const size_t lds_q = (size_t)ipw_a * item_stride + (size_t)ipw_a * LP * 16;
+            const dim3 qgrid((items + ipw_a - 1) / ipw_a);
+#define MSDA_LAUNCH_Q(SP)                                                                              \
+            hipLaunchKernelGGL((bwd_query_d32_kernel<SP, false, VT, FUSED>), qgrid, dim3(kBlock), lds_q, stream, grad_out, value,    \
+                               shapes, level_start, loc, attn, S, M, L, Lq, P, items, ps, lps, ms, static_cast<VT *>(nullptr),       \
+                               grad_loc, grad_attn, xcd, pro)
+            if (sp == 4) MSDA_LAUNCH_Q(4); else if (sp == 2) MSDA_LAUNCH_Q(2); else MSDA_LAUNCH_Q(1);
+#undef MSDA_LAUNCH_Q
+            return check_launch("msda backward (d32, query-major)");
+        }
+        return MSDA_OK;
+    }
     const long long nA = skip_a ? 0 : n_a(split);
     CellLaunch clm = cl;
     if (skip_b) clm.nB = 0;

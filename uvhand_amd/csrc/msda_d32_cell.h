@@ -40,8 +40,11 @@ constexpr int kTileW = 16;                   // widest tile
 constexpr int kMaxKeys = kTileRows == 256 ? 576 : kTileRows == 128 ? 320 : 4 * (kTileRows / 2 + 2);
 constexpr int kPendCap = 2 * kCBlock;        // pending points per sort+gather batch
 constexpr int kScanPPT = 1;                  // points per thread per scan round
+constexpr int kSortedCap = kPendCap + 3 * kMaxKeys;             // sorted positions: every cell starts at a multiple of 4
 
-struct alignas(16) PRec { int q; float lh, lw, a; };
+// One record per kept sampling point, written once by the scan (one lane per point): the four corner weights
+// (bilinear x attention) and the element offset of the query's grad_out row relative to the (batch, head) base.
+struct alignas(16) WRec { float k00, k01, k10, k11; };
 
 // Diagnostic build only (-DMSDA_STAMPS, tools/micro/kbench.cpp): thread 0 sums the time a workgroup spends in each
 // phase of its items; [blocks][8] = {start, end, scan, sort, gather, flush, batches, kept points} in region 0.
@@ -62,8 +65,10 @@ struct CellPlan {
     float *slabs;              // [pairs][slab_rows][32] or null
 };
 
-constexpr size_t kCellLdsBytes = (size_t)kTileRows * kD * 4 + (size_t)kPendCap * (sizeof(PRec) + 4 + 2) +
-                                 (size_t)kMaxKeys * kCWaves * 4 + (size_t)kMaxKeys * 8 + 128;
+// LDS of a role-B workgroup: tile image | weights | row offsets | (cell, wave, rank) of each pending point | sorted
+// position -> pending slot | per-(cell, wavefront) counters, two 16-bit counters per word | non-empty cells | scalars
+constexpr size_t kCellLdsBytes = (size_t)kTileRows * kD * 4 + (size_t)kPendCap * (sizeof(WRec) + 4 + 4) +
+                                 (size_t)kSortedCap * 2 + (size_t)kMaxKeys * (kCWaves / 2) * 4 + (size_t)kMaxKeys * 8 + 128;
 
 // Tiling of one level, identical in every kernel that needs it (role B, slab reduce).
 struct LevelTiles {
@@ -104,13 +109,21 @@ __device__ __forceinline__ void level_tiles(const int64_t *__restrict__ shapes, 
 }
 
 // ---- gather of one colour: compact entries [e0, e1) of `nz` ---------------------------------------------
-// nz[e] = { first sorted position, count << 16 | tile-local cell row << 5 | cell column }.
+// nz[e] = { first sorted position (a multiple of 4), count << 16 | tile-local cell row << 5 | cell column }.
+// SLOTS lane groups (of one wavefront) share a cell: group s takes the records [s*per, (s+1)*per), per a multiple of 4,
+// so every group reads its sorted indices as aligned quads.  Full quads run without any select; the last, partial quad
+// of a group zeroes the weights of the missing records and points their row at the quad's first (valid) record.
+__device__ __forceinline__ void fma_corners(float4 &a00, float4 &a01, float4 &a10, float4 &a11, const WRec &w, const float4 &g)
+{
+    fma4(a00, w.k00, g); fma4(a01, w.k01, g); fma4(a10, w.k10, g); fma4(a11, w.k11, g);
+}
+
 template <int SLOTS, typename VT>
-__device__ __forceinline__ void gather_cells(const VT *__restrict__ go_base, int row_stride, const int2 *nz, int e0, int e1,
-                                             const unsigned short *sidx, const PRec *pend, float *tile, int th, int tw)
+__device__ __forceinline__ void gather_cells(const VT *__restrict__ go_base, const int2 *nz, int e0, int e1,
+                                             const unsigned short *sidx, const WRec *wrec, const int *qrec, float *tile,
+                                             int th, int tw)
 {
     constexpr int CPW = 8 / SLOTS;                           // cells per wavefront trip
-    constexpr int CH = 4;                                    // records in flight per lane group
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int sub = lane / (SLOTS * 8), slot = (lane >> 3) % SLOTS, j = lane & 7;
     for (int eb = e0 + wave * CPW; eb < e1; eb += kCWaves * CPW) {          // wave-uniform trip count
@@ -118,27 +131,35 @@ __device__ __forceinline__ void gather_cells(const VT *__restrict__ go_base, int
         const bool have = e < e1;
         const int2 ent = have ? nz[e] : make_int2(0, 0);
         const int cnt = have ? (int)((unsigned)ent.y >> 16) : 0;
+        int lo = 0, hi = cnt;
+        if (SLOTS > 1) {
+            const int per = (((cnt + SLOTS - 1) / SLOTS) + 3) & ~3;
+            lo = min(cnt, slot * per); hi = min(cnt, lo + per);
+        }
         const unsigned short *ix = sidx + ent.x;
         float4 a00 = make_float4(0.f, 0.f, 0.f, 0.f), a01 = a00, a10 = a00, a11 = a00;
-        for (int i0 = slot; i0 < cnt; i0 += CH * SLOTS) {
-            PRec r[CH]; float4 g[CH];
-#pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                r[u].q = -1; r[u].lh = r[u].lw = r[u].a = 0.f;
-                if (i0 + u * SLOTS < cnt) r[u] = pend[ix[i0 + u * SLOTS]];
-            }
-#pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                const float4 t = Row<VT>::load(go_base + (long long)(r[u].q >= 0 ? r[u].q : 0) * row_stride);
-                const bool ok = r[u].q >= 0;                  // component selects: an Inf in row 0 must not leak in
-                g[u] = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
-            }
-#pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                const float hh = 1.f - r[u].lh, hw = 1.f - r[u].lw;
-                fma4(a00, hh * hw * r[u].a, g[u]); fma4(a01, hh * r[u].lw * r[u].a, g[u]);
-                fma4(a10, r[u].lh * hw * r[u].a, g[u]); fma4(a11, r[u].lh * r[u].lw * r[u].a, g[u]);
-            }
+        int i = lo;
+        for (; i + 4 <= hi; i += 4) {                                          // full quads: 4 row loads in flight
+            const uint2 q4 = *reinterpret_cast<const uint2 *>(ix + i);
+            const int i0 = q4.x & 0xffff, i1 = q4.x >> 16, i2 = q4.y & 0xffff, i3 = q4.y >> 16;
+            const WRec w0 = wrec[i0], w1 = wrec[i1], w2 = wrec[i2], w3 = wrec[i3];
+            const float4 g0 = Row<VT>::load(go_base + qrec[i0]), g1 = Row<VT>::load(go_base + qrec[i1]);
+            const float4 g2 = Row<VT>::load(go_base + qrec[i2]), g3 = Row<VT>::load(go_base + qrec[i3]);
+            fma_corners(a00, a01, a10, a11, w0, g0); fma_corners(a00, a01, a10, a11, w1, g1);
+            fma_corners(a00, a01, a10, a11, w2, g2); fma_corners(a00, a01, a10, a11, w3, g3);
+        }
+        if (i < hi) {                                                          // last quad, 1..3 records
+            const uint2 q4 = *reinterpret_cast<const uint2 *>(ix + i);
+            const int i0 = q4.x & 0xffff;
+            const int n = hi - i;
+            const int i1 = n > 1 ? (int)(q4.x >> 16) : i0, i2 = n > 2 ? (int)(q4.y & 0xffff) : i0;
+            WRec w0 = wrec[i0], w1 = wrec[i1], w2 = wrec[i2];
+            if (n <= 1) w1.k00 = w1.k01 = w1.k10 = w1.k11 = 0.f;
+            if (n <= 2) w2.k00 = w2.k01 = w2.k10 = w2.k11 = 0.f;
+            const float4 g0 = Row<VT>::load(go_base + qrec[i0]), g1 = Row<VT>::load(go_base + qrec[i1]);
+            const float4 g2 = Row<VT>::load(go_base + qrec[i2]);
+            fma_corners(a00, a01, a10, a11, w0, g0); fma_corners(a00, a01, a10, a11, w1, g1);
+            fma_corners(a00, a01, a10, a11, w2, g2);
         }
         if (SLOTS >= 2) { add4(a00, shfl_xor4(a00, 8)); add4(a01, shfl_xor4(a01, 8)); add4(a10, shfl_xor4(a10, 8)); add4(a11, shfl_xor4(a11, 8)); }
         if (SLOTS >= 4) { add4(a00, shfl_xor4(a00, 16)); add4(a01, shfl_xor4(a01, 16)); add4(a10, shfl_xor4(a10, 16)); add4(a11, shfl_xor4(a11, 16)); }
@@ -146,12 +167,12 @@ __device__ __forceinline__ void gather_cells(const VT *__restrict__ go_base, int
         if (have && slot == 0) {
             // corners of cell (tch, tcw): pixels (tch-1, tcw-1) (tch-1, tcw) (tch, tcw-1) (tch, tcw), tile-local
             const int tch = (ent.y >> 5) & 2047, tcw = ent.y & 31;
-            float4 *t4 = reinterpret_cast<float4 *>(tile) + j;
+            float4 *t4 = reinterpret_cast<float4 *>(tile) + ((tch - 1) * tw + tcw - 1) * 8 + j;
             const bool r0 = tch >= 1, r1 = tch < th, c0 = tcw >= 1, c1 = tcw < tw;
-            if (r0 && c0) { float4 *p = t4 + ((tch - 1) * tw + tcw - 1) * 8; float4 o = *p; add4(o, a00); *p = o; }
-            if (r0 && c1) { float4 *p = t4 + ((tch - 1) * tw + tcw) * 8;     float4 o = *p; add4(o, a01); *p = o; }
-            if (r1 && c0) { float4 *p = t4 + (tch * tw + tcw - 1) * 8;       float4 o = *p; add4(o, a10); *p = o; }
-            if (r1 && c1) { float4 *p = t4 + (tch * tw + tcw) * 8;           float4 o = *p; add4(o, a11); *p = o; }
+            if (r0 && c0) { float4 o = t4[0]; add4(o, a00); t4[0] = o; }
+            if (r0 && c1) { float4 o = t4[8]; add4(o, a01); t4[8] = o; }
+            if (r1 && c0) { float4 o = t4[tw * 8]; add4(o, a10); t4[tw * 8] = o; }
+            if (r1 && c1) { float4 o = t4[tw * 8 + 8]; add4(o, a11); t4[tw * 8 + 8] = o; }
         }
     }
 }
@@ -165,14 +186,16 @@ __device__ __forceinline__ void cell_item(
     float *slab_pair, unsigned char *smem)
 {
     float *tile = reinterpret_cast<float *>(smem);                               // [kTileRows][32]
-    PRec *pend = reinterpret_cast<PRec *>(tile + kTileRows * kD);               // [kPendCap]
-    unsigned *pk = reinterpret_cast<unsigned *>(pend + kPendCap);               // [kPendCap] (key*8+wave) << 16 | rank
-    int *cnt = reinterpret_cast<int *>(pk + kPendCap);                          // [kMaxKeys][8] counts, then starts
-    int2 *nz = reinterpret_cast<int2 *>(cnt + kMaxKeys * kCWaves);              // [kMaxKeys] non-empty cells
-    unsigned short *sidx = reinterpret_cast<unsigned short *>(nz + kMaxKeys);   // [kPendCap] sorted position -> pending slot
-    int *wcnt = reinterpret_cast<int *>(sidx + kPendCap);                       // [2][8] kept points per wavefront
+    WRec *wrec = reinterpret_cast<WRec *>(tile + kTileRows * kD);               // [kPendCap] corner weights
+    int *qrec = reinterpret_cast<int *>(wrec + kPendCap);                       // [kPendCap] grad_out row offset (elements)
+    unsigned *pk = reinterpret_cast<unsigned *>(qrec + kPendCap);               // [kPendCap] (key*8+wave) << 16 | rank
+    unsigned *cnt = pk + kPendCap;                                              // [kMaxKeys][kCWaves/2]: two 16-bit counters per word
+    int2 *nz = reinterpret_cast<int2 *>(cnt + kMaxKeys * (kCWaves / 2));        // [kMaxKeys] non-empty cells
+    unsigned short *sidx = reinterpret_cast<unsigned short *>(nz + kMaxKeys);   // [kSortedCap] sorted position -> pending slot
+    int *wcnt = reinterpret_cast<int *>(sidx + kSortedCap);                     // [2][8] kept points per wavefront
     int *cstart = wcnt + 16;                                                    // [5] first compact entry of each colour
     int *wsum = cstart + 8;                                                     // [8] prefix-scan partials
+    constexpr int CW = kCWaves / 2;                                             // counter words per cell
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int b = pr / M, m = pr - b * M;
@@ -184,11 +207,11 @@ __device__ __forceinline__ void cell_item(
     const int q0 = (int)((long long)chunk * Lq / lt.C), q1 = (int)((long long)(chunk + 1) * Lq / lt.C);
     const int pt0 = q0 * P, pt1 = q1 * P;
     const long long item_base = (long long)b * Lq * M + m;                       // item(q) = item_base + q*M
-    const int row_stride = M * kD;
+    const int row_stride = M * kD;                                               // elements between consecutive queries' rows
     const VT *go_base = grad_out + item_base * kD + (lane & 7) * 4;
 
     for (int i = tid; i < npx * 8; i += kCBlock) reinterpret_cast<float4 *>(tile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int i = tid; i < nkeys * kCWaves; i += kCBlock) cnt[i] = 0;
+    for (int i = tid; i < nkeys * CW; i += kCBlock) cnt[i] = 0;
     // (the first round's barrier orders these stores before any use)
 
     unsigned long long st_t = CELL_T(), st_begin = st_t, st_scan = 0, st_sort = 0, st_gather = 0, st_flush = 0, st_batches = 0, st_kept = 0;
@@ -205,9 +228,8 @@ __device__ __forceinline__ void cell_item(
         }
     }
     for (int r = 0; r < rounds; ++r) {
-        const bool scanning = r < rounds;
-        int key = -1; PRec rec; rec.q = -1; rec.lh = rec.lw = rec.a = 0.f;
-        if (scanning) {
+        int key = -1; WRec rec; rec.k00 = rec.k01 = rec.k10 = rec.k11 = 0.f; int qoff = 0;
+        {
             const float2 xy = xy_n; const float at = at_n; const int q = q_n;
             // prefetch the next round's point
             xy_n = make_float2(-8.f, -8.f); at_n = 0.f; q_n = -1;
@@ -221,7 +243,9 @@ __device__ __forceinline__ void cell_item(
             const int tch = g.h0 + 1 - h_lo, tcw = g.w0 + 1 - w_lo;              // cell, tile-local
             if (q >= 0 && g.inside && tch >= 0 && tch <= th && tcw >= 0 && tcw <= tw) {
                 key = ((tch & 1) * 2 + (tcw & 1)) * kc + (tch >> 1) * kcw + (tcw >> 1);
-                rec.q = q; rec.lh = g.lh; rec.lw = g.lw; rec.a = at;
+                const float hh = 1.f - g.lh, hw = 1.f - g.lw;
+                rec.k00 = hh * hw * at; rec.k01 = hh * g.lw * at; rec.k10 = g.lh * hw * at; rec.k11 = g.lh * g.lw * at;
+                qoff = q * row_stride;                                          // < 2^31: d32_supported()
             }
         }
         const unsigned long long bal = __ballot(key >= 0);
@@ -233,9 +257,11 @@ __device__ __forceinline__ void cell_item(
             for (int w2 = 0; w2 < kCWaves; ++w2) { const int c = wcnt[(r & 1) * 8 + w2]; if (w2 < wave) base += c; total += c; }
             if (key >= 0) {
                 const int pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
-                const int rank = atomicAdd(&cnt[key * kCWaves + wave], 1);      // this wavefront's own counter: stable order
-                pend[pos] = rec;
-                pk[pos] = ((unsigned)(key * kCWaves + wave) << 16) | (unsigned)rank;
+                // this wavefront's own 16-bit counter of the cell: the order inside a cell is the same on every run
+                const unsigned old = atomicAdd(&cnt[key * CW + (wave >> 1)], 1u << ((wave & 1) * 16));
+                const unsigned rank = (old >> ((wave & 1) * 16)) & 0xffffu;
+                wrec[pos] = rec; qrec[pos] = qoff;
+                pk[pos] = ((unsigned)(key * kCWaves + wave) << 16) | rank;
             }
             pcount += total;
         }
@@ -243,7 +269,8 @@ __device__ __forceinline__ void cell_item(
         if (!(pcount > kPendCap - kCBlock * kScanPPT || r + 1 >= rounds)) continue;
         __syncthreads();
         CELL_ACC(st_scan, st_t); st_batches += 1; st_kept += pcount;
-        // ---- prefix over cells: thread t owns cells [t*KPT, (t+1)*KPT) with their 8 wavefront counters ----
+        // ---- prefix over cells: thread t owns cells [t*KPT, (t+1)*KPT) with their per-wavefront counters; every cell's
+        // run starts at a multiple of 4 (aligned quads of sorted indices) ----
         const int KPT = (nkeys + kCBlock - 1) / kCBlock;                          // 1, 2 or 3
         int tot[3] = {0, 0, 0}, mine = 0, mine_nz = 0;
         for (int k = 0; k < KPT; ++k) {
@@ -251,12 +278,12 @@ __device__ __forceinline__ void cell_item(
             if (ky < nkeys) {
                 int t = 0;
 #pragma unroll
-                for (int w2 = 0; w2 < kCWaves; ++w2) t += cnt[ky * kCWaves + w2];
+                for (int w2 = 0; w2 < CW; ++w2) { const unsigned c = cnt[ky * CW + w2]; t += (int)(c & 0xffffu) + (int)(c >> 16); }
                 tot[k] = t;
-                mine += tot[k]; mine_nz += tot[k] > 0;
+                mine += (t + 3) & ~3; mine_nz += t > 0;
             }
         }
-        int incl = mine | (mine_nz << 20);                                        // records and non-empty cells in one scan
+        int incl = mine | (mine_nz << 20);                                        // padded records and non-empty cells in one scan
 #pragma unroll
         for (int o = 1; o < kWave; o <<= 1) { const int y = __shfl_up(incl, o, kWave); if (lane >= o) incl += y; }
         if (lane == kWave - 1) wsum[wave] = incl;
@@ -276,10 +303,15 @@ __device__ __forceinline__ void cell_item(
                     const int rem = ky - colour * kc, rh = rem / kcw, rw = rem - rh * kcw;
                     const int tch = rh * 2 + (colour >> 1), tcw = rw * 2 + (colour & 1);
                     nz[nzpos++] = make_int2(start, (tot[k] << 16) | (tch << 5) | tcw);
-                    int s = start;
+                    unsigned s = (unsigned)start;                                  // counts -> first positions, in place
 #pragma unroll
-                    for (int w2 = 0; w2 < kCWaves; ++w2) { const int c = cnt[ky * kCWaves + w2]; cnt[ky * kCWaves + w2] = s; s += c; }
-                    start += tot[k];
+                    for (int w2 = 0; w2 < CW; ++w2) {
+                        const unsigned c = cnt[ky * CW + w2];
+                        const unsigned lo16 = s; s += c & 0xffffu;
+                        const unsigned hi16 = s; s += c >> 16;
+                        cnt[ky * CW + w2] = lo16 | (hi16 << 16);
+                    }
+                    start += (tot[k] + 3) & ~3;
                 }
             }
         }
@@ -287,8 +319,9 @@ __device__ __forceinline__ void cell_item(
         __syncthreads();
         // ---- sorted position -> pending slot ----
         for (int i = tid; i < pcount; i += kCBlock) {
-            const unsigned v = pk[i];
-            sidx[cnt[v >> 16] + (int)(v & 0xffffu)] = (unsigned short)i;
+            const unsigned v = pk[i], f = v >> 16;                                 // f = key*kCWaves + wave
+            const unsigned word = cnt[(f / kCWaves) * CW + ((f % kCWaves) >> 1)];
+            sidx[((word >> ((f & 1) * 16)) & 0xffffu) + (v & 0xffffu)] = (unsigned short)i;
         }
         __syncthreads();
         CELL_ACC(st_sort, st_t);
@@ -297,20 +330,20 @@ __device__ __forceinline__ void cell_item(
             const int nnz = all >> 20;
             const int mean2 = nnz > 0 ? (2 * pcount) / nnz : 0;                   // 2 x mean points per non-empty cell
             const int per_colour = max(1, (nnz + 3) >> 2);
-            int slots = mean2 <= 16 ? 1 : mean2 <= 32 ? 2 : mean2 <= 64 ? 4 : 8;
-            // few cells: spread each over more lane groups as long as every group still has a couple of points
-            while (slots < 8 && per_colour * slots < kCBlock / 8 && mean2 >= 8 * slots) slots <<= 1;
+            int slots = mean2 <= 32 ? 1 : mean2 <= 64 ? 2 : mean2 <= 128 ? 4 : 8;
+            // few cells: spread each over more lane groups as long as every group still has a few quads
+            while (slots < 8 && per_colour * slots < kCBlock / 8 && mean2 >= 16 * slots) slots <<= 1;
             for (int c = 0; c < 4; ++c) {
                 const int e0 = cstart[c], e1 = cstart[c + 1];
-                if (slots == 1)      gather_cells<1, VT>(go_base, row_stride, nz, e0, e1, sidx, pend, tile, th, tw);
-                else if (slots == 2) gather_cells<2, VT>(go_base, row_stride, nz, e0, e1, sidx, pend, tile, th, tw);
-                else if (slots == 4) gather_cells<4, VT>(go_base, row_stride, nz, e0, e1, sidx, pend, tile, th, tw);
-                else                 gather_cells<8, VT>(go_base, row_stride, nz, e0, e1, sidx, pend, tile, th, tw);
+                if (slots == 1)      gather_cells<1, VT>(go_base, nz, e0, e1, sidx, wrec, qrec, tile, th, tw);
+                else if (slots == 2) gather_cells<2, VT>(go_base, nz, e0, e1, sidx, wrec, qrec, tile, th, tw);
+                else if (slots == 4) gather_cells<4, VT>(go_base, nz, e0, e1, sidx, wrec, qrec, tile, th, tw);
+                else                 gather_cells<8, VT>(go_base, nz, e0, e1, sidx, wrec, qrec, tile, th, tw);
                 __syncthreads();
             }
         }
         CELL_ACC(st_gather, st_t);
-        for (int i = tid; i < nkeys * kCWaves; i += kCBlock) cnt[i] = 0;          // next batch (ordered by its round barrier)
+        for (int i = tid; i < nkeys * CW; i += kCBlock) cnt[i] = 0;               // next batch (ordered by its round barrier)
         pcount = 0;
     }
     __syncthreads();
@@ -345,6 +378,8 @@ __device__ __forceinline__ void bwd_cell_body(
     const int NP = Lq * P;
     float *slab_pair = pl.slabs ? pl.slabs + (long long)pr * pl.slab_rows * kD : nullptr;
     int cursor = 0, first = 0, cover_end = 0;
+    // Items are numbered level by level, tiles then chunks (numbering the coarse levels — the longest items of a pair —
+    // first was measured: cfg-4 encoder role B 264 -> 410 us; profiles/r02_notes.md).
     for (int l = 0; l < L; ++l) {                                                  // uniform (scalar) walk over the levels
         LevelTiles lt;
         level_tiles(shapes, level_start, l, S, NP, Lq, pl, cursor, lt);
