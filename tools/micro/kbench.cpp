@@ -89,6 +89,17 @@ int main(int argc, char **argv)
             for (int k = 2; k < 6; ++k) sum[k - 1] += (double)t[k] * 0.01;
             batches += t[6]; kept += t[7];
         }
+        {   // whole-workgroup lifetimes (entry -> exit), region 1
+            double life = 0, lmax = 0; size_t nw = 0; unsigned long long a = ~0ull, z = 0;
+            for (size_t b = 0; b < 65536; ++b) {
+                const unsigned long long *t = &hsb[region + b * 8];
+                if (!t[0] || !t[1]) continue;
+                ++nw; a = std::min(a, t[0]); z = std::max(z, t[1]);
+                const double d = (double)(t[1] - t[0]) * 0.01; life += d; lmax = std::max(lmax, d);
+            }
+            if (nw) printf("cell kernel: %zu workgroups launched, span %.2f us, mean lifetime %.2f us (max %.2f), sum of lifetimes / span = %.1f "
+                           "workgroups in flight\n", nw, (double)(z - a) * 0.01, life / nw, lmax, life / ((double)(z - a) * 0.01));
+        }
         if (nb) printf("cell role B: %zu workgroups with items, span %.2f us; per workgroup: last item %.2f us (max %.2f), scan %.2f sort %.2f gather %.2f "
                        "flush %.2f us; batches %.2f, kept points %.1f\n", nb, (double)(tmax - tmin) * 0.01, sum[0] / nb, mx, sum[1] / nb, sum[2] / nb,
                        sum[3] / nb, sum[4] / nb, (double)batches / nb, (double)kept / nb);

@@ -871,19 +871,25 @@ namespace msda {
 // Role B alone on the cell-sorted path (large problems: role A then runs as its own 256-thread kernel with its own,
 // smaller LDS and register footprint — inside one launch it would inherit role B's and lose a third of its occupancy).
 template <typename VT, typename GT>
-__global__ __launch_bounds__(kCBlock, (128 * 8) / kCBlock >= 4 ? 4 : 2) void bwd_cell_d32_kernel(
+__global__ __launch_bounds__(kCBlock, MSDA_CELL_MIN_WAVES) void bwd_cell_d32_kernel(
     const VT *__restrict__ grad_out, const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
     const float *__restrict__ loc, const float *__restrict__ attn, int S, int M, int L, int Lq, int P, int p_shift,
-    const CellPlan plan, GT *__restrict__ grad_value, int xcd)
+    const CellPlan plan, GT *__restrict__ grad_value, int xcd, int nvb)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // pair-major numbering, whole pairs per XCD: the items of a (batch, head) pair run at the same time on one XCD and
     // share its grad_out rows in that L2 (slot-major — every pair's heaviest item first — was measured: cfg-4 encoder role B
     // 264 -> 371 us, the pair's rows no longer survive in L2 between its items)
-    const int bid = xcd ? xcd_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
-    const int pr = bid / plan.slots;
-    bwd_cell_body<VT, GT>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, grad_value, plan, pr,
-                          bid - pr * plan.slots, smem);
+    // persistent form: the launch has at most as many workgroups as fit on the chip at once (a multiple of 8, so a
+    // workgroup keeps its XCD) and each walks the virtual blocks vb = blockIdx.x, + gridDim.x, ...
+    MSDA_STAMP_AT(1, 0);
+    for (int vb = (int)blockIdx.x; vb < nvb; vb += (int)gridDim.x) {
+        const int bid = xcd ? xcd_block(vb, nvb) : vb;
+        const int pr = bid / plan.slots;
+        bwd_cell_body<VT, GT>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, grad_value, plan, pr,
+                              bid - pr * plan.slots, smem);
+    }
+    MSDA_STAMP_AT(1, 1);
 }
 
 // The whole backward in ONE launch, second generation: the first nB workgroups are role B on the cell-sorted
@@ -1110,8 +1116,10 @@ static int launch_bwd_cells_t(const VT *grad_out, const VT *value, const int64_t
     if ((long long)Lq * P > kCellChunkPoints || cl.nB + n_a(split) > 1024) {
         if (!skip_b) {
             if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_cell_d32_kernel<VT, GT>), kCellLdsBytes)) return rc;
-            hipLaunchKernelGGL((bwd_cell_d32_kernel<VT, GT>), dim3((unsigned)cl.nB), dim3(kCBlock), kCellLdsBytes, stream, grad_out,
-                               shapes, level_start, loc, attn, S, M, L, Lq, P, ps, cl.pl, grad_value, xcd);
+            static const int persist = env_int("MSDA_CELL_PERSIST", 0);           // diagnostic builds: 0 = one workgroup per block
+            const long long grid_b = (persist > 0 && cl.nB > persist) ? persist : cl.nB;
+            hipLaunchKernelGGL((bwd_cell_d32_kernel<VT, GT>), dim3((unsigned)grid_b), dim3(kCBlock), kCellLdsBytes, stream, grad_out,
+                               shapes, level_start, loc, attn, S, M, L, Lq, P, ps, cl.pl, grad_value, xcd, (int)cl.nB);
             if (int rc = check_launch("msda backward (d32, cells)")) return rc;
             if (cl.pl.c_max > 1) {
                 const int row_blocks = ceil_div(S, 32);

@@ -33,12 +33,21 @@ namespace msda {
 #endif
 constexpr int kCBlock = MSDA_CELL_THREADS;   // threads per role-B workgroup (and per role-A workgroup of the fused launch)
 constexpr int kCWaves = kCBlock / kWave;
-constexpr int kTileRows = kCBlock / 2;       // destination pixels per tile: 128 B of fp32 image each
+#ifndef MSDA_CELL_TILE_ROWS
+#define MSDA_CELL_TILE_ROWS (MSDA_CELL_THREADS / 2)
+#endif
+#ifndef MSDA_CELL_PEND
+#define MSDA_CELL_PEND (2 * MSDA_CELL_THREADS)
+#endif
+#ifndef MSDA_CELL_MIN_WAVES
+#define MSDA_CELL_MIN_WAVES ((128 * 8) / MSDA_CELL_THREADS >= 4 ? 4 : 2)
+#endif
+constexpr int kTileRows = MSDA_CELL_TILE_ROWS;   // destination pixels per tile: 128 B of fp32 image each
 constexpr int kTileW = 16;                   // widest tile
 // cells of a tile are numbered colour-major: 4 * ((TH/2)+1) * ((TW/2)+1) keys; the maximum over TH*TW <= kTileRows,
 // TW <= 16 is at TW = 2 (130 for 256 rows, 66 for 128)
 constexpr int kMaxKeys = kTileRows == 256 ? 576 : kTileRows == 128 ? 320 : 4 * (kTileRows / 2 + 2);
-constexpr int kPendCap = 2 * kCBlock;        // pending points per sort+gather batch
+constexpr int kPendCap = MSDA_CELL_PEND;     // pending points per sort+gather batch
 constexpr int kScanPPT = 1;                  // points per thread per scan round
 constexpr int kSortedCap = kPendCap + 3 * kMaxKeys;             // sorted positions: every cell starts at a multiple of 4
 
