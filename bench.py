@@ -271,13 +271,19 @@ def main():
             harness.barrier(device)
 
         def timed_block(call, calls):
-            """EXACTLY `calls` invocations bracketed by barrier + synchronize on both sides (seconds, this rank)."""
+            """EXACTLY `calls` invocations bracketed by barrier + synchronize on both sides.  Returns this rank's seconds
+            from the common start (every rank past the barrier, device idle) to ITS OWN completion (device idle again);
+            the closing barrier follows the clock read, so the collective's own latency (tens of us on RCCL, a
+            sizeable share of a 20-step block) is not billed to the steps — the slowest rank's time, taken by the
+            caller as the max over ranks, is when the whole job was done."""
             barrier()
             t0 = time.perf_counter()
             for _ in range(calls):
                 call()
+            torch.cuda.synchronize(device)
+            t1 = time.perf_counter()
             barrier()
-            return time.perf_counter() - t0
+            return t1 - t0
 
         for _ in range((args.warmup + per_graph - 1) // per_graph):
             run()

@@ -156,3 +156,34 @@ def test_inconsistent_shapes_are_memory_safe(native):
     short["shapes"] = np.asarray([(6, 6), (2, 2)], dtype=np.int64)             # covers S - 5 pixels only
     gv2, _, _ = _backward(native, short)
     assert torch.count_nonzero(gv2[:, 40:]) == 0
+
+
+@pytest.mark.parametrize("M,Lq,shapes", [(8, 37, [(12, 12), (6, 6), (3, 3), (2, 2)]),          # one launch (roles fused)
+                                         (8, 700, [(16, 16), (8, 8), (4, 4), (2, 2)]),          # Lq*P > 2048: role A as its own launch
+                                         (16, 600, [(10, 10), (5, 5)]),                           # 16 heads: whole queries per workgroup
+                                         (2, 2100, [(16, 16), (8, 8), (4, 4), (2, 2)])])          # few pairs: query chunks + slabs
+def test_deterministic_fused_prologue_backward(native, M, Lq, shapes):
+    """msda_backward_prologue_ws_f32 with MSDA_FLAG_DETERMINISTIC: the raw-tensor gradients equal the default kernels'
+    (same role A arithmetic: bit for bit) and grad_value matches within summation order and is reproducible."""
+    g = torch.Generator().manual_seed(M * 1000 + Lq)
+    N, P, L = 2, 4, len(shapes)
+    S = sum(h * w for h, w in shapes)
+    sh = torch.tensor(shapes, dtype=torch.long).cuda()
+    lsi = torch.cat((sh.new_zeros(1), sh.prod(1).cumsum(0)[:-1]))
+    if not native.prologue_geometry_supported(N, S, M, 32, L, Lq, P):
+        pytest.skip("geometry outside the fused prologue")
+    value = (torch.rand(N, S, M, 32, generator=g) - 0.5).cuda()
+    ref = (torch.rand(N, Lq, L, 2, generator=g) * 1.4 - 0.2).cuda()
+    off = (torch.randn(N, Lq, M, L, P, 2, generator=g) * 2.0).cuda()
+    logits = torch.randn(N, Lq, M, L * P, generator=g).cuda()
+    go = torch.randn(N, Lq, M * 32, generator=g).cuda()
+    out, loc, attn = native.ms_deform_attn_forward_prologue(value, sh, lsi, ref, off, logits, 64)
+    base = native.ms_deform_attn_backward_prologue(value, sh, lsi, loc, attn, go, deterministic=False)
+    det1 = native.ms_deform_attn_backward_prologue(value, sh, lsi, loc, attn, go, deterministic=True)
+    det2 = native.ms_deform_attn_backward_prologue(value, sh, lsi, loc, attn, go, deterministic=True)
+    torch.cuda.synchronize()
+    for a, b in zip(det1, det2):
+        assert torch.equal(a, b)
+    assert rel_err(det1[0].cpu().numpy(), base[0].cpu().numpy()) < 2e-5            # grad_value
+    for k in (1, 2, 3):                                                             # offsets, logits, reference points
+        assert torch.equal(det1[k], base[k])

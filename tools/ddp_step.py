@@ -85,6 +85,10 @@ def main():
     ap.add_argument("--ballast-mb", type=float, default=0.0)
     ap.add_argument("--levels", default="28,14,7,4")
     ap.add_argument("--dropout", type=float, default=0.1, help="util/settings.py:113")
+    ap.add_argument("--vote", action="store_true",
+                    help="f4 A/B: the reference's per-step barrier() + all_reduce(num_err) skip vote (engine.py:564-572)")
+    ap.add_argument("--find-unused", action="store_true",
+                    help="f4 A/B: DistributedDataParallel(find_unused_parameters=True) as in main.py:97")
     ap.add_argument("--plain-layers", action="store_true",
                     help="A/B: stock add + LayerNorm and stock FFN weight gradients inside the layers")
     ap.add_argument("--amp", default="", choices=["", "bf16"],
@@ -103,7 +107,7 @@ def main():
                                      plain_layers=args.plain_layers).to(device)
     if distributed:
         model = nn.parallel.DistributedDataParallel(model, device_ids=[dev_index] if backend == "nccl" else None,
-                                                    gradient_as_bucket_view=True)
+                                                    gradient_as_bucket_view=True, find_unused_parameters=args.find_unused)
     opt = torch.optim.AdamW(model.parameters(), lr=2e-5, weight_decay=1e-4)
 
     shapes_list = [(int(x), int(x)) for x in args.levels.split(",")]
@@ -121,7 +125,14 @@ def main():
             if isinstance(mod, MSDeformAttn):
                 mod.bf16_storage = True
 
+    num_err = torch.zeros(1, dtype=torch.int64, device=device)
+
     def step():
+        if args.vote and distributed:                       # engine.py:564-572: every rank agrees the batch is valid
+            torch.distributed.barrier()
+            torch.distributed.all_reduce(num_err)
+            if int(num_err.item()) > 0:                     # (the host read is part of what the vote costs)
+                return torch.zeros((), device=device)
         opt.zero_grad(set_to_none=True)
         if args.amp == "bf16":
             with torch.autocast("cuda", dtype=torch.bfloat16):
@@ -157,7 +168,8 @@ def main():
                           "ms_per_step": 1e3 * elapsed / args.steps, "steps": args.steps,
                           "per_rank": {"window": args.window, "S": S, "queries": args.queries, "enc": args.enc,
                                        "dec": args.dec, "ballast_mb": args.ballast_mb, "amp": args.amp or None,
-                                       "dropout": args.dropout, "layers": "plain" if args.plain_layers else "fused"},
+                                       "dropout": args.dropout, "layers": "plain" if args.plain_layers else "fused",
+                                       "vote": args.vote, "find_unused_parameters": args.find_unused},
                           "backend": backend if distributed else None, "loss_finite": finite,
                           "params_in_sync": in_sync, "ranks": digests}))
     if distributed:

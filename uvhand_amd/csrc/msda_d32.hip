@@ -1112,8 +1112,13 @@ static int launch_bwd_cells_t(const VT *grad_out, const VT *value, const int64_t
     static const int skip_a = env_int("MSDA_CELL_SKIP_A", 0), skip_b = env_int("MSDA_CELL_SKIP_B", 0);   // measurement only
     const int ipw = kCWaves * 8 / split;
     const size_t lds_a = (size_t)ipw * item_stride + (size_t)ipw * LP * 16;
-    // Large problems: two launches (role B cells, role A query-major), each with its own occupancy.
-    if ((long long)Lq * P > kCellChunkPoints || cl.nB + n_a(split) > 1024) {
+    // Large problems: two launches (role B cells, role A query-major), each with its own occupancy.  With the fused
+    // prologue role A needs whole queries per (here 256-thread) workgroup: take fewer wavefronts per octet until M divides
+    // the items per workgroup, or stay with the single launch.
+    int sp_q = pick_split(items, LP);
+    if (FUSED) while (sp_q > 1 && (32 / sp_q) % M != 0) sp_q >>= 1;
+    const bool whole_queries = !FUSED || (32 / sp_q) % M == 0;
+    if (whole_queries && ((long long)Lq * P > kCellChunkPoints || cl.nB + n_a(split) > 1024)) {
         if (!skip_b) {
             if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_cell_d32_kernel<VT, GT>), kCellLdsBytes)) return rc;
             static const int persist = env_int("MSDA_CELL_PERSIST", 0);           // diagnostic builds: 0 = one workgroup per block
@@ -1129,7 +1134,7 @@ static int launch_bwd_cells_t(const VT *grad_out, const VT *value, const int64_t
             }
         }
         if (!skip_a) {
-            const int sp = pick_split(items, LP);
+            const int sp = sp_q;
             const int ipw_a = 32 / sp;
             const size_t lds_q = (size_t)ipw_a * item_stride + (size_t)ipw_a * LP * 16;
             const dim3 qgrid((items + ipw_a - 1) / ipw_a);
