@@ -107,6 +107,9 @@ ORACLE_CASES = {
     "wide_map":      (1, [(3, 40), (20, 2)], 8, 32, 64, 4),
     "few_queries":   (1, [(40, 40), (20, 20)], 8, 32, 3, 2),                    # more rows than record slots per workgroup
     "flat_levels":   (2, [(9, 9), (9, 9), (8, 10)], 8, 32, 120, 4),             # equal-size levels: no range skew
+    # N*M*L >= 256 with one level of 1920 pixels and Lq*P = 1536: the fused backward launch asks for > 64 KiB of
+    # dynamic LDS (tp_cap 1920 rows + 4*1536 records) — hipFuncSetAttribute on the fused kernels (round 1 review)
+    "one_big_level": (32, [(40, 48)], 8, 32, 384, 4),
 }
 
 
