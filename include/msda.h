@@ -234,6 +234,11 @@ int msda_linear_wgrad_f32(const float *grad_out, const float *input, int M, int 
  * row_mask: one byte per row (a torch.bool tensor's storage).  cols must be a multiple of 4, x 16-byte aligned. */
 int msda_linear_wgrad_masked_f32(const float *grad_out, const float *input, const uint8_t *row_mask, int M, int N, int K,
                                  float *grad_weight, float *grad_bias, void *workspace, msda_stream_t stream);
+/* bf16 operands (what the layer sees under torch.autocast(bfloat16)), fp32 products, accumulation and results: the weight
+ * gradient reaches the fp32 master parameter without a rounding to bf16 in between, at half the operand bytes.  Same
+ * workspace size as the f32 entry point; grad_out / input 8-byte aligned. */
+int msda_linear_wgrad_masked_bf16(const uint16_t *grad_out, const uint16_t *input, const uint8_t *row_mask, int M, int N, int K,
+                                  float *grad_weight, float *grad_bias, void *workspace, msda_stream_t stream);
 int msda_zero_masked_rows_f32(float *x, const uint8_t *row_mask, long long rows, int cols, msda_stream_t stream);
 
 /* Thread-local description of the last failure on the calling thread ("" if none). */

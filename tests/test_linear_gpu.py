@@ -126,3 +126,43 @@ def test_wgrad_random_shapes(M, N, K, frac):
     scale_w = max(1.0, float(np.abs(ref_w).max()))
     assert np.abs(gw.cpu().numpy() - ref_w).max() < 3e-6 * scale_w * max(1.0, np.sqrt(M) / 8)
     assert np.abs(gb.cpu().numpy() - ref_b).max() < 3e-6 * max(1.0, float(np.abs(ref_b).max())) * max(1.0, np.sqrt(M) / 8)
+
+
+@pytest.mark.parametrize("M,N,K", [(600, 256, 256), (600, 384, 256), (33, 8, 12), (6120, 256, 1024)])
+def test_bf16_operand_weight_gradient(M, N, K):
+    """msda_linear_wgrad_masked_bf16: bf16 operands, fp32 products and sums — equal to the fp32 kernel on the same
+    (bf16-representable) values, bit for bit, and within 2e-6 of an fp64 product."""
+    from uvhand_amd import _native
+    g = torch.Generator().manual_seed(M + N + K)
+    go = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda()
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    gw, gb = _native.linear_wgrad(go, x)
+    gw32, gb32 = _native.linear_wgrad(go.float(), x.float())
+    assert gw.dtype == torch.float32 and torch.equal(gw, gw32) and torch.equal(gb, gb32)
+    ref = go.double().t() @ x.double()
+    assert (gw.double() - ref).abs().max().item() < 2e-6 * ref.abs().max().item()
+
+
+def test_bracket_linear_under_bf16_autocast_uses_the_kernel_and_tracks_stock_autocast(monkeypatch):
+    from uvhand_amd import _native
+    from uvhand_amd.functions.linear_func import bracket_linear
+    calls = []
+    orig = _native.linear_wgrad
+    monkeypatch.setattr(_native, "linear_wgrad", lambda *a, **k: (calls.append(a[0].dtype), orig(*a, **k))[1])
+    torch.manual_seed(0)
+    layer = torch.nn.Linear(256, 128).cuda()
+    x = torch.randn(4, 150, 256, device="cuda", requires_grad=True)
+    go = torch.randn(4, 150, 128, device="cuda")
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = bracket_linear(x, layer)
+    assert y.dtype == torch.bfloat16
+    y.backward(go.to(y.dtype))
+    got = (y.detach().float(), x.grad.clone(), layer.weight.grad.clone(), layer.bias.grad.clone())
+    assert calls == [torch.bfloat16] and got[2].dtype == torch.float32
+    layer.zero_grad(); x.grad = None
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y2 = layer(x)
+    y2.backward(go.to(y2.dtype))
+    assert torch.equal(got[0], y2.detach().float())                       # same forward
+    for a, b in ((got[1], x.grad), (got[2], layer.weight.grad), (got[3], layer.bias.grad)):
+        assert (a - b).abs().max().item() < 2e-2 * b.abs().max().item()   # stock rounds dW to bf16; the kernel does not

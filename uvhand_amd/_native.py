@@ -26,7 +26,7 @@ _SYMBOLS = (
     "msda_backward_workspace_bytes", "msda_backward_ws_f32", "msda_backward_ws_bf16", "msda_backward_ws_bf16_gv32",
     "msda_backward_prologue_ws_f32", "msda_forward_prologue_bf16", "msda_backward_prologue_bf16_gv32",
     "msda_add_layernorm_workspace_bytes", "msda_add_layernorm_forward_f32", "msda_add_layernorm_backward_f32",
-    "msda_linear_wgrad_f32", "msda_linear_wgrad_masked_f32", "msda_linear_wgrad_workspace_bytes",
+    "msda_linear_wgrad_f32", "msda_linear_wgrad_masked_f32", "msda_linear_wgrad_masked_bf16", "msda_linear_wgrad_workspace_bytes",
     "msda_zero_masked_rows_f32",
     "msda_prologue_supported", "msda_forward_prologue_f32", "msda_backward_prologue_f32",
     "msda_last_error", "msda_version", "msda_path_for", "msda_force_path",
@@ -267,8 +267,9 @@ _WGRAD_ARGTYPES = [_VP, _VP, _VP, _CI, _CI, _CI, _VP, _VP, _VP, _VP]
 
 
 def linear_wgrad_supported(grad_out, inp):
-    """fp32, contiguous 2-D views [M, N] / [M, K] on one GPU, N and K multiples of 4."""
-    return (grad_out.is_cuda and inp.is_cuda and grad_out.dtype == torch.float32 and inp.dtype == torch.float32
+    """fp32 (or both bfloat16), contiguous 2-D views [M, N] / [M, K] on one GPU, N and K multiples of 4."""
+    return (grad_out.is_cuda and inp.is_cuda and grad_out.dtype == inp.dtype
+            and grad_out.dtype in (torch.float32, torch.bfloat16)
             and grad_out.dim() == 2 and inp.dim() == 2 and grad_out.shape[0] == inp.shape[0]
             and grad_out.is_contiguous() and inp.is_contiguous() and grad_out.device == inp.device
             and grad_out.shape[1] % 4 == 0 and inp.shape[1] % 4 == 0 and inp.shape[0] < (1 << 30)
@@ -298,11 +299,11 @@ def zero_masked_rows_(x, row_mask):
 
 
 def linear_wgrad(grad_out, inp, want_bias=True, row_mask=None):
-    """(grad_weight[N,K], grad_bias[N] or None) = (grad_out^T @ inp, grad_out.sum(0)) — include/msda.h.
-    Rows of grad_out with row_mask[r] True count as zero."""
+    """(grad_weight[N,K], grad_bias[N] or None) = (grad_out^T @ inp, grad_out.sum(0)) — include/msda.h; float32 results
+    also for bfloat16 operands.  Rows of grad_out with row_mask[r] True count as zero."""
     lib = _lib or load()
     if not linear_wgrad_supported(grad_out, inp):
-        raise RuntimeError("linear_wgrad: expected contiguous fp32 CUDA matrices [M,N] and [M,K] with N, K % 4 == 0")
+        raise RuntimeError("linear_wgrad: expected contiguous fp32 (or both bf16) CUDA matrices [M,N] and [M,K] with N, K % 4 == 0")
     M, N = grad_out.shape
     K = inp.shape[1]
     with _DeviceGuard(inp.device):
@@ -310,7 +311,7 @@ def linear_wgrad(grad_out, inp, want_bias=True, row_mask=None):
         gb = torch.empty((N,), dtype=torch.float32, device=inp.device) if want_bias else None
         nbytes = lib.msda_linear_wgrad_workspace_bytes(M, N, K)
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=inp.device) if nbytes else None
-        rc = _entry(lib, "msda_linear_wgrad_masked_f32", _WGRAD_ARGTYPES)(
+        rc = _entry(lib, "msda_linear_wgrad_masked_" + ("bf16" if grad_out.dtype == torch.bfloat16 else "f32"), _WGRAD_ARGTYPES)(
             grad_out.data_ptr(), inp.data_ptr(), _row_mask_ptr(row_mask, M, inp.device), M, N, K, gw.data_ptr(),
             gb.data_ptr() if want_bias else None,
             ws.data_ptr() if ws is not None else None, _raw_stream(inp.device))

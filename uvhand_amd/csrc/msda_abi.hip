@@ -435,6 +435,26 @@ int msda_linear_wgrad_masked_f32(const float *grad_out, const float *input, cons
                                      static_cast<float *>(workspace), (hipStream_t)stream);
 }
 
+int msda_linear_wgrad_masked_bf16(const uint16_t *grad_out, const uint16_t *input, const uint8_t *row_mask, int M, int N, int K,
+                                  float *grad_weight, float *grad_bias, void *workspace, msda_stream_t stream)
+{
+    if (M < 0 || N <= 0 || K <= 0 || (N & 3) || (K & 3))
+        return msda::set_error(MSDA_ERR_ARGUMENT, "msda_linear_wgrad_masked_bf16: need N, K > 0 and multiples of 4");
+    if (grad_weight == nullptr || (M > 0 && (grad_out == nullptr || input == nullptr)))
+        return msda::set_error(MSDA_ERR_ARGUMENT, "msda_linear_wgrad_masked_bf16: null device pointer");
+    if (!msda::aligned_to(grad_out, 8) || !msda::aligned_to(input, 8) || !msda::aligned_to(workspace, 16))
+        return msda::set_error(MSDA_ERR_ARGUMENT, "msda_linear_wgrad_masked_bf16: grad_out and input must be 8-byte, workspace "
+                                                  "16-byte aligned");
+    msda::begin_call();
+    if (M == 0) {
+        hipError_t e = hipMemsetAsync(grad_weight, 0, sizeof(float) * (size_t)N * K, (hipStream_t)stream);
+        if (e == hipSuccess && grad_bias) e = hipMemsetAsync(grad_bias, 0, sizeof(float) * (size_t)N, (hipStream_t)stream);
+        return e == hipSuccess ? MSDA_OK : msda::set_error(MSDA_ERR_LAUNCH, hipGetErrorString(e));
+    }
+    return msda::launch_linear_wgrad_bf16(grad_out, input, row_mask, M, N, K, grad_weight, grad_bias,
+                                          static_cast<float *>(workspace), (hipStream_t)stream);
+}
+
 int msda_zero_masked_rows_f32(float *x, const uint8_t *row_mask, long long rows, int cols, msda_stream_t stream)
 {
     if (rows < 0 || cols <= 0 || (cols & 3) || ((uintptr_t)x & 15))

@@ -95,6 +95,9 @@ size_t linear_wgrad_workspace_bytes(int M, int N, int K);
 // row_mask (may be null): one byte per row of dY, non-zero = that row counts as zero
 int launch_linear_wgrad(const float *dY, const float *X, const uint8_t *row_mask, int M, int N, int K, float *dW, float *db,
                         float *workspace, hipStream_t stream);
+// bf16 operands (uint16_t bits), fp32 products / accumulation / results
+int launch_linear_wgrad_bf16(const uint16_t *dY, const uint16_t *X, const uint8_t *row_mask, int M, int N, int K, float *dW,
+                             float *db, float *workspace, hipStream_t stream);
 int launch_zero_masked_rows(float *x, const uint8_t *mask, long long rows, int cols, hipStream_t stream);
 
 // ---- residual add + LayerNorm of the layers around the op (msda_layernorm.hip) ---------------------

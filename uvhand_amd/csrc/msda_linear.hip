@@ -65,8 +65,21 @@ constexpr int kWgStage = 32;       // reduction rows per LDS stage (64 measured:
 constexpr int kWgBlock = 256;      // 4 wavefronts
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
+// Operand storage: float, or bfloat16 bits (uint16_t) widened to fp32 on the way into LDS — the products and the
+// accumulation are the same exact fp32 MFMA chain either way (bf16 operands under autocast: half the operand bytes,
+// and a weight gradient that is NOT rounded to bf16 before it reaches the fp32 master parameter).
+template <typename OT> __device__ __forceinline__ float4 ld_operand4(const OT *p);
+template <> __device__ __forceinline__ float4 ld_operand4<float>(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+template <> __device__ __forceinline__ float4 ld_operand4<uint16_t>(const uint16_t *p)
+{
+    const uint2 u = *reinterpret_cast<const uint2 *>(p);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u));
+}
+
+template <typename OT>
 __global__ __launch_bounds__(kWgBlock) void linear_wgrad_partial_kernel(
-    const float *__restrict__ dY, const float *__restrict__ X, const uint8_t *__restrict__ row_mask, int M, int N, int K,
+    const OT *__restrict__ dY, const OT *__restrict__ X, const uint8_t *__restrict__ row_mask, int M, int N, int K,
     int chunk, int tiles, int splits, long long slab, float *__restrict__ out_w, float *__restrict__ out_b)
 {
     // `slab` = elements between consecutive splits' partial results (0 when there is one split and the
@@ -97,8 +110,8 @@ __global__ __launch_bounds__(kWgBlock) void linear_wgrad_partial_kernel(
             mk[r] = 0;                                                                                              \
             if (row_mask != nullptr && m < m_end) mk[r] = row_mask[m];                                              \
             ra[r] = zero; rb[r] = zero;                                                                             \
-            if (a_ok && m < m_end) ra[r] = *reinterpret_cast<const float4 *>(dY + (long long)m * N + n0 + lcol);    \
-            if (b_ok && m < m_end) rb[r] = *reinterpret_cast<const float4 *>(X + (long long)m * K + k0 + lcol);     \
+            if (a_ok && m < m_end) ra[r] = ld_operand4<OT>(dY + (long long)m * N + n0 + lcol);                      \
+            if (b_ok && m < m_end) rb[r] = ld_operand4<OT>(X + (long long)m * K + k0 + lcol);                       \
         }                                                                                                           \
     } while (0)
     f32x16 acc;
@@ -246,15 +259,16 @@ size_t linear_wgrad_workspace_bytes(int M, int N, int K)
     return splits <= 1 ? 0 : sizeof(float) * (size_t)splits * ((size_t)N * K + (size_t)N);
 }
 
-int launch_linear_wgrad(const float *dY, const float *X, const uint8_t *row_mask, int M, int N, int K, float *dW, float *db,
-                        float *workspace, hipStream_t stream)
+template <typename OT>
+static int launch_linear_wgrad_t(const OT *dY, const OT *X, const uint8_t *row_mask, int M, int N, int K, float *dW, float *db,
+                                 float *workspace, hipStream_t stream)
 {
     const int splits = wgrad_splits(M, N, K);
     int chunk = (M + splits - 1) / splits;
     chunk = ((chunk + kWgStage - 1) / kWgStage) * kWgStage;
     const int tiles = ((N + kWgTile - 1) / kWgTile) * ((K + kWgTile - 1) / kWgTile);
     const dim3 grid((unsigned)(tiles * splits));
-    auto partial = linear_wgrad_partial_kernel;
+    auto partial = linear_wgrad_partial_kernel<OT>;
     if (splits == 1) {
         hipLaunchKernelGGL(partial, grid, dim3(kWgBlock), 0, stream, dY, X, row_mask, M, N, K, chunk, tiles, splits, 0LL, dW, db);
         return check_launch("msda linear wgrad");
@@ -267,6 +281,17 @@ int launch_linear_wgrad(const float *dY, const float *X, const uint8_t *row_mask
     hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((unsigned)((slab / 4 + 63) / 64)), dim3(256), 0, stream, workspace,
                        splits, nw, slab, dW, db);
     return check_launch("msda linear wgrad (reduce)");
+}
+
+int launch_linear_wgrad(const float *dY, const float *X, const uint8_t *row_mask, int M, int N, int K, float *dW, float *db,
+                        float *workspace, hipStream_t stream)
+{
+    return launch_linear_wgrad_t<float>(dY, X, row_mask, M, N, K, dW, db, workspace, stream);
+}
+int launch_linear_wgrad_bf16(const uint16_t *dY, const uint16_t *X, const uint8_t *row_mask, int M, int N, int K, float *dW,
+                             float *db, float *workspace, hipStream_t stream)
+{
+    return launch_linear_wgrad_t<uint16_t>(dY, X, row_mask, M, N, K, dW, db, workspace, stream);
 }
 
 }  // namespace msda

@@ -8,9 +8,10 @@ on the vendor BLAS at these shapes, while the weight gradient ``dy^T @ x`` with 
 (tools/gemm_baseline.py).  Numerics: fp32 MFMA is an exact fp32 fma chain; the split-M partial sums
 are combined in a fixed order, so the result is reproducible run to run.
 
-Falls back to ``F.linear`` — PyTorch's own implementation of the same layer, not an alternative
-implementation of the op — whenever the kernel's preconditions do not hold (CPU tensors, non-fp32,
-autocast, feature counts not multiples of 4), so the module keeps working everywhere nn.Linear does.
+Under ``torch.autocast(bfloat16)`` the same is done on bf16 operands (``_BracketLinearAmpFn``).  Falls back to
+``F.linear`` — PyTorch's own implementation of the same layer, not an alternative implementation of the op —
+whenever the kernels' preconditions do not hold (CPU tensors, other dtypes, fp16 autocast, feature counts not
+multiples of 4), so the module keeps working everywhere nn.Linear does.
 """
 import os
 
@@ -46,6 +47,42 @@ class _BracketLinearFn(Function):
             else:
                 grad_w = go2c.t() @ x2c
                 grad_b = go2c.sum(0) if (ctx.has_bias and need_b) else None
+            if not need_w:
+                grad_w = None
+        return grad_x, grad_w, grad_b
+
+
+class _BracketLinearAmpFn(Function):
+    """The same layer under ``torch.autocast(dtype=torch.bfloat16)``: the forward is what autocast would run (operands
+    rounded to bf16, bf16 output); the backward takes the bf16-operand weight-gradient kernel — fp32 products and
+    accumulation, an fp32 result handed to the fp32 master parameter without a bf16 rounding in between — instead of the
+    vendor's small-M bf16 GEMM (49.7 us at M = 600, 2 x 118 us at M = 33 440: profiles/r02_notes.md section 7)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        xb, wb = x.to(torch.bfloat16), weight.to(torch.bfloat16)
+        ctx.save_for_backward(xb, wb)
+        ctx.has_bias = bias is not None
+        ctx.x_dtype = x.dtype
+        return F.linear(xb, wb, bias.to(torch.bfloat16) if bias is not None else None)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        xb, wb = ctx.saved_tensors
+        need_x, need_w, need_b = ctx.needs_input_grad
+        go2 = grad_out.reshape(-1, grad_out.shape[-1]).to(torch.bfloat16)
+        grad_x = grad_w = grad_b = None
+        if need_x:
+            grad_x = (go2 @ wb).view_as(xb).to(ctx.x_dtype)
+        if need_w or (need_b and ctx.has_bias):
+            x2 = xb.reshape(-1, xb.shape[-1])
+            go2c, x2c = go2.contiguous(), x2.contiguous()
+            if MSDA.linear_wgrad_supported(go2c, x2c):
+                grad_w, grad_b = MSDA.linear_wgrad(go2c, x2c, want_bias=ctx.has_bias and need_b)
+            else:
+                grad_w = (go2c.t() @ x2c).float()
+                grad_b = go2c.float().sum(0) if (ctx.has_bias and need_b) else None
             if not need_w:
                 grad_w = None
         return grad_x, grad_w, grad_b
@@ -99,10 +136,26 @@ def _kernel_applies(x, weight):
             and weight.shape[1] % 4 == 0 and weight.shape[0] % 4 == 0)
 
 
+def _autocast_dtype():
+    try:
+        return torch.get_autocast_dtype("cuda")
+    except (AttributeError, TypeError):                      # older torch
+        return torch.get_autocast_gpu_dtype()
+
+
+def _amp_kernel_applies(x, weight):
+    """bf16 autocast on CUDA around an fp32 layer (the reference trains its transformer this way when --amp is on)."""
+    return (_ENABLED and x.is_cuda and torch.is_autocast_enabled() and _autocast_dtype() == torch.bfloat16
+            and weight.dtype == torch.float32 and x.dtype in (torch.float32, torch.bfloat16) and torch.is_grad_enabled()
+            and weight.shape[1] % 4 == 0 and weight.shape[0] % 4 == 0)
+
+
 def bracket_linear_wb(x, weight, bias):
     """``F.linear(x, weight, bias)``; custom weight-gradient kernel when applicable."""
     if _kernel_applies(x, weight):
         return _BracketLinearFn.apply(x, weight, bias)
+    if _amp_kernel_applies(x, weight):
+        return _BracketLinearAmpFn.apply(x, weight, bias)
     return F.linear(x, weight, bias)
 
 
@@ -119,4 +172,6 @@ def bracket_linear(x, layer):
     """``layer(x)`` for an ``nn.Linear`` ``layer``; custom weight-gradient kernel when applicable."""
     if _kernel_applies(x, layer.weight):
         return _BracketLinearFn.apply(x, layer.weight, layer.bias)
+    if _amp_kernel_applies(x, layer.weight):
+        return _BracketLinearAmpFn.apply(x, layer.weight, layer.bias)
     return layer(x)
