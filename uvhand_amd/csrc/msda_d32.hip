@@ -930,7 +930,9 @@ bool d32_supported(int N, int S, int M, int D, int L, int Lq, int P)
     return true;
 }
 
-static int env_int(const char *name, int dflt) { return tuning_int(name, dflt); }   // diagnostic builds only (msda_launch.h)
+// Every MSDA_* knob named in this file is read in DIAGNOSTIC builds only (-DMSDA_TUNING, msda_launch.h); the shipped
+// library gets the defaults.
+static int env_int(const char *name, int dflt) { return tuning_int(name, dflt); }
 
 static int bwd_target_wgs()
 {
