@@ -76,3 +76,28 @@ def test_mixed_dtypes_fall_back_to_the_python_node(ext):
     v = value.half().requires_grad_(True)
     out = MSDeformAttnFunction.apply(v, shapes, lsi, loc, attn, 64)
     assert "MSDeformAttnFunction" in out.grad_fn.name() and out.dtype == torch.float32
+
+
+def test_bf16_cpp_node_equals_python_node(ext):
+    from torch.autograd import Function
+    from uvhand_amd.functions import MSDeformAttnBF16Function
+    z, value, shapes, lsi, loc, attn, go = _inputs("cfg1")
+    res = []
+    for vdtype in (torch.float32, torch.bfloat16):
+        for use_ext in (True, False):
+            v = value.to(vdtype).clone().requires_grad_(True)
+            l, a = loc.clone().requires_grad_(True), attn.clone().requires_grad_(True)
+            if use_ext:
+                out = MSDeformAttnBF16Function.apply(v, shapes, lsi, l, a, 64)
+                assert "MSDABF16Function" in out.grad_fn.name()
+            else:
+                out = Function.apply.__func__(MSDeformAttnBF16Function, v, shapes, lsi, l, a, 64)
+                assert "MSDeformAttnBF16Function" in out.grad_fn.name()
+            assert out.dtype == torch.bfloat16
+            out.backward(go.to(torch.bfloat16))
+            assert v.grad.dtype == vdtype
+            res.append((out.detach().float(), v.grad.float(), l.grad, a.grad))
+        x, y = res[-2], res[-1]
+        assert torch.equal(x[0], y[0]) and torch.equal(x[2], y[2]) and torch.equal(x[3], y[3])
+        assert rel_err(x[1].cpu().numpy(), y[1].cpu().numpy()) < 8e-3          # grad_value: summation order (+ bf16 rounding)
+    assert rel_err(res[0][0].cpu().numpy(), z["out"]) < 1e-2                  # bf16 rows vs the fp64 golden

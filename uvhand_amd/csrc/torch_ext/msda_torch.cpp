@@ -137,6 +137,97 @@ at::Tensor apply(const at::Tensor &value, const at::Tensor &shapes, const at::Te
     return MSDAFunction::apply(value, shapes, lsi, loc, attn, im2col_step, deterministic);
 }
 
+// ---- bf16 rows (uvhand_amd.functions.MSDeformAttnBF16Function as a C++ node; no reference counterpart) ----
+Dims dims_bf16(const at::Tensor &value, const at::Tensor &shapes, const at::Tensor &lsi, const at::Tensor &loc,
+               const at::Tensor &attn, int64_t im2col_step)
+{
+    TORCH_CHECK(value.scalar_type() == at::kBFloat16 && loc.scalar_type() == at::kFloat && attn.scalar_type() == at::kFloat,
+                "bf16 rows: expected bfloat16 value and float32 sampling_loc / attn_weight");
+    // shape / index checks are dtype-independent: run them on views that satisfy the dtype check of dims()
+    TORCH_CHECK(value.dim() == 4 && loc.dim() == 6 && attn.dim() == 5,
+                "ms_deform_attn: expected value[N,S,M,D], sampling_loc[N,Lq,M,L,P,2], attn_weight[N,Lq,M,L,P]");
+    Dims d;
+    d.N = (int)value.size(0); d.S = (int)value.size(1); d.M = (int)value.size(2); d.D = (int)value.size(3);
+    d.L = (int)shapes.size(0); d.Lq = (int)loc.size(1); d.P = (int)loc.size(4);
+    TORCH_CHECK(loc.sizes() == at::IntArrayRef({d.N, d.Lq, d.M, d.L, d.P, 2}) && attn.sizes() == at::IntArrayRef({d.N, d.Lq, d.M, d.L, d.P}),
+                "ms_deform_attn: sampling_loc ", loc.sizes(), " / attn_weight ", attn.sizes(), " do not match value ", value.sizes());
+    TORCH_CHECK(shapes.scalar_type() == at::kLong && lsi.scalar_type() == at::kLong,
+                "expected scalar type Long for spatial_shapes / level_start_index");
+    TORCH_CHECK(shapes.dim() == 2 && shapes.size(1) == 2 && lsi.dim() == 1 && lsi.size(0) == d.L,
+                "ms_deform_attn: spatial_shapes must be [L,2] and level_start_index [L]");
+    const int64_t step = std::min<int64_t>(d.N, im2col_step);
+    TORCH_CHECK(d.N == 0 || (step > 0 && d.N % step == 0), "batch(", d.N, ") must divide im2col_step(", step, ")");
+    return d;
+}
+
+inline const uint16_t *bf16_ptr(const at::Tensor &t) { return reinterpret_cast<const uint16_t *>(t.data_ptr<at::BFloat16>()); }
+inline uint16_t *bf16_mut(at::Tensor &t) { return reinterpret_cast<uint16_t *>(t.data_ptr<at::BFloat16>()); }
+
+class MSDABF16Function : public torch::autograd::Function<MSDABF16Function> {
+public:
+    static at::Tensor forward(torch::autograd::AutogradContext *ctx, const at::Tensor &value, const at::Tensor &shapes,
+                              const at::Tensor &lsi, const at::Tensor &loc, const at::Tensor &attn, int64_t im2col_step,
+                              bool deterministic)
+    {
+        ctx->saved_data["step"] = im2col_step;
+        ctx->saved_data["det"] = deterministic;
+        ctx->save_for_backward({value, shapes, lsi, loc, attn});
+        const at::Tensor v16 = value.to(at::kBFloat16), l32 = loc.to(at::kFloat), a32 = attn.to(at::kFloat);
+        check_inputs({{"value", &v16}, {"spatial_shapes", &shapes}, {"level_start_index", &lsi}, {"sampling_loc", &l32},
+                      {"attn_weight", &a32}});
+        const Dims d = dims_bf16(v16, shapes, lsi, l32, a32, im2col_step);
+        c10::hip::HIPGuardMasqueradingAsCUDA guard(v16.device());
+        auto out = at::empty({d.N, d.Lq, (int64_t)d.M * d.D}, v16.options());
+        auto stream = (msda_stream_t)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(v16.device().index()).stream();
+        raise_if(msda_forward_bf16(bf16_ptr(v16), shapes.data_ptr<int64_t>(), lsi.data_ptr<int64_t>(), l32.data_ptr<float>(),
+                                   a32.data_ptr<float>(), d.N, d.S, d.M, d.D, d.L, d.Lq, d.P, bf16_mut(out), stream),
+                 "ms_deform_attn_forward (bf16 rows)");
+        return out;
+    }
+
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext *ctx, torch::autograd::variable_list grads)
+    {
+        const auto saved = ctx->get_saved_variables();
+        const at::Tensor &value = saved[0], &shapes = saved[1], &lsi = saved[2], &loc = saved[3], &attn = saved[4];
+        const at::Tensor v16 = value.to(at::kBFloat16), l32 = loc.to(at::kFloat), a32 = attn.to(at::kFloat);
+        const at::Tensor go = grads[0].to(at::kBFloat16).contiguous();
+        check_inputs({{"value", &v16}, {"spatial_shapes", &shapes}, {"level_start_index", &lsi}, {"sampling_loc", &l32},
+                      {"attn_weight", &a32}, {"grad_output", &go}});
+        const Dims d = dims_bf16(v16, shapes, lsi, l32, a32, ctx->saved_data["step"].toInt());
+        TORCH_CHECK(go.numel() == (int64_t)d.N * d.Lq * d.M * d.D, "ms_deform_attn_backward: grad_output has the wrong size");
+        // fp32 grad_value straight from the kernel when that is what `value` needs, and for multi-pass backwards
+        const bool gv32 = value.scalar_type() == at::kFloat || msda_backward_passes(d.Lq, d.P) > 1;
+        const unsigned flags = ctx->saved_data["det"].toBool() ? MSDA_FLAG_DETERMINISTIC : 0u;
+        c10::hip::HIPGuardMasqueradingAsCUDA guard(v16.device());
+        auto gv = at::empty_like(v16, v16.options().dtype(gv32 ? at::kFloat : at::kBFloat16));
+        auto gl = at::empty_like(l32), ga = at::empty_like(a32);
+        at::Tensor ws;
+        const unsigned long long nbytes = flags ? msda_backward_workspace_bytes(d.N, d.S, d.M, d.D, d.L, d.Lq, d.P, flags) : 0;
+        if (nbytes) ws = at::empty({(int64_t)nbytes}, v16.options().dtype(at::kByte));
+        auto stream = (msda_stream_t)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(v16.device().index()).stream();
+        int rc;
+        if (gv32)
+            rc = msda_backward_ws_bf16_gv32(bf16_ptr(go), bf16_ptr(v16), shapes.data_ptr<int64_t>(), lsi.data_ptr<int64_t>(),
+                                            l32.data_ptr<float>(), a32.data_ptr<float>(), d.N, d.S, d.M, d.D, d.L, d.Lq, d.P,
+                                            gv.data_ptr<float>(), gl.data_ptr<float>(), ga.data_ptr<float>(),
+                                            nbytes ? ws.data_ptr() : nullptr, nbytes, flags, stream);
+        else
+            rc = msda_backward_ws_bf16(bf16_ptr(go), bf16_ptr(v16), shapes.data_ptr<int64_t>(), lsi.data_ptr<int64_t>(),
+                                       l32.data_ptr<float>(), a32.data_ptr<float>(), d.N, d.S, d.M, d.D, d.L, d.Lq, d.P, bf16_mut(gv),
+                                       gl.data_ptr<float>(), ga.data_ptr<float>(), nbytes ? ws.data_ptr() : nullptr, nbytes, flags,
+                                       stream);
+        raise_if(rc, "ms_deform_attn_backward (bf16 rows)");
+        return {gv.to(value.scalar_type()), at::Tensor(), at::Tensor(), gl.to(loc.scalar_type()), ga.to(attn.scalar_type()),
+                at::Tensor(), at::Tensor()};
+    }
+};
+
+at::Tensor apply_bf16(const at::Tensor &value, const at::Tensor &shapes, const at::Tensor &lsi, const at::Tensor &loc,
+                      const at::Tensor &attn, int64_t im2col_step, bool deterministic)
+{
+    return MSDABF16Function::apply(value, shapes, lsi, loc, attn, im2col_step, deterministic);
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
@@ -145,5 +236,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("ms_deform_attn_forward", &forward, "replaces MSDA.ms_deform_attn_forward (vision.cpp:14)");
     m.def("ms_deform_attn_backward", &backward, "replaces MSDA.ms_deform_attn_backward (vision.cpp:15)");
     m.def("apply", &apply, "MSDeformAttnFunction.apply as a C++ autograd node");
+    m.def("apply_bf16", &apply_bf16, "MSDeformAttnBF16Function.apply as a C++ autograd node");
     m.def("abi_version", [] { return msda_version(); });
 }

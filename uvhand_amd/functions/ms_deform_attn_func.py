@@ -80,6 +80,19 @@ class MSDeformAttnBF16Function(Function):
     D = 32 kernel family implements it.
     """
 
+    @classmethod
+    def apply(cls, value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights,
+              im2col_step):
+        ext = _ext.get()                       # the same node in C++ when the torch extension is built (see above)
+        if (ext is not None and hasattr(ext, "apply_bf16") and torch.is_tensor(value) and value.is_cuda
+                and value.dtype in (torch.float32, torch.bfloat16) and torch.is_tensor(sampling_locations)
+                and sampling_locations.is_floating_point() and torch.is_tensor(attention_weights)
+                and attention_weights.is_floating_point() and not torch.is_autocast_enabled()):
+            return ext.apply_bf16(value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                                  attention_weights, int(im2col_step), MSDA.deterministic_requested())
+        return super().apply(value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights,
+                             im2col_step)
+
     @staticmethod
     def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations,
                 attention_weights, im2col_step):
