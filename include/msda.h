@@ -258,6 +258,23 @@ int msda_add_layernorm_backward_f32(const float *grad_y, const float *x, const f
                                     const float *mean, const float *rstd, long long rows, int d, float *grad_sum,
                                     float *grad_gamma, float *grad_beta, void *workspace, msda_stream_t stream);
 
+/* ---- Transformer input assembly -----------------------------------------------------
+ * The flatten block of DeformableTransformer.forward (models/arctic_transformer.py:162-173): per level
+ * src_l[N,C,H,W] -> rows [level_start_l, level_start_l + H*W) of src_flatten[N,S,C], and pos_l the same way with
+ * level_embed[l][C] added — one tiled-transpose launch for all levels and both tensors instead of the reference's
+ * strided torch.cat copies and the add.  `src_levels` / `pos_levels` are HOST arrays of L device pointers, `heights` /
+ * `widths` host arrays (the caller knows the feature-map shapes as Python ints; nothing is read back from the device);
+ * either tensor family may be NULL.  msda_unflatten_levels_f32 is the inverse copy (the backward: flattened gradient rows
+ * back into per-level NCHW gradients, and — with grad_level_embed and a workspace of msda_unflatten_workspace_bytes — the
+ * level-embedding gradient as per-tile column sums combined in a fixed order).  fp32, C a multiple of 4, L <= 16. */
+int msda_flatten_levels_f32(int L, const float *const *src_levels, const float *const *pos_levels, const float *level_embed,
+                            const int *heights, const int *widths, int N, int C, float *src_flatten, float *pos_flatten,
+                            msda_stream_t stream);
+int msda_unflatten_levels_f32(int L, float *const *grad_src_levels, float *const *grad_pos_levels, const int *heights,
+                              const int *widths, int N, int C, const float *grad_src_flatten, const float *grad_pos_flatten,
+                              float *grad_level_embed /* [L, C] or NULL */, void *workspace, msda_stream_t stream);
+unsigned long long msda_unflatten_workspace_bytes(int L, const int *heights, const int *widths, int N, int C);
+
 const char *msda_last_error(void);
 
 /* Library/ABI version (major*100 + minor) and the kernel family a geometry maps to. */

@@ -107,3 +107,36 @@ def test_flatten_and_decoder_reference_points_match_the_reference():
 @pytest.mark.gpu
 def test_flatten_and_decoder_reference_points_match_the_reference_on_device():
     _check_flatten("cuda")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,C,shapes", [(3, 8, [(12, 16), (6, 8), (3, 4), (2, 2)]), (2, 256, [(28, 28), (14, 14), (7, 7), (4, 4)]),
+                                         (1, 68, [(5, 67), (1, 1)]), (2, 4, [(1, 130)])])
+def test_native_flatten_equals_the_reference_composition_with_gradients(N, C, shapes, monkeypatch):
+    """msda_flatten_levels_f32 / msda_unflatten_levels_f32 against the reference's composition (flatten(2).transpose(1, 2),
+    + level_embed, cat — models/arctic_transformer.py:162-173) run by PyTorch on the same device tensors: identical
+    values (copies and one fp32 add), identical gradients for the feature maps, positional maps and the level embedding."""
+    from uvhand_amd import _native
+    calls = {"f": 0, "u": 0}
+    for name, key in (("flatten_levels", "f"), ("unflatten_levels", "u")):
+        orig = getattr(_native, name)
+        monkeypatch.setattr(_native, name, lambda *a, _o=orig, _k=key, **k: (calls.__setitem__(_k, calls[_k] + 1), _o(*a, **k))[1])
+    g = torch.Generator().manual_seed(N * 100 + C)
+    mk = lambda: [torch.randn(N, C, h, w, generator=g).cuda().requires_grad_(True) for h, w in shapes]
+    srcs, poss = mk(), mk()
+    masks = [torch.zeros(N, h, w, dtype=torch.bool).cuda() for h, w in shapes]
+    embed = torch.randn(len(shapes), C, generator=g).cuda().requires_grad_(True)
+    src, mask, pos, ss, lsi, valid = flatten_feature_levels(srcs, masks, poss, embed)
+    assert calls["f"] == 1
+    S = sum(h * w for h, w in shapes)
+    ref_src = torch.cat([t.flatten(2).transpose(1, 2) for t in srcs], 1)
+    ref_pos = torch.cat([t.flatten(2).transpose(1, 2) + embed[l].view(1, 1, -1) for l, t in enumerate(poss)], 1)
+    assert src.shape == (N, S, C) and torch.equal(src, ref_src) and torch.equal(pos, ref_pos)
+    assert ss.tolist() == [list(s) for s in shapes] and int(lsi[-1]) == S - shapes[-1][0] * shapes[-1][1]
+    g1, g2 = torch.randn(N, S, C, generator=g).cuda(), torch.randn(N, S, C, generator=g).cuda()
+    got = torch.autograd.grad([src, pos], srcs + poss + [embed], [g1, g2])
+    want = torch.autograd.grad([ref_src, ref_pos], srcs + poss + [embed], [g1, g2])
+    assert calls["u"] == 1
+    for a, b in zip(got[:-1], want[:-1]):
+        assert torch.equal(a, b)
+    assert torch.allclose(got[-1], want[-1], rtol=1e-5, atol=1e-5)            # level-embedding column sums: summation order

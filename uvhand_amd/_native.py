@@ -26,6 +26,7 @@ _SYMBOLS = (
     "msda_backward_workspace_bytes", "msda_backward_ws_f32", "msda_backward_ws_bf16", "msda_backward_ws_bf16_gv32",
     "msda_backward_prologue_ws_f32", "msda_forward_prologue_bf16", "msda_backward_prologue_bf16_gv32",
     "msda_add_layernorm_workspace_bytes", "msda_add_layernorm_forward_f32", "msda_add_layernorm_backward_f32",
+    "msda_flatten_levels_f32", "msda_unflatten_levels_f32", "msda_unflatten_workspace_bytes",
     "msda_linear_wgrad_f32", "msda_linear_wgrad_masked_f32", "msda_linear_wgrad_masked_bf16", "msda_linear_wgrad_workspace_bytes",
     "msda_zero_masked_rows_f32",
     "msda_prologue_supported", "msda_forward_prologue_f32", "msda_backward_prologue_f32",
@@ -54,6 +55,8 @@ def load():
     lib.msda_prologue_supported.argtypes = [ctypes.c_int] * 7
     lib.msda_backward_workspace_bytes.restype = ctypes.c_ulonglong
     lib.msda_backward_workspace_bytes.argtypes = [ctypes.c_int] * 7 + [ctypes.c_uint]
+    lib.msda_unflatten_workspace_bytes.restype = ctypes.c_ulonglong
+    lib.msda_unflatten_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     lib.msda_add_layernorm_workspace_bytes.restype = ctypes.c_ulonglong
     lib.msda_add_layernorm_workspace_bytes.argtypes = [ctypes.c_longlong, ctypes.c_int]
     lib.msda_linear_wgrad_workspace_bytes.restype = ctypes.c_ulonglong
@@ -502,6 +505,73 @@ def add_layernorm_backward(grad_y, x, residual, weight, mean, rstd):
     if rc != 0:
         _raise(lib, rc, "add_layernorm_backward")
     return gs, gw, gb
+
+
+def flatten_levels_supported(srcs, poss, level_embed):
+    """fp32 contiguous NCHW CUDA feature maps of one batch size / channel count (a multiple of 4), at most 16 levels."""
+    ts = list(srcs) + list(poss)
+    if not ts or len(srcs) != len(poss) or len(srcs) > 16:
+        return False
+    n, c = ts[0].shape[0], ts[0].shape[1]
+    return (c % 4 == 0 and all(t.dim() == 4 and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+                               and t.shape[0] == n and t.shape[1] == c and t.device == ts[0].device for t in ts)
+            and all(s.shape == p.shape for s, p in zip(srcs, poss))
+            and level_embed.is_cuda and level_embed.dtype == torch.float32 and level_embed.is_contiguous()
+            and tuple(level_embed.shape) == (len(srcs), c) and level_embed.data_ptr() % 16 == 0)
+
+
+def _level_arrays(tensors):
+    L = len(tensors)
+    ptrs = (ctypes.c_void_p * L)(*[t.data_ptr() for t in tensors])
+    hs = (ctypes.c_int * L)(*[t.shape[2] for t in tensors])
+    ws = (ctypes.c_int * L)(*[t.shape[3] for t in tensors])
+    return ptrs, hs, ws
+
+
+def flatten_levels(srcs, poss, level_embed):
+    """(src_flatten[N,S,C], lvl_pos_embed_flatten[N,S,C]) — msda_flatten_levels_f32 (include/msda.h)."""
+    lib = _lib or load()
+    L, (N, C) = len(srcs), srcs[0].shape[:2]
+    S = sum(t.shape[2] * t.shape[3] for t in srcs)
+    sp, hs, ws = _level_arrays(srcs)
+    pp, _, _ = _level_arrays(poss)
+    with _DeviceGuard(srcs[0].device):
+        src_flat = torch.empty((N, S, C), dtype=torch.float32, device=srcs[0].device)
+        pos_flat = torch.empty((N, S, C), dtype=torch.float32, device=srcs[0].device)
+        rc = _entry(lib, "msda_flatten_levels_f32", [_CI] + [_VP] * 5 + [_CI, _CI] + [_VP] * 3)(
+            L, sp, pp, level_embed.data_ptr(), hs, ws, N, C, src_flat.data_ptr(), pos_flat.data_ptr(),
+            _raw_stream(srcs[0].device))
+    if rc != 0:
+        _raise(lib, rc, "flatten_levels")
+    return src_flat, pos_flat
+
+
+def unflatten_levels(grad_src_flat, grad_pos_flat, shapes_nchw, want_level_embed=False):
+    """Per-level NCHW gradients from the flattened ones (either may be None) and, on request, the level-embedding
+    gradient [L, C] — msda_unflatten_levels_f32."""
+    lib = _lib or load()
+    ref = grad_src_flat if grad_src_flat is not None else grad_pos_flat
+    N, S, C = ref.shape
+    L = len(shapes_nchw)
+    with _DeviceGuard(ref.device):
+        gs = [torch.empty(sh, dtype=torch.float32, device=ref.device) for sh in shapes_nchw] if grad_src_flat is not None else None
+        gp = [torch.empty(sh, dtype=torch.float32, device=ref.device) for sh in shapes_nchw] if grad_pos_flat is not None else None
+        hs = (ctypes.c_int * L)(*[sh[2] for sh in shapes_nchw])
+        ws_ = (ctypes.c_int * L)(*[sh[3] for sh in shapes_nchw])
+        sp = _level_arrays(gs)[0] if gs is not None else None
+        pp = _level_arrays(gp)[0] if gp is not None else None
+        gembed = ws = None
+        if want_level_embed and grad_pos_flat is not None:
+            gembed = torch.empty((L, C), dtype=torch.float32, device=ref.device)
+            nbytes = max(16, int(lib.msda_unflatten_workspace_bytes(L, hs, ws_, N, C)))
+            ws = torch.empty((nbytes,), dtype=torch.uint8, device=ref.device)
+        rc = _entry(lib, "msda_unflatten_levels_f32", [_CI] + [_VP] * 4 + [_CI, _CI] + [_VP] * 5)(
+            L, sp, pp, hs, ws_, N, C, grad_src_flat.data_ptr() if grad_src_flat is not None else None,
+            grad_pos_flat.data_ptr() if grad_pos_flat is not None else None,
+            gembed.data_ptr() if gembed is not None else None, ws.data_ptr() if ws is not None else None, _raw_stream(ref.device))
+    if rc != 0:
+        _raise(lib, rc, "unflatten_levels")
+    return gs, gp, gembed
 
 
 def path_for(elem_bytes, M, D, L, P):

@@ -518,6 +518,77 @@ int msda_add_layernorm_backward_f32(const float *grad_y, const float *x, const f
                                           static_cast<float *>(workspace), (hipStream_t)stream);
 }
 
+static int flatten_impl(const char *who, int L, float *const *src_levels, float *const *pos_levels, const float *level_embed,
+                        const int *heights, const int *widths, int N, int C, float *src_flatten, float *pos_flatten, bool unflatten,
+                        msda_stream_t stream, float *grad_level_embed = nullptr, void *workspace = nullptr,
+                        unsigned long long *workspace_bytes_out = nullptr)
+{
+    char buf[200];
+    if (L <= 0 || L > msda::kMaxLevels || N < 0 || C <= 0 || (C & 3) || heights == nullptr || widths == nullptr) {
+        std::snprintf(buf, sizeof(buf), "%s: need 1 <= L <= %d, N >= 0, C > 0 and a multiple of 4, host arrays of H and W", who,
+                      msda::kMaxLevels);
+        return msda::set_error(MSDA_ERR_ARGUMENT, buf);
+    }
+    msda::FlattenPlan plan;
+    plan.L = L;
+    long long S = 0;
+    for (int l = 0; l < L; ++l) {
+        if (heights[l] <= 0 || widths[l] <= 0 || (long long)heights[l] * widths[l] > 0x3fffffffLL)
+            return msda::set_error(MSDA_ERR_ARGUMENT, "msda flatten: level sizes must be positive");
+        plan.src[l] = src_levels ? src_levels[l] : nullptr;
+        plan.pos[l] = pos_levels ? pos_levels[l] : nullptr;
+        if (N > 0 && ((src_flatten && plan.src[l] == nullptr) || (pos_flatten && plan.pos[l] == nullptr)))
+            return msda::set_error(MSDA_ERR_ARGUMENT, "msda flatten: null level pointer");
+        plan.hw[l] = heights[l] * widths[l];
+        plan.start[l] = (int)S;
+        plan.first_block[l] = 0;
+        S += plan.hw[l];
+    }
+    if (S > 0x3fffffffLL) return msda::set_error(MSDA_ERR_ARGUMENT, "msda flatten: too many pixels");
+    if (((uintptr_t)src_flatten & 15) || ((uintptr_t)pos_flatten & 15) || ((uintptr_t)level_embed & 15))
+        return msda::set_error(MSDA_ERR_ARGUMENT, "msda flatten: flattened tensors and level_embed must be 16-byte aligned");
+    if (workspace_bytes_out) { *workspace_bytes_out = N > 0 ? msda::unflatten_workspace_bytes(plan, N, C) : 0; return MSDA_OK; }
+    if (((uintptr_t)grad_level_embed & 15) || ((uintptr_t)workspace & 15))
+        return msda::set_error(MSDA_ERR_ARGUMENT, "msda unflatten: grad_level_embed and workspace must be 16-byte aligned");
+    msda::begin_call();
+    if (N == 0) {
+        if (grad_level_embed) {
+            const hipError_t e = hipMemsetAsync(grad_level_embed, 0, sizeof(float) * (size_t)L * C, (hipStream_t)stream);
+            if (e != hipSuccess) return msda::set_error(MSDA_ERR_LAUNCH, hipGetErrorString(e));
+        }
+        return MSDA_OK;
+    }
+    return msda::launch_flatten_levels(plan, N, C, (int)S, level_embed, src_flatten, pos_flatten, unflatten, (hipStream_t)stream,
+                                       grad_level_embed, static_cast<float *>(workspace));
+}
+
+int msda_flatten_levels_f32(int L, const float *const *src_levels, const float *const *pos_levels, const float *level_embed,
+                            const int *heights, const int *widths, int N, int C, float *src_flatten, float *pos_flatten,
+                            msda_stream_t stream)
+{
+    return flatten_impl("msda_flatten_levels_f32", L, const_cast<float *const *>(src_levels), const_cast<float *const *>(pos_levels),
+                        level_embed, heights, widths, N, C, src_flatten, pos_flatten, false, stream);
+}
+
+int msda_unflatten_levels_f32(int L, float *const *grad_src_levels, float *const *grad_pos_levels, const int *heights,
+                              const int *widths, int N, int C, const float *grad_src_flatten, const float *grad_pos_flatten,
+                              float *grad_level_embed, void *workspace, msda_stream_t stream)
+{
+    return flatten_impl("msda_unflatten_levels_f32", L, grad_src_levels, grad_pos_levels, nullptr, heights, widths, N, C,
+                        const_cast<float *>(grad_src_flatten), const_cast<float *>(grad_pos_flatten), true, stream,
+                        grad_level_embed, workspace);
+}
+
+unsigned long long msda_unflatten_workspace_bytes(int L, const int *heights, const int *widths, int N, int C)
+{
+    unsigned long long n = 0;
+    float *dummy[msda::kMaxLevels] = {};
+    if (flatten_impl("msda_unflatten_workspace_bytes", L, dummy, dummy, nullptr, heights, widths, N, C, nullptr, nullptr, true, nullptr,
+                     nullptr, nullptr, &n) != MSDA_OK)
+        return 0;
+    return n;
+}
+
 const char *msda_last_error(void) { return msda::g_err; }
 
 int msda_version(void) { return 101; }

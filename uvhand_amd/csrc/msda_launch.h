@@ -6,6 +6,7 @@
 #include <stdlib.h>
 
 #include "msda.h"
+#include "msda_common.h"
 
 namespace msda {
 
@@ -99,6 +100,17 @@ int launch_linear_wgrad(const float *dY, const float *X, const uint8_t *row_mask
 int launch_linear_wgrad_bf16(const uint16_t *dY, const uint16_t *X, const uint8_t *row_mask, int M, int N, int K, float *dW,
                              float *db, float *workspace, hipStream_t stream);
 int launch_zero_masked_rows(float *x, const uint8_t *mask, long long rows, int cols, hipStream_t stream);
+
+// ---- transformer input assembly (msda_flatten.hip): per-level NCHW <-> the flattened [N, S, C] layout ----
+struct FlattenPlan {
+    int L;
+    float *src[kMaxLevels];          // per level [N, C, H_l, W_l] (device), or null
+    float *pos[kMaxLevels];
+    int hw[kMaxLevels], start[kMaxLevels], first_block[kMaxLevels];
+};
+int launch_flatten_levels(const FlattenPlan &plan, int N, int C, int S, const float *level_embed, float *src_flat, float *pos_flat,
+                          bool unflatten, hipStream_t stream, float *grad_level_embed = nullptr, float *workspace = nullptr);
+size_t unflatten_workspace_bytes(const FlattenPlan &plan, int N, int C);
 
 // ---- residual add + LayerNorm of the layers around the op (msda_layernorm.hip) ---------------------
 size_t add_layernorm_workspace_bytes(long long rows, int d);

@@ -11,9 +11,42 @@
   * ``decoder_reference_points``  models/arctic_transformer.py:413-419 (2-d points, or the ARCTIC 42-d = 21 (x, y)
                                   keypoints, times the valid ratios of each level)
 
-Plain PyTorch on whatever device the inputs live on: layout work, no kernels of this package involved.
+On fp32 CUDA feature maps the flatten (both tensors, all levels, the level-embedding add) is ONE tiled-transpose HIP kernel
+per direction (``msda_flatten_levels_f32`` / ``msda_unflatten_levels_f32``, csrc/msda_flatten.hip); everything else — and
+the flatten on other devices / dtypes — is plain PyTorch layout work, exactly the reference's composition.
 """
 import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .. import _native
+
+
+class _FlattenLevelsFn(Function):
+    """(src_flatten, lvl_pos_embed_flatten) = flatten(srcs..., pos_embeds..., level_embed): one tiled-transpose kernel per
+    direction (msda_flatten_levels_f32 / msda_unflatten_levels_f32) instead of the strided torch.cat copies and the add."""
+
+    @staticmethod
+    def forward(ctx, level_embed, *maps):
+        L = len(maps) // 2
+        srcs, poss = maps[:L], maps[L:]
+        ctx.shapes = [tuple(t.shape) for t in srcs]
+        ctx.L = L
+        src_flat, pos_flat = _native.flatten_levels(srcs, poss, level_embed)
+        return src_flat, pos_flat
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_src_flat, grad_pos_flat):
+        L, need = ctx.L, ctx.needs_input_grad
+        need_src, need_pos = any(need[1:1 + L]), any(need[1 + L:])
+        gs = gp = g_embed = None
+        if need_src or need_pos or need[0]:
+            # the level-embedding gradient (column sums of grad_pos_flat per level) rides along with the positional copy
+            gs, gp, g_embed = _native.unflatten_levels(grad_src_flat.contiguous() if need_src else None,
+                                                       grad_pos_flat.contiguous() if (need_pos or need[0]) else None,
+                                                       ctx.shapes, want_level_embed=need[0])
+        return (g_embed,) + tuple(gs if gs is not None else [None] * L) + tuple(gp if (gp is not None and need_pos) else [None] * L)
 
 
 def get_valid_ratio(mask):
@@ -29,6 +62,16 @@ def flatten_feature_levels(srcs, masks, pos_embeds, level_embed):
     """srcs / pos_embeds: lists of [N,C,H_l,W_l]; masks: list of [N,H_l,W_l] bool; level_embed [L,C].
     Returns (src_flatten[N,S,C], mask_flatten[N,S], lvl_pos_embed_flatten[N,S,C], spatial_shapes int64[L,2],
     level_start_index int64[L], valid_ratios[N,L,2])."""
+    srcs, masks, pos_embeds = list(srcs), list(masks), list(pos_embeds)
+    if (not torch.is_autocast_enabled() and _native.flatten_levels_supported(srcs, pos_embeds, level_embed)):
+        # MI355X path: both flattened tensors from one kernel (and one for their gradients)
+        shapes = [(s.shape[2], s.shape[3]) for s in srcs]
+        src_flatten, pos_flatten = _FlattenLevelsFn.apply(level_embed, *srcs, *pos_embeds)
+        spatial_shapes = torch.as_tensor(shapes, dtype=torch.long, device=src_flatten.device)
+        level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
+        valid_ratios = torch.stack([get_valid_ratio(m) for m in masks], 1)
+        return (src_flatten, torch.cat([m.flatten(1) for m in masks], 1), pos_flatten, spatial_shapes, level_start_index,
+                valid_ratios)
     src_parts, mask_parts, pos_parts, shapes = [], [], [], []
     for lvl, (src, mask, pos) in enumerate(zip(srcs, masks, pos_embeds)):
         shapes.append((src.shape[2], src.shape[3]))
