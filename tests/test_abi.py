@@ -164,3 +164,43 @@ def test_torch_extension_loads_and_matches_the_library(native):
     assert mod.abi_version() == native.load().msda_version()
     for name in ("ms_deform_attn_forward", "ms_deform_attn_backward", "apply"):
         assert callable(getattr(mod, name))
+
+
+def test_argument_errors_are_reported_before_anything_is_launched(native):
+    """Bad sizes / null pointers come back as MSDA_ERR_ARGUMENT with a message — no GPU needed, nothing is enqueued."""
+    lib = ctypes.CDLL(native.LIB_PATH)
+    lib.msda_last_error.restype = ctypes.c_char_p
+    V, I, LL = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong
+    # residual add + LayerNorm: row width must be a multiple of 4, at most 1024
+    fn = lib.msda_add_layernorm_forward_f32
+    fn.argtypes = [V, V, V, V, LL, I, ctypes.c_float, V, V, V, V]
+    fn.restype = I
+    assert fn(None, None, None, None, 4, 6, 1e-5, None, None, None, None) == 1
+    assert b"multiple of 4" in lib.msda_last_error()
+    assert fn(None, None, None, None, 4, 2048, 1e-5, None, None, None, None) == 1
+    assert fn(None, None, None, None, 4, 256, 1e-5, None, None, None, None) == 1        # null pointers with rows > 0
+    # the op with flags / scratch: null tensors with a non-empty problem
+    fn = lib.msda_backward_ws_f32
+    fn.argtypes = [V] * 6 + [I] * 7 + [V] * 4 + [ctypes.c_ulonglong, ctypes.c_uint, V]
+    fn.restype = I
+    assert fn(None, None, None, None, None, None, 1, 4, 8, 32, 1, 2, 4, None, None, None, None, 0, 1, None) == 1
+    assert b"null device pointer" in lib.msda_last_error()
+    assert fn(None, None, None, None, None, None, 1, 4, 0, 32, 1, 2, 4, None, None, None, None, 0, 1, None) == 1   # M = 0
+    # pyramid flatten: level count and channel width
+    fn = lib.msda_flatten_levels_f32
+    fn.argtypes = [I, V, V, V, V, V, I, I, V, V, V]
+    fn.restype = I
+    hs, ws = (I * 1)(4), (I * 1)(4)
+    assert fn(0, None, None, None, hs, ws, 1, 8, None, None, None) == 1
+    assert fn(1, None, None, None, hs, ws, 1, 6, None, None, None) == 1
+    assert fn(17, None, None, None, hs, ws, 1, 8, None, None, None) == 1
+    # sizes only (no pointers, no launch)
+    lib.msda_backward_workspace_bytes.restype = ctypes.c_ulonglong
+    lib.msda_backward_workspace_bytes.argtypes = [I] * 7 + [ctypes.c_uint]
+    assert lib.msda_backward_workspace_bytes(2, 3060, 8, 32, 4, 300, 4, 1) == 0           # decoder regime: no query chunks
+    assert lib.msda_backward_workspace_bytes(2, 3060, 8, 32, 4, 3060, 4, 1) > 0           # encoder regime, few pairs
+    assert lib.msda_backward_workspace_bytes(2, 3060, 8, 32, 4, 3060, 4, 0) == 0           # default kernels need none
+    lib.msda_unflatten_workspace_bytes.restype = ctypes.c_ulonglong
+    lib.msda_unflatten_workspace_bytes.argtypes = [I, V, V, I, I]
+    hs4, ws4 = (I * 4)(28, 14, 7, 4), (I * 4)(28, 14, 7, 4)
+    assert lib.msda_unflatten_workspace_bytes(4, hs4, ws4, 32, 256) == 32 * (13 + 4 + 1 + 1) * 4 * 64 * 4
