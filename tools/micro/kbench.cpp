@@ -9,6 +9,7 @@
 #include "../../uvhand_amd/csrc/msda_d32.hip"
 #include "../../uvhand_amd/csrc/msda_linear.hip"
 #include "../../uvhand_amd/csrc/msda_layernorm.hip"
+#include "../../uvhand_amd/csrc/msda_flatten.hip"
 
 #include <algorithm>
 #include <cstdio>
