@@ -287,7 +287,12 @@ def main():
 
         for _ in range((args.warmup + per_graph - 1) // per_graph):
             run()
-        blocks = [timed_block(run, args.steps // per_graph) for _ in range(max(1, args.repeats))]
+        # --repeats blocks, but no more than fit in ~5 s of timed work (the first block tells how long one takes)
+        blocks = [timed_block(run, args.steps // per_graph)]
+        fit = int(5.0 / max(blocks[0], 1e-6))
+        n_blocks = max(1, min(args.repeats, max(3, fit)))
+        n_blocks = int(harness.max_over_ranks(n_blocks, device) + 0.5) if world > 1 else n_blocks    # same count on every rank
+        blocks += [timed_block(run, args.steps // per_graph) for _ in range(n_blocks - 1)]
 
         # the other two launch modes of the same step, for the record (not `value`)
         side = {}
