@@ -187,3 +187,24 @@ def test_deterministic_fused_prologue_backward(native, M, Lq, shapes):
     assert rel_err(det1[0].cpu().numpy(), base[0].cpu().numpy()) < 2e-5            # grad_value
     for k in (1, 2, 3):                                                             # offsets, logits, reference points
         assert torch.equal(det1[k], base[k])
+
+
+@pytest.mark.parametrize("name", ["cfg2_decoder", "cfg2_encoder", "cfg4_decoder", "cfg4_encoder"])
+def test_deterministic_full_size_shapes(native, name):
+    """BASELINE's full sizes: the adjoint identity <out, go> = <value, grad_value> (the op is linear in value), agreement
+    with the default kernels, and reproducibility.  cfg-2 encoder is the chunked case (query chunks + slab reduce), the
+    cfg-4 shapes run role B and role A as two launches."""
+    from test_parity_gpu import FULL
+    z = make_case(0, *FULL[name], lo=-0.1, hi=1.1)
+    t = {k: dev(z[k]) for k in ("value", "loc", "attn", "grad_out")}
+    sh, ls = dev(z["shapes"]), dev(z["level_start"])
+    out = native.ms_deform_attn_forward(t["value"], sh, ls, t["loc"], t["attn"], 64)
+    base = native.ms_deform_attn_backward(t["value"], sh, ls, t["loc"], t["attn"], t["grad_out"], 64, deterministic=False)
+    det = native.ms_deform_attn_backward(t["value"], sh, ls, t["loc"], t["attn"], t["grad_out"], 64, deterministic=True)
+    det2 = native.ms_deform_attn_backward(t["value"], sh, ls, t["loc"], t["attn"], t["grad_out"], 64, deterministic=True)
+    torch.cuda.synchronize()
+    dot = (out.double() * t["grad_out"].double()).sum().item()
+    assert abs(dot - (t["value"].double() * det[0].double()).sum().item()) < 1e-5 * abs(dot)
+    assert rel_err(det[0].cpu().numpy(), base[0].cpu().numpy()) < 2e-5
+    assert torch.equal(det[1], base[1]) and torch.equal(det[2], base[2])          # role A is the same arithmetic
+    assert all(torch.equal(a, b) for a, b in zip(det, det2))
