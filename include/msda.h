@@ -99,8 +99,10 @@ int msda_backward_f64(const double *grad_out, const double *value, const int64_t
                       double *grad_value, double *grad_sampling_loc, double *grad_attn_weight,
                       msda_stream_t stream);
 
-/* bf16 tensors are passed as uint16_t* (raw bfloat16 bits).  Returns MSDA_ERR_ARGUMENT for
- * geometries outside the D = 32 kernel family. */
+/* bf16 tensors are passed as uint16_t* (raw bfloat16 bits); all arithmetic and accumulation is fp32, one rounding at
+ * the final store.  D = 32 geometries take the tiled kernels, every other D (or rows at an odd element offset) the
+ * generic ones.  msda_backward_bf16 (bf16 grad_value) exists for the D = 32 family only and returns MSDA_ERR_ARGUMENT
+ * elsewhere — msda_backward_bf16_gv32 below serves every geometry (msda_path_for(2, M, D, L, P) tells which is which). */
 int msda_forward_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start,
                       const float *sampling_loc, const float *attn_weight,
                       int N, int S, int M, int D, int L, int Lq, int P,

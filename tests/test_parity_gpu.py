@@ -148,6 +148,10 @@ def test_random_geometries_match_c_oracle(native, oracle, idx, case):
         assert rel_err(gl[keep], r_gl[keep]) < 2e-5, case
 
 
+def _bf16_round(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(torch.bfloat16).float().numpy()
+
+
 def _misaligned_copy(t):
     """Same values, contiguous, but starting one element into its storage (4-byte aligned for fp32 only)."""
     buf = torch.empty(t.numel() + 1, dtype=t.dtype, device=t.device)
@@ -158,7 +162,7 @@ def _misaligned_copy(t):
 
 def test_contiguous_views_at_odd_offsets(native, oracle):
     """Tensors that are contiguous but not 16-byte aligned (views one element into a buffer): fp32 calls are
-    served by the element-wise generic kernels with the same results; bf16 rows are refused loudly."""
+    served by the element-wise generic kernels with the same results, and so are bf16 rows (fp32 grad_value)."""
     z = make_case(21, *ORACLE_CASES["model_small"])
     s, i = dev(z["shapes"]), dev(z["level_start"])
     v, l, a, go = (_misaligned_copy(dev(z[k])) for k in ("value", "loc", "attn", "grad_out"))
@@ -171,9 +175,19 @@ def test_contiguous_views_at_odd_offsets(native, oracle):
     assert rel_err(gv.cpu().numpy(), r_gv) < 2e-5 and rel_err(ga.cpu().numpy(), r_ga) < 2e-5
     keep = ~near_boundary_mask(z, tol=1e-5)
     assert rel_err(gl.cpu().numpy()[keep], r_gl[keep]) < 2e-5
-    v16 = _misaligned_copy(dev(z["value"]).to(torch.bfloat16))           # 2-byte aligned
-    with pytest.raises(RuntimeError, match="aligned"):
-        native.ms_deform_attn_forward(v16, s, i, dev(z["loc"]), dev(z["attn"]), 64)
+    # bf16 rows at a 2-byte offset: generic kernels too (fp32 grad_value; the bf16 grad_value entry is D = 32-family only)
+    zr = dict(z, value=_bf16_round(z["value"]), grad_out=_bf16_round(z["grad_out"]))
+    v16 = _misaligned_copy(dev(zr["value"]).to(torch.bfloat16))
+    go16 = _misaligned_copy(dev(zr["grad_out"]).to(torch.bfloat16))
+    assert v16.data_ptr() % 8 != 0
+    args = [zr["value"], z["shapes"], z["level_start"], z["loc"], z["attn"]]
+    out16 = native.ms_deform_attn_forward(v16, s, i, dev(z["loc"]), dev(z["attn"]), 64)
+    assert rel_err(out16.float().cpu().numpy(), oracle.forward(*args)) < 4e-3
+    gv, gl, ga = native.ms_deform_attn_backward(v16, s, i, dev(z["loc"]), dev(z["attn"]), go16, 64, fp32_grad_value=True)
+    r_gv, r_gl, r_ga = oracle.backward(zr["grad_out"], *args)
+    assert rel_err(gv.cpu().numpy(), r_gv) < 2e-5 and rel_err(ga.cpu().numpy(), r_ga) < 2e-5
+    with pytest.raises(RuntimeError, match="msda_backward_bf16_gv32 serves"):
+        native.ms_deform_attn_backward(v16, s, i, dev(z["loc"]), dev(z["attn"]), go16, 64)
     assert not native.linear_wgrad_supported(_misaligned_copy(torch.zeros(8, 8, device="cuda")), torch.zeros(8, 8, device="cuda"))
 
 
@@ -203,6 +217,55 @@ def test_random_generic_geometries_match_c_oracle(native, oracle, idx, case):
         keep = ~near_boundary_mask(zz, tol=1e-5 if dtype == torch.float32 else 1e-12)
         if keep.any():
             assert rel_err(gl[keep], r_gl[keep]) < tol, (case, dtype)
+
+
+@pytest.mark.parametrize("idx,case", list(enumerate(_random_generic_geometries(10, 777))))
+def test_bf16_rows_on_generic_geometries(native, oracle, idx, case):
+    """bf16 rows outside the D = 32 family (any D): generic kernels, fp32 arithmetic and grad_value.  Tolerances as for
+    the D = 32 bf16 tests: forward (rounded once to bf16) 4e-3 of max, the fp32 gradients 2e-5; the autograd Function
+    returns grad_value in value's dtype."""
+    from uvhand_amd.functions import MSDeformAttnBF16Function
+    z = make_case(900 + idx, *case)
+    z["value"] = _bf16_round(z["value"])
+    z["grad_out"] = _bf16_round(z["grad_out"])
+    args = [z["value"], z["shapes"], z["level_start"], z["loc"], z["attn"]]
+    r_out = oracle.forward(*args)
+    r_gv, r_gl, r_ga = oracle.backward(z["grad_out"], *args)
+    v16, go16 = dev(z["value"]).to(torch.bfloat16), dev(z["grad_out"]).to(torch.bfloat16)
+    s, i, l, a = dev(z["shapes"]), dev(z["level_start"]), dev(z["loc"]), dev(z["attn"])
+    out = native.ms_deform_attn_forward(v16, s, i, l, a, 64)
+    assert out.dtype == torch.bfloat16 and rel_err(out.float().cpu().numpy(), r_out) < 4e-3, case
+    gv, gl, ga = native.ms_deform_attn_backward(v16, s, i, l, a, go16, 64, fp32_grad_value=True)
+    keep = ~near_boundary_mask(z, tol=1e-5)
+    assert rel_err(gv.cpu().numpy(), r_gv) < 2e-5 and rel_err(ga.cpu().numpy(), r_ga) < 2e-5, case
+    if keep.any():
+        assert rel_err(gl.cpu().numpy()[keep], r_gl[keep]) < 2e-5, case
+    vq = v16.clone().requires_grad_(True)
+    lq, aq = l.clone().requires_grad_(True), a.clone().requires_grad_(True)
+    MSDeformAttnBF16Function.apply(vq, s, i, lq, aq, 64).backward(go16)
+    assert vq.grad.dtype == torch.bfloat16 and rel_err(vq.grad.float().cpu().numpy(), r_gv) < 4e-3, case
+    assert rel_err(aq.grad.cpu().numpy(), r_ga) < 2e-5, case
+
+
+def test_bf16_generic_and_d32_families_agree(native, oracle):
+    """The same bf16 call through both kernel families (msda_force_path): fp32 gradients within summation-order distance,
+    the bf16 output within one rounding."""
+    z = make_case(31, *ORACLE_CASES["model_small"])
+    v16, go16 = dev(z["value"]).to(torch.bfloat16), dev(z["grad_out"]).to(torch.bfloat16)
+    s, i, l, a = dev(z["shapes"]), dev(z["level_start"]), dev(z["loc"]), dev(z["attn"])
+    res = []
+    try:
+        for path in (native.PATH_D32, native.PATH_GENERIC):
+            native.force_path(path)
+            out = native.ms_deform_attn_forward(v16, s, i, l, a, 64)
+            res.append((out.float().cpu().numpy(),) + tuple(
+                t.cpu().numpy() for t in native.ms_deform_attn_backward(v16, s, i, l, a, go16, 64, fp32_grad_value=True)))
+    finally:
+        native.force_path(-1)
+    assert rel_err(res[0][0], res[1][0]) < 4e-3
+    keep = ~near_boundary_mask(z, tol=1e-5)
+    assert rel_err(res[0][1], res[1][1]) < 2e-5 and rel_err(res[0][3], res[1][3]) < 2e-5
+    assert rel_err(res[0][2][keep], res[1][2][keep]) < 2e-5
 
 
 @pytest.mark.parametrize("spread", [0.0, 0.02, 0.2])
@@ -460,10 +523,6 @@ def test_runs_on_the_current_stream_without_sync(native):
 # ---------------------------------------------------------------------------------------------
 # bf16 storage (BASELINE config 3): new capability, judged against the fp32/fp64 oracle
 # ---------------------------------------------------------------------------------------------
-def _bf16_round(a):
-    return torch.from_numpy(np.ascontiguousarray(a)).to(torch.bfloat16).float().numpy()
-
-
 @pytest.mark.parametrize("name", ["model_small", "ragged_items", "many_queries", "cfg2_decoder"])
 def test_bf16_storage_matches_oracle_on_rounded_inputs(native, oracle, name):
     """Tolerances (stated): with value and grad_out pre-rounded to bf16 the only
@@ -555,11 +614,16 @@ def test_bf16_storage_vs_fp32_path_and_errors(native):
     MSDeformAttnFunction.apply(vref, s, i, l, a, 64).sum().backward()
     assert v32.grad.dtype == torch.float32
     assert rel_err(v32.grad.cpu().numpy(), vref.grad.cpu().numpy()) < 1e-5      # same weights, grad_out = 1 exactly
-    # D != 32 has no bf16 kernel: loud error, no silent fallback
+    # D != 32: the generic kernels serve bf16 rows (test_bf16_rows_on_generic_geometries); only the bf16-grad_value
+    # ABI entry is refused there, loudly
     zz = make_case(5, *ORACLE_CASES["d64"])
-    with pytest.raises(RuntimeError, match="bf16"):
-        MSDeformAttnBF16Function.apply(dev(zz["value"]), dev(zz["shapes"]), dev(zz["level_start"]),
-                                       dev(zz["loc"]), dev(zz["attn"]), 64)
+    o64 = MSDeformAttnBF16Function.apply(dev(zz["value"]), dev(zz["shapes"]), dev(zz["level_start"]),
+                                         dev(zz["loc"]), dev(zz["attn"]), 64)
+    r64 = MSDeformAttnFunction.apply(dev(zz["value"]), dev(zz["shapes"]), dev(zz["level_start"]), dev(zz["loc"]), dev(zz["attn"]), 64)
+    assert o64.dtype == torch.bfloat16 and torch.allclose(o64.float(), r64, rtol=2e-2, atol=1e-3 * r64.abs().max().item())
+    with pytest.raises(RuntimeError, match="msda_backward_bf16_gv32 serves"):
+        native.ms_deform_attn_backward(dev(zz["value"]).bfloat16(), dev(zz["shapes"]), dev(zz["level_start"]), dev(zz["loc"]),
+                                       dev(zz["attn"]), dev(zz["grad_out"]).bfloat16(), 64)
 
 
 def test_beyond_int32_element_offsets_uses_the_generic_kernels(native):

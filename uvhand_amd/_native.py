@@ -230,7 +230,7 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
                             im2col_step, fp32_grad_value=False, deterministic=None):
     """Replaces MSDA.ms_deform_attn_backward (vision.cpp:15).
     Returns (grad_value, grad_sampling_loc, grad_attn_weight).  fp32_grad_value (bf16 rows only): grad_value
-    comes back in float32 (msda_backward_bf16_gv32, include/msda.h).  deterministic (None = deterministic_requested()):
+    comes back in float32 (msda_backward_bf16_gv32, include/msda.h; the only bf16 backward outside D = 32).  deterministic (None = deterministic_requested()):
     bitwise reproducible grad_value (MSDA_FLAG_DETERMINISTIC; D = 32 kernel family, fp32 / bf16 rows)."""
     lib = _lib or load()
     _check_inputs((("value", value), ("spatial_shapes", spatial_shapes),
@@ -572,6 +572,9 @@ def unflatten_levels(grad_src_flat, grad_pos_flat, shapes_nchw, want_level_embed
     if rc != 0:
         _raise(lib, rc, "unflatten_levels")
     return gs, gp, gembed
+
+
+PATH_GENERIC, PATH_D32 = 0, 1          # MSDA_PATH_* (include/msda.h)
 
 
 def path_for(elem_bytes, M, D, L, P):

@@ -65,7 +65,7 @@ static int check_row_strides(const char *who, int M, int L, int P, const void *o
 
 // The D = 32 kernels move rows as 16-byte (fp32) / 8-byte (bf16) vectors and locations as (x, y) pairs.
 // Tensors straight from an allocator always qualify; a contiguous VIEW at an odd element offset does not —
-// fp32 calls then take the generic kernels (element-wise accesses), the others are refused.
+// fp32 / bf16 op calls then take the generic kernels (element-wise accesses); the prologue and wgrad entries refuse.
 static bool aligned_to(const void *p, size_t bytes) { return ((uintptr_t)p & (bytes - 1)) == 0; }
 
 static int refuse_unaligned(const char *who)
@@ -157,20 +157,26 @@ static int backward_bf16_impl(const uint16_t *grad_out, const uint16_t *value, c
         }
         return e == hipSuccess ? MSDA_OK : msda::set_error(MSDA_ERR_LAUNCH, hipGetErrorString(e));
     }
-    if (!msda::d32_supported(N, S, M, D, L, Lq, P))
-        return msda::set_error(MSDA_ERR_ARGUMENT, "msda bf16: only the D=32 kernel family implements bf16 storage "
-                                                  "(needs D == 32, L <= 16, L*P <= 32)");
-    if (!msda::aligned_to(grad_out, 8) || !msda::aligned_to(value, 8) || !msda::aligned_to(grad_value, sizeof(GT) * 4) ||
-        !msda::aligned_to(sampling_loc, 8) || !msda::aligned_to(grad_sampling_loc, 8))
-        return msda::refuse_unaligned("msda_backward_bf16");
-    if constexpr (sizeof(GT) == 2)
+    const bool d32 = msda::use_d32(N, S, M, D, L, Lq, P) && msda::aligned_to(grad_out, 8) && msda::aligned_to(value, 8) &&
+                     msda::aligned_to(grad_value, sizeof(GT) * 4) && msda::aligned_to(sampling_loc, 8) &&
+                     msda::aligned_to(grad_sampling_loc, 8);
+    if constexpr (sizeof(GT) == 2) {
+        if (!d32)
+            return msda::set_error(MSDA_ERR_ARGUMENT, "msda_backward_bf16: bf16 grad_value needs the D=32 kernel family (D == 32, "
+                                                      "L <= 16, L*P <= 32, 8-byte aligned rows); msda_backward_bf16_gv32 serves "
+                                                      "every other shape");
         return msda::launch_bwd_d32_bf16(grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M,
                                          L, Lq, P, grad_value, grad_sampling_loc, grad_attn_weight, (hipStream_t)stream,
                                          workspace, ws_bytes, (flags & MSDA_FLAG_DETERMINISTIC) != 0);
-    else
+    } else {
+        if (!d32)                                                   // element-wise accesses: any D, any element offset
+            return msda::launch_bwd_generic<float>(grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, N,
+                                                   S, M, D, L, Lq, P, grad_value, grad_sampling_loc, grad_attn_weight,
+                                                   (hipStream_t)stream);
         return msda::launch_bwd_d32_bf16_gv32(grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S,
                                               M, L, Lq, P, grad_value, grad_sampling_loc, grad_attn_weight,
                                               (hipStream_t)stream, workspace, ws_bytes, (flags & MSDA_FLAG_DETERMINISTIC) != 0);
+    }
 }
 
 extern "C" {
@@ -226,11 +232,10 @@ int msda_forward_bf16(const uint16_t *value, const int64_t *spatial_shapes, cons
         const hipError_t e = hipMemsetAsync(out, 0, 2 * (size_t)N * Lq * M * D, (hipStream_t)stream);
         return e == hipSuccess ? MSDA_OK : msda::set_error(MSDA_ERR_LAUNCH, hipGetErrorString(e));
     }
-    if (!msda::d32_supported(N, S, M, D, L, Lq, P))
-        return msda::set_error(MSDA_ERR_ARGUMENT, "msda bf16: only the D=32 kernel family implements bf16 storage "
-                                                  "(needs D == 32, L <= 16, L*P <= 32)");
-    if (!msda::aligned_to(value, 8) || !msda::aligned_to(out, 8) || !msda::aligned_to(sampling_loc, 8))
-        return msda::refuse_unaligned("msda_forward_bf16");
+    if (!msda::use_d32(N, S, M, D, L, Lq, P) || !msda::aligned_to(value, 8) || !msda::aligned_to(out, 8) ||
+        !msda::aligned_to(sampling_loc, 8))
+        return msda::launch_fwd_generic<float>(value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M, D, L, Lq,
+                                               P, out, (hipStream_t)stream);
     return msda::launch_fwd_d32_bf16(value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M, L, Lq, P,
                                      out, (hipStream_t)stream);
 }
@@ -596,7 +601,7 @@ int msda_version(void) { return 101; }
 int msda_path_for(int elem_bytes, int M, int D, int L, int P)
 {
     // N, S, Lq only matter through the int32-offset limits; probe with small ones.
-    return (elem_bytes == 4 && msda::use_d32(1, 1, M, D, L, 1, P)) ? MSDA_PATH_D32 : MSDA_PATH_GENERIC;
+    return ((elem_bytes == 4 || elem_bytes == 2) && msda::use_d32(1, 1, M, D, L, 1, P)) ? MSDA_PATH_D32 : MSDA_PATH_GENERIC;
 }
 
 void msda_force_path(int path) { msda::g_force_path.store(path, std::memory_order_relaxed); }

@@ -1,5 +1,6 @@
 // Generic multi-scale deformable attention kernels: any channel count D, any
-// (L, P), float or double.  One 64-lane wavefront owns one (batch, query, head)
+// (L, P), float or double — or bf16 rows (value / out / grad_out as bf16 bits,
+// fp32 arithmetic, fp32 grad_value) for the shapes the D = 32 family does not take.  One 64-lane wavefront owns one (batch, query, head)
 // item; lanes stride over the D channels, so a tap is read as contiguous
 // 4*64-byte (or 8*64-byte) runs and the three per-point gradients are reduced
 // across the wavefront with cross-lane shuffles — no LDS, no barriers.
@@ -19,12 +20,26 @@ namespace msda {
 constexpr int kGenericBlock = 256;                       // 4 wavefronts = 4 items per block
 constexpr int kGenericItemsPerBlock = kGenericBlock / kWave;
 
-template <typename T>
+// One row element: T itself, or bf16 bits widened to / rounded from float (round-to-nearest-even, like the D = 32 family).
+template <typename T, typename VT>
+__device__ __forceinline__ T ld_elem(const VT *p)
+{
+    if constexpr (sizeof(VT) == sizeof(T)) return *p;
+    else return __uint_as_float((uint32_t)*p << 16);
+}
+template <typename T, typename VT>
+__device__ __forceinline__ void st_elem(VT *p, T v)
+{
+    if constexpr (sizeof(VT) == sizeof(T)) *p = v;
+    else *p = __builtin_bit_cast(unsigned short, static_cast<__bf16>(v));
+}
+
+template <typename T, typename VT>
 __global__ __launch_bounds__(kGenericBlock) void fwd_generic_kernel(
-    const T *__restrict__ value, const int64_t *__restrict__ shapes,
+    const VT *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ level_start, const T *__restrict__ loc,
     const T *__restrict__ attn, int S, int M, int D, int L, int Lq, int P, long long items,
-    T *__restrict__ out)
+    VT *__restrict__ out)
 {
     const int lane = threadIdx.x & (kWave - 1);
     long long item = (long long)blockIdx.x * kGenericItemsPerBlock + (threadIdx.x >> 6);
@@ -43,7 +58,7 @@ __global__ __launch_bounds__(kGenericBlock) void fwd_generic_kernel(
         for (int l = 0; l < L; ++l) {
             const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
             if (!level_fits(shapes[2 * l], shapes[2 * l + 1], level_start[l], S)) continue;
-            const T *v = value + ((b * S + level_start[l]) * M + m) * D + (live ? c : 0);
+            const VT *v = value + ((b * S + level_start[l]) * M + m) * D + (live ? c : 0);
             for (int p = 0; p < P; ++p) {
                 const int k = l * P + p;
                 const PointGeom<T> g = point_geom<T>(lp[2 * k], lp[2 * k + 1], H, W);
@@ -54,15 +69,15 @@ __global__ __launch_bounds__(kGenericBlock) void fwd_generic_kernel(
                 const long long r1 = r0 + (long long)W * ws;
                 T v1 = 0, v2 = 0, v3 = 0, v4 = 0;
                 if (live) {
-                    if (g.ok00) v1 = v[r0];
-                    if (g.ok01) v2 = v[r0 + ws];
-                    if (g.ok10) v3 = v[r1];
-                    if (g.ok11) v4 = v[r1 + ws];
+                    if (g.ok00) v1 = ld_elem<T>(v + r0);
+                    if (g.ok01) v2 = ld_elem<T>(v + r0 + ws);
+                    if (g.ok10) v3 = ld_elem<T>(v + r1);
+                    if (g.ok11) v4 = ld_elem<T>(v + r1 + ws);
                 }
                 acc += (hh * hw * v1 + hh * g.lw * v2 + g.lh * hw * v3 + g.lh * g.lw * v4) * a;
             }
         }
-        if (live) out[item * D + c] = acc;
+        if (live) st_elem<T>(out + item * D + c, acc);
     }
 }
 
@@ -71,9 +86,9 @@ __global__ __launch_bounds__(kGenericBlock) void fwd_generic_kernel(
 // the channels, written once per point (zero for a point outside the map, as the
 // reference's shared-memory variants produce, ms_deform_im2col_cuda.cuh:365-393).
 // grad_value must be zero on entry (the launcher enqueues the memset).
-template <typename T>
+template <typename T, typename VT>
 __global__ __launch_bounds__(kGenericBlock) void bwd_generic_kernel(
-    const T *__restrict__ grad_out, const T *__restrict__ value,
+    const VT *__restrict__ grad_out, const VT *__restrict__ value,
     const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
     const T *__restrict__ loc, const T *__restrict__ attn, int S, int M, int D, int L, int Lq,
     int P, long long items, T *__restrict__ grad_value, T *__restrict__ grad_loc,
@@ -87,7 +102,7 @@ __global__ __launch_bounds__(kGenericBlock) void bwd_generic_kernel(
     const int LP = L * P;
     const T *lp = loc + item * LP * 2;
     const T *ap = attn + item * LP;
-    const T *go = grad_out + item * D;
+    const VT *go = grad_out + item * D;
     T *gl = grad_loc + item * LP * 2;
     T *ga = grad_attn + item * LP;
     const long long ws = (long long)M * D;
@@ -107,12 +122,12 @@ __global__ __launch_bounds__(kGenericBlock) void bwd_generic_kernel(
                 const long long r0 = lvl + ((long long)g.h0 * W + g.w0) * ws;
                 const long long r1 = r0 + (long long)W * ws;
                 for (int c = lane; c < D; c += kWave) {
-                    const T top = go[c], tv = top * a;
+                    const T top = ld_elem<T>(go + c), tv = top * a;
                     T v1 = 0, v2 = 0, v3 = 0, v4 = 0;
-                    if (g.ok00) { v1 = value[r0 + c];      atomicAdd(grad_value + r0 + c, k1 * tv); }
-                    if (g.ok01) { v2 = value[r0 + ws + c]; atomicAdd(grad_value + r0 + ws + c, k2 * tv); }
-                    if (g.ok10) { v3 = value[r1 + c];      atomicAdd(grad_value + r1 + c, k3 * tv); }
-                    if (g.ok11) { v4 = value[r1 + ws + c]; atomicAdd(grad_value + r1 + ws + c, k4 * tv); }
+                    if (g.ok00) { v1 = ld_elem<T>(value + r0 + c);      atomicAdd(grad_value + r0 + c, k1 * tv); }
+                    if (g.ok01) { v2 = ld_elem<T>(value + r0 + ws + c); atomicAdd(grad_value + r0 + ws + c, k2 * tv); }
+                    if (g.ok10) { v3 = ld_elem<T>(value + r1 + c);      atomicAdd(grad_value + r1 + c, k3 * tv); }
+                    if (g.ok11) { v4 = ld_elem<T>(value + r1 + ws + c); atomicAdd(grad_value + r1 + ws + c, k4 * tv); }
                     s_attn += top * (k1 * v1 + k2 * v2 + k3 * v3 + k4 * v4);
                     s_x += (hh * (v2 - v1) + g.lh * (v4 - v3)) * tv;    // d/dw of the bilinear form
                     s_y += (hw * (v3 - v1) + g.lw * (v4 - v2)) * tv;    // d/dh
@@ -126,21 +141,21 @@ __global__ __launch_bounds__(kGenericBlock) void bwd_generic_kernel(
     }
 }
 
-template <typename T>
-int launch_fwd_generic(const T *value, const int64_t *shapes, const int64_t *level_start,
+template <typename T, typename VT>
+int launch_fwd_generic(const VT *value, const int64_t *shapes, const int64_t *level_start,
                        const T *loc, const T *attn, int N, int S, int M, int D, int L, int Lq, int P,
-                       T *out, hipStream_t stream)
+                       VT *out, hipStream_t stream)
 {
     const long long items = (long long)N * Lq * M;
     const long long blocks = (items + kGenericItemsPerBlock - 1) / kGenericItemsPerBlock;
     if (blocks > 0x7fffffffLL) return set_error(MSDA_ERR_ARGUMENT, "N*Lq*M too large for one launch");
-    hipLaunchKernelGGL(fwd_generic_kernel<T>, dim3((unsigned)blocks), dim3(kGenericBlock), 0, stream,
+    hipLaunchKernelGGL((fwd_generic_kernel<T, VT>), dim3((unsigned)blocks), dim3(kGenericBlock), 0, stream,
                        value, shapes, level_start, loc, attn, S, M, D, L, Lq, P, items, out);
     return check_launch("msda forward (generic)");
 }
 
-template <typename T>
-int launch_bwd_generic(const T *grad_out, const T *value, const int64_t *shapes,
+template <typename T, typename VT>
+int launch_bwd_generic(const VT *grad_out, const VT *value, const int64_t *shapes,
                        const int64_t *level_start, const T *loc, const T *attn, int N, int S, int M,
                        int D, int L, int Lq, int P, T *grad_value, T *grad_loc, T *grad_attn,
                        hipStream_t stream)
@@ -150,23 +165,20 @@ int launch_bwd_generic(const T *grad_out, const T *value, const int64_t *shapes,
     if (blocks > 0x7fffffffLL) return set_error(MSDA_ERR_ARGUMENT, "N*Lq*M too large for one launch");
     hipError_t e = hipMemsetAsync(grad_value, 0, sizeof(T) * (size_t)N * S * M * D, stream);
     if (e != hipSuccess) return set_error(MSDA_ERR_LAUNCH, hipGetErrorString(e));
-    hipLaunchKernelGGL(bwd_generic_kernel<T>, dim3((unsigned)blocks), dim3(kGenericBlock), 0, stream,
+    hipLaunchKernelGGL((bwd_generic_kernel<T, VT>), dim3((unsigned)blocks), dim3(kGenericBlock), 0, stream,
                        grad_out, value, shapes, level_start, loc, attn, S, M, D, L, Lq, P, items,
                        grad_value, grad_loc, grad_attn);
     return check_launch("msda backward (generic)");
 }
 
-template int launch_fwd_generic<float>(const float *, const int64_t *, const int64_t *, const float *,
-                                       const float *, int, int, int, int, int, int, int, float *,
-                                       hipStream_t);
-template int launch_fwd_generic<double>(const double *, const int64_t *, const int64_t *,
-                                        const double *, const double *, int, int, int, int, int, int,
-                                        int, double *, hipStream_t);
-template int launch_bwd_generic<float>(const float *, const float *, const int64_t *, const int64_t *,
-                                       const float *, const float *, int, int, int, int, int, int, int,
-                                       float *, float *, float *, hipStream_t);
-template int launch_bwd_generic<double>(const double *, const double *, const int64_t *,
-                                        const int64_t *, const double *, const double *, int, int, int,
-                                        int, int, int, int, double *, double *, double *, hipStream_t);
+#define MSDA_GENERIC_INST(T, VT)                                                                                        \
+    template int launch_fwd_generic<T, VT>(const VT *, const int64_t *, const int64_t *, const T *, const T *, int, int, int, \
+                                           int, int, int, int, VT *, hipStream_t);                                            \
+    template int launch_bwd_generic<T, VT>(const VT *, const VT *, const int64_t *, const int64_t *, const T *, const T *,    \
+                                           int, int, int, int, int, int, int, T *, T *, T *, hipStream_t);
+MSDA_GENERIC_INST(float, float)
+MSDA_GENERIC_INST(double, double)
+MSDA_GENERIC_INST(float, uint16_t)       // bf16 rows, fp32 grad_value
+#undef MSDA_GENERIC_INST
 
 }  // namespace msda

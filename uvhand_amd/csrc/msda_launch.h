@@ -26,13 +26,13 @@ int set_error(int code, const char *msg);
 // Returns MSDA_OK, or records hipGetLastError() (prefixed by `what`) and returns MSDA_ERR_LAUNCH.
 int check_launch(const char *what);
 
-// ---- generic family (msda_generic.hip): any D, float / double -------------------------------
-template <typename T>
-int launch_fwd_generic(const T *value, const int64_t *shapes, const int64_t *level_start,
+// ---- generic family (msda_generic.hip): any D, float / double; VT = T, or uint16_t (bf16 rows) with T = float --------
+template <typename T, typename VT>
+int launch_fwd_generic(const VT *value, const int64_t *shapes, const int64_t *level_start,
                        const T *loc, const T *attn, int N, int S, int M, int D, int L, int Lq, int P,
-                       T *out, hipStream_t stream);
-template <typename T>
-int launch_bwd_generic(const T *grad_out, const T *value, const int64_t *shapes,
+                       VT *out, hipStream_t stream);
+template <typename T, typename VT>
+int launch_bwd_generic(const VT *grad_out, const VT *value, const int64_t *shapes,
                        const int64_t *level_start, const T *loc, const T *attn, int N, int S, int M,
                        int D, int L, int Lq, int P, T *grad_value, T *grad_loc, T *grad_attn,
                        hipStream_t stream);

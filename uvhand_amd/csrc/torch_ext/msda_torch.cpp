@@ -196,7 +196,10 @@ public:
         const Dims d = dims_bf16(v16, shapes, lsi, l32, a32, ctx->saved_data["step"].toInt());
         TORCH_CHECK(go.numel() == (int64_t)d.N * d.Lq * d.M * d.D, "ms_deform_attn_backward: grad_output has the wrong size");
         // fp32 grad_value straight from the kernel when that is what `value` needs, and for multi-pass backwards
-        const bool gv32 = value.scalar_type() == at::kFloat || msda_backward_passes(d.Lq, d.P) > 1;
+        // — and wherever the generic kernels serve the call (they accumulate grad_value with fp32 atomics only)
+        const bool gv32 = value.scalar_type() == at::kFloat || msda_backward_passes(d.Lq, d.P) > 1 ||
+                          msda_path_for(2, d.M, d.D, d.L, d.P) != MSDA_PATH_D32 ||
+                          (((uintptr_t)go.data_ptr() | (uintptr_t)v16.data_ptr() | (uintptr_t)l32.data_ptr()) & 7) != 0;
         const unsigned flags = ctx->saved_data["det"].toBool() ? MSDA_FLAG_DETERMINISTIC : 0u;
         c10::hip::HIPGuardMasqueradingAsCUDA guard(v16.device());
         auto gv = at::empty_like(v16, v16.options().dtype(gv32 ? at::kFloat : at::kBFloat16));

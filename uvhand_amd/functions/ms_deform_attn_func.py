@@ -76,8 +76,8 @@ class MSDeformAttnBF16Function(Function):
     ``value`` is rounded to bfloat16 and the output / grad_value come back in bfloat16 (half the
     HBM bytes of every row gather and store); sampling locations, attention weights and their
     gradients stay float32, and all arithmetic and accumulation inside the kernels is float32 with
-    one rounding at the final store.  Same call signature as ``MSDeformAttnFunction``; only the
-    D = 32 kernel family implements it.
+    one rounding at the final store.  Same call signature as ``MSDeformAttnFunction``; D = 32 takes the tiled
+    kernels, any other D the generic ones (fp32 grad_value inside, rounded here).
     """
 
     @classmethod
@@ -111,8 +111,10 @@ class MSDeformAttnBF16Function(Function):
             ctx.saved_tensors
         # grad_value in float32 straight from the kernel when that is what `value` needs anyway, and for long
         # backwards (several query chunks accumulate: fp32 in place, one rounding at the end)
+        # — and wherever the generic kernels serve the call (D != 32: fp32 atomics are their only accumulation)
         Lq, P = sampling_locations.shape[1], sampling_locations.shape[4]
-        fp32_gv = value.dtype == torch.float32 or MSDA.backward_passes(Lq, P) > 1
+        fp32_gv = (value.dtype == torch.float32 or MSDA.backward_passes(Lq, P) > 1
+                   or MSDA.path_for(2, value.shape[2], value.shape[3], value_spatial_shapes.shape[0], P) != MSDA.PATH_D32)
         grad_value, grad_sampling_loc, grad_attn_weight = MSDA.ms_deform_attn_backward(
             value.to(torch.bfloat16), value_spatial_shapes, value_level_start_index,
             sampling_locations.float(), attention_weights.float(),
