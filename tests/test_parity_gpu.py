@@ -268,11 +268,19 @@ def test_bf16_generic_and_d32_families_agree(native, oracle):
     assert rel_err(res[0][2][keep], res[1][2][keep]) < 2e-5
 
 
-@pytest.mark.parametrize("spread", [0.0, 0.02, 0.2])
-def test_taps_piled_on_few_pixels(native, oracle, spread):
+PILED = {"cfg2_decoder": (2, [(48, 48), (24, 24), (12, 12), (6, 6)], 8, 32, 300, 4),
+         # Lq*P beyond one pass: the kept-taps single pass (bwd_value_wide_body) and, when a workgroup's rows receive more
+         # taps than its record array holds (small spreads), its chunked fall-back
+         "many_queries": (2, [(16, 16), (8, 8)], 8, 32, 2100, 4),
+         "long_encoder": (1, [(40, 40), (20, 20), (10, 10), (5, 5)], 8, 32, 2125, 4)}
+
+
+@pytest.mark.parametrize("geometry", list(PILED))
+@pytest.mark.parametrize("spread", [0.0, 0.02, 0.2, 0.6])
+def test_taps_piled_on_few_pixels(native, oracle, spread, geometry):
     """grad_value's counting sort with every sampling point inside a small patch (collisions: thousands of
-    taps on one pixel, most rows of the map empty).  cfg-2 decoder geometry; compared with the C oracle."""
-    z = make_case(11, 2, [(48, 48), (24, 24), (12, 12), (6, 6)], 8, 32, 300, 4)
+    taps on one pixel, most rows of the map empty); compared with the C oracle."""
+    z = make_case(11, *PILED[geometry])
     g = torch.Generator().manual_seed(12)
     centre = torch.tensor([0.37, 0.61])
     z["loc"] = (centre + (torch.rand(z["loc"].shape, generator=g) - 0.5) * spread).numpy().astype(np.float32)

@@ -120,20 +120,22 @@ int main(int argc, char **argv)
             ++nb; tmin = std::min(tmin, t[0]); tmax = std::max(tmax, t[last]); smax = std::max(smax, t[0]);
             for (int k = 0; k < last; ++k) { const double d = (double)(t[k + 1] - t[k]) * 0.01; ph[k] += d; phmax[k] = std::max(phmax[k], d); }
         }
-        if (rg == 0 && getenv("KB_W")) {                    // role-B gather time by level (xcd numbering assumed on)
+        if (rg == 0 && getenv("KB_W")) {                    // role-B phase times by level (xcd numbering assumed on)
             const int W = atoi(getenv("KB_W")), nBb = W * N * M * L;
-            double gs[16] = {0}, gm[16] = {0}; int gn[16] = {0};
+            const bool skew = !getenv("KB_SKEW") || atoi(getenv("KB_SKEW")) != 0;      // kAccWide deals W to every level
+            double gs[16][5] = {{0}}, gm[16] = {0}; int gn[16] = {0};
             for (int b = 0; b < nBb && b < 65536; ++b) {
                 const unsigned long long *t = &hsb[b * 8];
                 if (!t[0] || !t[5]) continue;
                 const int x = b & 7, idx = b >> 3, q = nBb >> 3, r = nBb & 7, logical = x * q + (x < r ? x : r) + idx;
                 // same dealing as value_block_to_range (msda_d32.hip) for a pyramid whose level 0 is the largest
                 const int sl = logical % (W * L); int lvl = 0, base = 0;
-                for (int k = 0; k < L; ++k) { const int wk = W + (W >= 2 && L >= 2 ? (k == 0) - (k == L - 1) : 0); if (sl < base + wk) { lvl = k; break; } base += wk; }
-                const double d = (double)(t[5] - t[4]) * 0.01;
-                gs[lvl] += d; gm[lvl] = std::max(gm[lvl], d); ++gn[lvl];
+                for (int k = 0; k < L; ++k) { const int wk = W + (skew && W >= 2 && L >= 2 ? (k == 0) - (k == L - 1) : 0); if (sl < base + wk) { lvl = k; break; } base += wk; }
+                for (int k = 0; k < 5; ++k) gs[lvl][k] += (double)(t[k + 1] - t[k]) * 0.01;
+                gm[lvl] = std::max(gm[lvl], (double)(t[5] - t[0]) * 0.01); ++gn[lvl];
             }
-            for (int l = 0; l < L; ++l) if (gn[l]) printf("  level %d: gather mean %.2f us max %.2f us (%d blocks)\n", l, gs[l] / gn[l], gm[l], gn[l]);
+            for (int l = 0; l < L; ++l) if (gn[l]) printf("  level %d: phases %.2f %.2f %.2f %.2f %.2f us, lifetime max %.2f us (%d blocks)\n", l, gs[l][0] / gn[l],
+                                                           gs[l][1] / gn[l], gs[l][2] / gn[l], gs[l][3] / gn[l], gs[l][4] / gn[l], gm[l], gn[l]);
         }
         if (!nb) continue;
         printf("%s: %zu sampled blocks, first start -> last end %.2f us, last block start +%.2f us\n", regs[rg].name, nb,

@@ -490,10 +490,13 @@ __global__ __launch_bounds__(kBlock) void bwd_query_d32_kernel(
 //             (the rows belong to this workgroup alone, passes are separated by __syncthreads, and
 //             they stay in L2) — no LDS tile, so several workgroups fit per CU;
 //   kAccTile  bf16 storage: rows accumulate in an fp32 LDS tile and are rounded ONCE at the flush.
+//   kAccWide  fp32 grad_value, Lq*P beyond one pass: bwd_value_wide_body below — ONE pass over all Lq*P points
+//             whenever the taps this workgroup KEEPS fit the record array (a workgroup owns 1/W of a level, so
+//             it keeps ~1/W of the level's taps), chunked kAccRmw passes otherwise.
 // ------------------------------------------------------------------------------------------
 constexpr int kSBlock = 512;
 constexpr int kSWaves = kSBlock / kWave;
-constexpr int kAccNone = 0, kAccRmw = 1, kAccTile = 2;
+constexpr int kAccNone = 0, kAccRmw = 1, kAccTile = 2, kAccWide = 3;
 struct alignas(8) SRec { float w; int q; };
 // Fixed-capacity segments (FIXED = true: steps 1-3 in one scan, for problems small enough that every workgroup
 // is resident at once and the backward is one latency chain): row d owns the record slots [d*CAP, (d+1)*CAP),
@@ -527,12 +530,14 @@ __device__ __forceinline__ void add4(float4 &a, const float4 &b) { a.x += b.x; a
 // CH*SLOTS records of two rows.  (A balanced "linear" variant — the sorted records cut evenly over
 // the lane groups, partial row runs combined in a fix-up phase — was measured and is not faster:
 // its per-record run bookkeeping costs what the load imbalance costs here; profiles/r01_notes.md.)
-template <int SLOTS, int ACC, typename VT, typename GT>
+// OFFS: a record's q is already the element offset of its grad_out row (q * row_stride), not the query index.
+template <int SLOTS, int ACC, typename VT, typename GT, bool OFFS = false>
 __device__ __forceinline__ void gather_rows(const VT *__restrict__ go_base, GT *__restrict__ gv_base,
                                             const int *cnt, const int *start, const SRec *rec, float *tile,
                                             int npx, int row_stride, bool first_pass, int cap_shift = -1,
-                                            const SOvf *ovf = nullptr, int novf = 0)
+                                            const SOvf *ovf = nullptr, int novf = 0, bool ends = false)
 {
+    // ends: start[d] holds the END of row d's segment (the scatter advanced it as its cursor)
     // cap_shift >= 0: fixed-capacity segments (row d at d << cap_shift, at most 1 << cap_shift records there,
     // the rest of a fuller row in ovf[0, novf)); cap_shift < 0: segments from the prefix sum (start[])
     constexpr int DPW = 8 / SLOTS;
@@ -546,8 +551,8 @@ __device__ __forceinline__ void gather_rows(const VT *__restrict__ go_base, GT *
         const int fullA = cnt[dA], fullB = hasB ? cnt[dB] : 0;
         const int nA = cap_shift >= 0 ? min(fullA, 1 << cap_shift) : fullA;
         const int nB = cap_shift >= 0 ? min(fullB, 1 << cap_shift) : fullB;
-        const SRec *rA = rec + (cap_shift >= 0 ? dA << cap_shift : start[dA]);
-        const SRec *rB = rec + (!hasB ? 0 : cap_shift >= 0 ? dB << cap_shift : start[dB]);
+        const SRec *rA = rec + (cap_shift >= 0 ? dA << cap_shift : start[dA] - (ends ? fullA : 0));
+        const SRec *rB = rec + (!hasB ? 0 : cap_shift >= 0 ? dB << cap_shift : start[dB] - (ends ? fullB : 0));
         float4 accA = make_float4(0.f, 0.f, 0.f, 0.f), accB = accA;
         const int nmax = max(nA, nB);
         for (int i0 = slot; i0 < nmax; i0 += CH * SLOTS) {
@@ -560,8 +565,8 @@ __device__ __forceinline__ void gather_rows(const VT *__restrict__ go_base, GT *
             }
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
-                const float4 ta = Row<VT>::load(go_base + (long long)(ra[u].q >= 0 ? ra[u].q : 0) * row_stride);
-                const float4 tb = Row<VT>::load(go_base + (long long)(rb[u].q >= 0 ? rb[u].q : 0) * row_stride);
+                const float4 ta = Row<VT>::load(go_base + (OFFS ? (long long)max(ra[u].q, 0) : (long long)max(ra[u].q, 0) * row_stride));
+                const float4 tb = Row<VT>::load(go_base + (OFFS ? (long long)max(rb[u].q, 0) : (long long)max(rb[u].q, 0) * row_stride));
                 const bool oa = ra[u].q >= 0, ob = rb[u].q >= 0;
                 ga[u] = make_float4(oa ? ta.x : 0.f, oa ? ta.y : 0.f, oa ? ta.z : 0.f, oa ? ta.w : 0.f);
                 gb[u] = make_float4(ob ? tb.x : 0.f, ob ? tb.y : 0.f, ob ? tb.z : 0.f, ob ? tb.w : 0.f);
@@ -600,6 +605,69 @@ __device__ __forceinline__ void gather_rows(const VT *__restrict__ go_base, GT *
     }
 }
 
+// Step 4, balanced (kAccWide): the SORTED record array is cut into 64 equal stretches, one per lane group, moved
+// to row boundaries (a row's records stay with one lane group: rows are stored once, no combining).  A lane group
+// walks its stretch eight records at a time — every load is a real record, where gather_rows pads a row's last
+// trip (21-record rows on 8 slots x 4: a third of the loads and FMAs) — and stores a row whenever the running
+// index passes its end.  endv[r] = end of row r's segment (segments are contiguous: row r starts at endv[r - 1]);
+// records hold element offsets.  For rows of comparable length; a row with thousands of records would leave most
+// lane groups idle, so the caller keeps gather_rows for those.
+template <typename VT, typename GT>
+__device__ __forceinline__ void gather_balanced(const VT *__restrict__ go_base, GT *__restrict__ gv_base,
+                                                const int *endv, const SRec *rec, int *firsts, int npx,
+                                                int row_stride, int total, bool first_pass)
+{
+    constexpr int G = kSBlock / 8, CH = 8;
+    const int tid = threadIdx.x, g = tid >> 3;
+    // first row of this lane group: the smallest r whose segment starts at or after record g * total / G
+    const int lo = (g * total) / G;                          // total <= kWideRecCap: no overflow
+    int a = 0, b = npx;
+    while (a < b) {
+        const int mid = (a + b) >> 1;
+        if ((mid ? endv[mid - 1] : 0) >= lo) b = mid; else a = mid + 1;
+    }
+    if ((tid & 7) == 0) firsts[g] = a;
+    if (tid == 0) firsts[G] = npx;
+    __syncthreads();
+    int r = a;
+    const int r_stop = firsts[g + 1];
+    if (r >= r_stop) return;                                 // (no barrier below)
+    int i = r ? endv[r - 1] : 0;
+    const int i_stop = endv[r_stop - 1];
+    int row_end = endv[r];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto flush = [&]() {                                     // row r is complete (possibly empty)
+        GT *p = gv_base + (long long)r * row_stride;
+        if (!first_pass) add4(acc, Row<GT>::load(p));
+        Row<GT>::store(p, acc);
+        acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        ++r;
+        row_end = r < r_stop ? endv[r] : 0x7fffffff;
+    };
+    for (; i + CH <= i_stop; i += CH) {
+        SRec e[CH]; float4 gl[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) e[u] = rec[i + u];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) gl[u] = Row<VT>::load(go_base + e[u].q);
+#pragma unroll
+        for (int u = 0; u < CH; ++u) { while (i + u >= row_end) flush(); fma4(acc, e[u].w, gl[u]); }
+    }
+    if (i < i_stop) {                                        // last, partial batch
+        SRec e[CH]; float4 gl[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) if (i + u < i_stop) { e[u] = rec[i + u]; gl[u] = Row<VT>::load(go_base + e[u].q); }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) if (i + u < i_stop) { while (i + u >= row_end) flush(); fma4(acc, e[u].w, gl[u]); }
+    }
+    while (r < r_stop) flush();                              // the row in progress and the empty rows after it
+}
+
+template <typename VT, typename GT>
+__device__ __forceinline__ void bwd_value_wide_body(const VT *__restrict__, const int64_t *__restrict__, const int64_t *__restrict__,
+                                                    const float *__restrict__, const float *__restrict__, int, int, int, int, int,
+                                                    int, int, GT *__restrict__, int, int, int, int, unsigned char *);   // kAccWide, below
+
 // PPT = sampling points per thread per pass: all of a thread's points are loaded up front (2*PPT
 // independent global loads in flight), their taps and histogram ranks stay in registers between
 // step 1 and step 3, so loc / attn are read exactly once and step 3 needs no atomics.
@@ -612,6 +680,11 @@ __device__ __forceinline__ void bwd_value_body(
     const float *__restrict__ attn, int S, int M, int L, int Lq, int P, int p_shift, int tp_cap,
     GT *__restrict__ grad_value, int ti, int W, int l, int pr, unsigned char *smem)
 {
+    if constexpr (ACC == kAccWide) {
+        bwd_value_wide_body<VT, GT>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, tp_cap, grad_value,
+                                    ti, W, l, pr, smem);
+        return;
+    }
     constexpr int NPC = PPT * kSBlock;                       // points per pass
     // LDS: [tile: tp_cap*32 floats if kAccTile] [cnt tp_cap] [start tp_cap] [wsum 16] [rec] [ovf kOvfCap if FIXED]
     float *tile = reinterpret_cast<float *>(smem);
@@ -790,6 +863,252 @@ __device__ __forceinline__ void bwd_value_body(
 }
 
 
+// ---- kAccWide: single pass by KEPT taps ----------------------------------------------------------------------
+// The chunked passes above size a pass by the points it SCANS (4 records per point), although a workgroup that
+// owns 1/W of a level keeps ~1/W of them: cfg-2 encoder took 8 passes of 1536 points, each a chain of five
+// barrier-separated phases that kept ~770 records (profiles/r02_notes.md §10).  Here a workgroup
+//   1. scans ALL Lq*P points of its (batch, head, level) once: histogram of the taps that land on its rows
+//      (LDS integer atomics, no return value) and a compact list of the points that have such a tap
+//      (wavefront ballot + one LDS atomic per wavefront);
+//   2. prefix-sums the histogram;
+//   3. revisits only the listed points (~1/W of them), recomputes their taps and drops the records into the
+//      rows' segments (the prefix array is the cursor: it ends up holding segment ENDS);
+//   4. gathers as before and stores every row once.
+// If the kept taps exceed the record array or the list (locations piled on this workgroup's rows), it starts
+// over in chunks of kWideChunk points — whose taps always fit — accumulating like kAccRmw.
+constexpr int kWideRecCap = 7168;                   // records (56 KB)
+constexpr int kWideListCap = kWideRecCap;           // listed points (14 KB of 16-bit chunk-relative indices): a listed
+                                                    // point has at least one tap here, so the records overflow first
+constexpr int kWideMaxStep = 65536;                 // points per attempt (what a 16-bit list entry can address)
+constexpr int kWideChunk = kWideRecCap / 4;         // points per fallback pass
+template <typename VT, typename GT>
+__device__ __forceinline__ void bwd_value_wide_body(
+    const VT *__restrict__ grad_out, const int64_t *__restrict__ shapes,
+    const int64_t *__restrict__ level_start, const float *__restrict__ loc,
+    const float *__restrict__ attn, int S, int M, int L, int Lq, int P, int p_shift, int tp_cap,
+    GT *__restrict__ grad_value, int ti, int W, int l, int pr, unsigned char *smem)
+{
+    // LDS: [cnt tp_cap] [start tp_cap] [wsum 32] [list kWideListCap x u16] [rec kWideRecCap]
+    int *cnt = reinterpret_cast<int *>(smem);
+    int *start = cnt + tp_cap;
+    int *wsum = start + tp_cap;
+    uint16_t *list = reinterpret_cast<uint16_t *>(wsum + 32);             // wsum[16..23]: per-wavefront longest row
+    SRec *rec = reinterpret_cast<SRec *>(list + kWideListCap);
+    int *kept_p = wsum + 8;                                  // wsum[0..7]: per-wavefront sums of the prefix scan
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    MSDA_STAMP(0);
+    const int H = (int)shapes[2 * l], Wd = (int)shapes[2 * l + 1], lstart = (int)level_start[l];
+    const int HW = H * Wd;
+    const int px0 = (int)((unsigned)(ti * HW) / (unsigned)W), px1 = (int)((unsigned)((ti + 1) * HW) / (unsigned)W);
+    const int npx = px1 - px0;
+    const int b = pr / M, m = pr - b * M;
+    if (l == 0 && ti == 0) {                                 // pixels past the last level that fits: see bwd_value_body
+        long long cover = 0;
+        for (int k = 0; k < L; ++k)
+            if (level_fits(shapes[2 * k], shapes[2 * k + 1], level_start[k], S))
+                cover = max(cover, (long long)level_start[k] + shapes[2 * k] * shapes[2 * k + 1]);
+        for (int i = threadIdx.x; i < (S - (int)cover) * 8; i += kSBlock)
+            Row<GT>::store(grad_value + ((long long)(b * S + (int)cover + (i >> 3)) * M + m) * kD + (i & 7) * 4,
+                           make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+    if (npx <= 0 || npx > tp_cap || !level_fits(shapes[2 * l], shapes[2 * l + 1], level_start[l], S)) return;
+    const int NP = Lq * P;
+    const long long item_base = (long long)b * Lq * M + m;
+    const int row_stride = M * kD;
+    const VT *go_base = grad_out + item_base * kD + (lane & 7) * 4;
+    GT *gv_base = grad_value + ((long long)(b * S + lstart + px0) * M + m) * kD + (lane & 7) * 4;
+    const float2 *loc2 = reinterpret_cast<const float2 *>(loc);
+    // Everything below is written for INSTRUCTION COUNT: a CU issues about one wavefront instruction per clock
+    // (4 SIMDs x 4 cycles per wave64 op; 32-bit integer multiplies take four times that), and the first version of
+    // this scan — 64-bit index arithmetic and the full tap geometry for every point — spent 18 us on 12 240 points.
+    // 32-bit indices throughout: d32_supported() bounds N*Lq*M*L*P*2 and N*S*M*D below 2^31 and S below 2^19.
+    const int MLP = M * L * P;
+    const unsigned off0 = (unsigned)((item_base * L + l) * P);                 // float2 index of (b, q = 0, m, l, p = 0)
+    const float Hf = (float)H, Wf = (float)Wd, px0f = (float)px0, npxf = (float)npx;
+
+    // range-local destinations of a point's four taps (-1: outside the map or not one of this workgroup's rows)
+    auto taps_of = [&](const float2 xy, int (&dest)[4], PointGeom<float> &g) {
+        g = point_geom<float>(xy.x, xy.y, H, Wd);
+        const int pix = g.h0 * Wd + g.w0 - px0;
+        const int p01 = pix + 1, p10 = pix + Wd, p11 = pix + Wd + 1;
+        dest[0] = (g.ok00 && pix >= 0 && pix < npx) ? pix : -1;
+        dest[1] = (g.ok01 && p01 >= 0 && p01 < npx) ? p01 : -1;
+        dest[2] = (g.ok10 && p10 >= 0 && p10 < npx) ? p10 : -1;
+        dest[3] = (g.ok11 && p11 >= 0 && p11 < npx) ? p11 : -1;
+    };
+    // float2 index of point idx = q*P + p, and q
+    auto point_of = [&](int idx, int &q) -> unsigned {
+        q = fdiv(idx, P, p_shift);
+        return off0 + (unsigned)(q * MLP + (idx - q * P));
+    };
+
+    // steps 1-2 for the points [p0, p1); returns the number of kept taps
+    auto count_points = [&](int p0, int p1) -> int {
+        for (int i = tid; i < npx; i += kSBlock) cnt[i] = 0;
+        if (tid == 0) *kept_p = 0;
+        __syncthreads();
+        // 1a. the points that MAY have a tap on this workgroup's rows -> list.  No histogram yet (an LDS atomic costs
+        // ~30 cycles per wavefront instruction however few lanes take part, and here ~1/W of them would); the test is
+        // a superset — inside the map and one of the two tap pairs meets [0, npx) — in float arithmetic (exact: S < 2^24);
+        // the exact taps are worked out for the listed points only.  The thread's point index advances by 512 per
+        // step: (q, p) and the address follow by additions.
+        constexpr int U = 8;
+        const int dq = fdiv(kSBlock, P, p_shift), dp = kSBlock - dq * P;        // 512 = dq*P + dp (uniform)
+        const int doff = dq * MLP + dp, wrap = MLP - P;
+        int q0;
+        unsigned off = point_of(p0 + tid, q0);
+        int p = p0 + tid - q0 * P;
+        for (int base = p0; base < p1; base += kSBlock * U) {
+            float2 xy[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                xy[u] = make_float2(-8.f, -8.f);                                // outside every map
+                if (base + u * kSBlock + tid < p1) xy[u] = loc2[off];
+                p += dp; off += doff;
+                if (p >= P) { p -= P; off += wrap; }
+            }
+            unsigned long long mask[U];
+            int n = 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float h_im = xy[u].y * Hf - 0.5f, w_im = xy[u].x * Wf - 0.5f;
+                const float pixf = fmaf(floorf(h_im), Wf, floorf(w_im)) - px0f;  // tap (h0, w0), range-local
+                // taps sit at pix, pix + 1 and pix + W, pix + W + 1 (border validity ignored: a superset)
+                const bool keep = h_im > -1.f && w_im > -1.f && h_im < Hf && w_im < Wf &&
+                                  ((pixf + 1.f >= 0.f && pixf < npxf) || (pixf + Wf + 1.f >= 0.f && pixf + Wf < npxf));
+                mask[u] = __ballot(keep);
+                n += __popcll(mask[u]);
+            }
+            if (n == 0) continue;                                               // uniform
+            int wbase = 0;
+            if (lane == 0) wbase = atomicAdd(kept_p, n);
+            wbase = __shfl(wbase, 0, kWave);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int pos = wbase + __popcll(mask[u] & ((1ull << lane) - 1ull));
+                if (((mask[u] >> lane) & 1ull) && pos < kWideListCap) list[pos] = (uint16_t)(base - p0 + u * kSBlock + tid);
+                wbase += __popcll(mask[u]);
+            }
+        }
+        __syncthreads();
+        MSDA_STAMP(1);
+        // 1b. histogram of the listed points' taps (dense lanes: ~4 atomics per 64 listed points)
+        {
+            const int kept = min(*kept_p, kWideListCap);
+            constexpr int UH = 4;
+            for (int base = 0; base < kept; base += kSBlock * UH) {
+                float2 xy[UH];
+#pragma unroll
+                for (int u = 0; u < UH; ++u) {
+                    const int i = base + u * kSBlock + tid;
+                    xy[u] = make_float2(-8.f, -8.f);
+                    if (i < kept) { int q; xy[u] = loc2[point_of(p0 + list[i], q)]; }
+                }
+#pragma unroll
+                for (int u = 0; u < UH; ++u) {
+                    int dest[4]; PointGeom<float> g;
+                    taps_of(xy[u], dest, g);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) if (dest[t] >= 0) atomicAdd(&cnt[dest[t]], 1);
+                }
+            }
+        }
+        __syncthreads();
+        MSDA_STAMP(2);
+        // exclusive prefix sum over the rows (512 threads x CH consecutive rows)
+        const int CH = (npx + kSBlock - 1) / kSBlock;
+        const int r0 = tid * CH;
+        int mine = 0, big = 0;
+        for (int k = 0; k < CH; ++k) if (r0 + k < npx) { mine += cnt[r0 + k]; big = max(big, cnt[r0 + k]); }
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) { const int y = __shfl_up(incl, o, kWave); if (lane >= o) incl += y; }
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) big = max(big, __shfl_xor(big, o, kWave));
+        if (lane == kWave - 1) { wsum[wave] = incl; wsum[16 + wave] = big; }
+        __syncthreads();
+        int excl = incl - mine, total = 0;
+        {
+            const int4 wa = *reinterpret_cast<const int4 *>(wsum), wb = *reinterpret_cast<const int4 *>(wsum + 4);
+            const int ws[kSWaves] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+#pragma unroll
+            for (int w2 = 0; w2 < kSWaves; ++w2) { if (w2 < wave) excl += ws[w2]; total += ws[w2]; }
+        }
+        for (int k = 0; k < CH; ++k) if (r0 + k < npx) { start[r0 + k] = excl; excl += cnt[r0 + k]; }
+        __syncthreads();
+        MSDA_STAMP(3);
+        return total;
+    };
+    auto longest_row = [&]() {
+        const int4 wa = *reinterpret_cast<const int4 *>(wsum + 16), wb = *reinterpret_cast<const int4 *>(wsum + 20);
+        return max(max(max(wa.x, wa.y), max(wa.z, wa.w)), max(max(wb.x, wb.y), max(wb.z, wb.w)));
+    };
+
+    // steps 3-4 for the listed points.  A record holds the ELEMENT offset of its grad_out row (q * row_stride).
+    auto scatter_and_gather = [&](int p0, int total, bool first) {
+        const int kept = *kept_p;
+        constexpr int U = 4;
+        for (int base = 0; base < kept; base += kSBlock * U) {
+            float2 xy[U]; float at[U]; int qq[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = base + u * kSBlock + tid;
+                xy[u] = make_float2(-8.f, -8.f); at[u] = 0.f; qq[u] = 0;
+                if (i < kept) {
+                    const unsigned pi = point_of(p0 + list[i], qq[u]);
+                    xy[u] = loc2[pi]; at[u] = attn[pi];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                int dest[4]; PointGeom<float> g;
+                taps_of(xy[u], dest, g);
+                const float hh = 1.f - g.lh, hw = 1.f - g.lw;
+                const float tw[4] = {hh * hw * at[u], hh * g.lw * at[u], g.lh * hw * at[u], g.lh * g.lw * at[u]};
+                const int qoff = qq[u] * row_stride;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (dest[t] >= 0) { SRec r; r.w = tw[t]; r.q = qoff; rec[atomicAdd(&start[dest[t]], 1)] = r; }
+            }
+        }
+        __syncthreads();
+        MSDA_STAMP(4);
+        // rows of comparable length (the longest no more than one lane group's share): the balanced walk
+        if (longest_row() * 64 <= max(total, 1024)) {
+            gather_balanced<VT, GT>(go_base, gv_base, start, rec, reinterpret_cast<int *>(list), npx, row_stride, total, first);
+            MSDA_STAMP(5);
+            return;
+        }
+        const int mean2 = (2 * total) / npx;                                  // 2 x mean records per row
+        if (mean2 <= 8)       gather_rows<1, kAccRmw, VT, GT, true>(go_base, gv_base, cnt, start, rec, nullptr, npx, row_stride, first, -1, nullptr, 0, true);
+        else if (mean2 <= 16) gather_rows<2, kAccRmw, VT, GT, true>(go_base, gv_base, cnt, start, rec, nullptr, npx, row_stride, first, -1, nullptr, 0, true);
+        else if (mean2 <= 32) gather_rows<4, kAccRmw, VT, GT, true>(go_base, gv_base, cnt, start, rec, nullptr, npx, row_stride, first, -1, nullptr, 0, true);
+        else                  gather_rows<8, kAccRmw, VT, GT, true>(go_base, gv_base, cnt, start, rec, nullptr, npx, row_stride, first, -1, nullptr, 0, true);
+        MSDA_STAMP(5);
+    };
+
+    // All points at once; if this workgroup's rows receive more taps than the record array holds, a chunk sized
+    // from the count just taken (7/8 full if the points spread evenly), halved while it still does not fit.
+    // A chunk of kWideChunk points always fits (4 taps per point), so the loop ends.
+    int a = 0, step = min(NP, kWideMaxStep);
+    bool first = true;
+    while (a < NP) {
+        const int a1 = min(NP, a + step);
+        __syncthreads();                                     // the previous attempt / gather still reads the LDS arrays
+        const int t = count_points(a, a1);
+        if (t > kWideRecCap || *kept_p > kWideListCap) {     // uniform: LDS values read after a barrier
+            const long long even = (long long)(a1 - a) * (kWideRecCap - kWideRecCap / 8) / max(t, 1);
+            step = max(kWideChunk, (int)min(even, (long long)(a1 - a) / 2));
+            continue;
+        }
+        scatter_and_gather(a, t, first);
+        first = false;
+        a = a1;
+    }
+}
+
+
 // Role-B workgroup id -> (pair, level, range, ranges of that level).  A (batch, head) pair has W*L workgroups.
 // They are dealt W per level, except that on a pyramid (the level with the most pixels has >= 4x the pixels
 // of the one with the fewest; W >= 2) the largest level takes one range from the smallest: every level
@@ -797,7 +1116,7 @@ __device__ __forceinline__ void bwd_value_body(
 // with its slowest workgroup (cfg-2 decoder: level 0 gather 5.9 us vs 3.6 us for level 3 with W = 4 each).
 // Uniform (scalar) arithmetic; the shapes come from the scalar cache.
 __device__ __forceinline__ void value_block_to_range(int bid, int W, int L, const int64_t *__restrict__ shapes,
-                                                     int &pr, int &l, int &ti, int &Wl)
+                                                     int &pr, int &l, int &ti, int &Wl, bool may_skew = true)
 {
     const int T = W * L;
     pr = bid / T;
@@ -809,7 +1128,8 @@ __device__ __forceinline__ void value_block_to_range(int bid, int W, int L, cons
         if (r > rmax) { rmax = r; lmax = k; }
         if (r <= rmin) { rmin = r; lmin = k; }
     }
-    const bool skew = L >= 2 && W >= 2 && lmax != lmin && rmax >= 4 * rmin;
+    // (kAccWide deals W to every level: there the RECORDS a workgroup keeps are what must stay equal)
+    const bool skew = may_skew && L >= 2 && W >= 2 && lmax != lmin && rmax >= 4 * rmin;
     int base = 0;
     l = 0; ti = 0; Wl = W;
     for (int k = 0; k < L; ++k) {
@@ -830,7 +1150,7 @@ __global__ __launch_bounds__(kSBlock) void bwd_value_d32_kernel(
     // grid = W ranges x L levels x N*M pairs, range fastest
     const int bid = xcd ? xcd_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
     int pr, l, ti, Wl;
-    value_block_to_range(bid, W, L, shapes, pr, l, ti, Wl);
+    value_block_to_range(bid, W, L, shapes, pr, l, ti, Wl, ACC != kAccWide);
     bwd_value_body<ACC, PPT, VT, GT>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, tp_cap,
                                        grad_value, ti, Wl, l, pr, smem);
 }
@@ -853,7 +1173,7 @@ __global__ __launch_bounds__(kSBlock) void bwd_fused_d32_kernel(
     if (bid < nB) {
         if (xcd) bid = xcd_block(bid, nB);
         int pr, l, ti, Wl;
-        value_block_to_range(bid, W, L, shapes, pr, l, ti, Wl);
+        value_block_to_range(bid, W, L, shapes, pr, l, ti, Wl, ACC != kAccWide);
         bwd_value_body<ACC, kSinglePPT, VT, GT, FIXED>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift,
                                                      tp_cap, grad_value, ti, Wl, l, pr, smem);
     } else {
@@ -995,7 +1315,20 @@ static ValuePlan plan_value(int N, int S, int M, int L, int Lq, int P, int targe
     ValuePlan pl;
     const int NP = Lq * P, pairs_levels = N * M * L;
     const bool multipass = NP > kSingleMaxPoints;
-    pl.acc = !multipass ? kAccNone : (sizeof(VT) == 4 ? kAccRmw : kAccTile);
+    static const int wide = env_int("MSDA_BWD_WIDE", 1);             // A/B knob: 0 = the chunked kAccRmw passes
+    pl.acc = !multipass ? kAccNone : (sizeof(VT) == 4 ? (wide ? kAccWide : kAccRmw) : kAccTile);
+    if (pl.acc == kAccWide) {
+        // enough ranges per level that the taps a workgroup keeps (4*NP/W on average) fit its record array with
+        // 15 % to spare, and at least as many workgroups as the chunked plan would launch
+        static const int wide_wgs = env_int("MSDA_WIDE_WGS", 2);     // x target_wgs
+        const long long need = ((long long)4 * NP * 115 / 100 + kWideRecCap - 1) / kWideRecCap;
+        pl.W = max(max(ceil_div(S, kSingleMaxRows), ceil_div(wide_wgs * target_wgs, pairs_levels)), (int)min(need, (long long)S));
+        pl.W = max(1, min(pl.W, max(1, S / 16)));
+        pl.tp_cap = (ceil_div(S, pl.W) + 3) & ~3;
+        pl.ppt = kSinglePPT;
+        pl.lds = (2 * (size_t)pl.tp_cap + 32) * 4 + (size_t)kWideListCap * 2 + (size_t)kWideRecCap * sizeof(SRec);
+        return pl;
+    }
     if (pl.acc == kAccTile) {
         pl.tp_cap = kMultiRows;
         pl.W = ceil_div(S, pl.tp_cap);
@@ -1222,6 +1555,7 @@ static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *
                                    pl.tp_cap, pl.W, (int)nB, grad_value, grad_loc, grad_attn, PrologueOut{nullptr, 0, 0}, xcd); } while (0)
                 if (fp.fixed)                { if (fp.split == 4) MSDA_LAUNCH_F(4, kAccNone, true); else if (fp.split == 2) MSDA_LAUNCH_F(2, kAccNone, true); else MSDA_LAUNCH_F(1, kAccNone, true); }
                 else if (pl.acc == kAccNone) { if (fp.split == 4) MSDA_LAUNCH_F(4, kAccNone, false); else if (fp.split == 2) MSDA_LAUNCH_F(2, kAccNone, false); else MSDA_LAUNCH_F(1, kAccNone, false); }
+                else if (pl.acc == kAccWide) { if (fp.split == 4) MSDA_LAUNCH_F(4, kAccWide, false); else if (fp.split == 2) MSDA_LAUNCH_F(2, kAccWide, false); else MSDA_LAUNCH_F(1, kAccWide, false); }
                 else                         { if (fp.split == 4) MSDA_LAUNCH_F(4, kAccRmw, false); else if (fp.split == 2) MSDA_LAUNCH_F(2, kAccRmw, false); else MSDA_LAUNCH_F(1, kAccRmw, false); }
 #undef MSDA_LAUNCH_F
                 return check_launch("msda backward (d32, fused)");
@@ -1236,6 +1570,7 @@ static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *
                                 shapes, level_start, loc, attn, S, M, L, Lq, P, ps, pl.tp_cap, pl.W, grad_value, xcd); } while (0)
         if (pl.acc == kAccNone) MSDA_LAUNCH_B(kAccNone, kSinglePPT);
         else if (pl.acc == kAccTile) MSDA_LAUNCH_B(kAccTile, kMultiPPT);
+        else if (pl.acc == kAccWide) MSDA_LAUNCH_B(kAccWide, kSinglePPT);
         else if (pl.ppt == kMultiPPT) MSDA_LAUNCH_B(kAccRmw, kMultiPPT);
         else MSDA_LAUNCH_B(kAccRmw, kSinglePPT);
 #undef MSDA_LAUNCH_B
@@ -1327,6 +1662,7 @@ static int launch_bwd_prologue_t(const VT *grad_out, const VT *value, const int6
                        grad_value, grad_offsets, grad_logits, pro, xcd_remap()); } while (0)
     if (fp.fixed)                { if (fp.split == 4) MSDA_LAUNCH_BP(4, kAccNone, true); else if (fp.split == 2) MSDA_LAUNCH_BP(2, kAccNone, true); else MSDA_LAUNCH_BP(1, kAccNone, true); }
     else if (pl.acc == kAccNone) { if (fp.split == 4) MSDA_LAUNCH_BP(4, kAccNone, false); else if (fp.split == 2) MSDA_LAUNCH_BP(2, kAccNone, false); else MSDA_LAUNCH_BP(1, kAccNone, false); }
+    else if (pl.acc == kAccWide) { if (fp.split == 4) MSDA_LAUNCH_BP(4, kAccWide, false); else if (fp.split == 2) MSDA_LAUNCH_BP(2, kAccWide, false); else MSDA_LAUNCH_BP(1, kAccWide, false); }
     else                         { if (fp.split == 4) MSDA_LAUNCH_BP(4, kAccRmw, false); else if (fp.split == 2) MSDA_LAUNCH_BP(2, kAccRmw, false); else MSDA_LAUNCH_BP(1, kAccRmw, false); }
 #undef MSDA_LAUNCH_BP
     return check_launch("msda backward (d32, fused prologue)");
