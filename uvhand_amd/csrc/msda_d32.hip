@@ -609,16 +609,18 @@ __device__ __forceinline__ void gather_rows(const VT *__restrict__ go_base, GT *
 // to row boundaries (a row's records stay with one lane group: rows are stored once, no combining).  A lane group
 // walks its stretch eight records at a time — every load is a real record, where gather_rows pads a row's last
 // trip (21-record rows on 8 slots x 4: a third of the loads and FMAs) — and stores a row whenever the running
-// index passes its end.  endv[r] = end of row r's segment (segments are contiguous: row r starts at endv[r - 1]);
-// records hold element offsets.  For rows of comparable length; a row with thousands of records would leave most
+// index passes its end.  endv[r] = end of row r's segment (segments are contiguous: row r starts at endv[r - 1]).
+// For rows of comparable length; a row with thousands of records would leave most
 // lane groups idle, so the caller keeps gather_rows for those.
-template <typename VT, typename GT>
+// ENDS: start[r] is the END of row r's segment (kAccWide's scatter cursor), else its beginning; OFFS as in gather_rows.
+template <typename VT, typename GT, bool ENDS, bool OFFS>
 __device__ __forceinline__ void gather_balanced(const VT *__restrict__ go_base, GT *__restrict__ gv_base,
-                                                const int *endv, const SRec *rec, int *firsts, int npx,
+                                                const int *cnt, const int *start, const SRec *rec, int *firsts, int npx,
                                                 int row_stride, int total, bool first_pass)
 {
     constexpr int G = kSBlock / 8, CH = 8;
     const int tid = threadIdx.x, g = tid >> 3;
+    struct { const int *cnt, *start; __device__ int operator[](int r) const { return ENDS ? start[r] : start[r] + cnt[r]; } } endv{cnt, start};
     // first row of this lane group: the smallest r whose segment starts at or after record g * total / G
     const int lo = (g * total) / G;                          // total <= kWideRecCap: no overflow
     int a = 0, b = npx;
@@ -649,14 +651,15 @@ __device__ __forceinline__ void gather_balanced(const VT *__restrict__ go_base, 
 #pragma unroll
         for (int u = 0; u < CH; ++u) e[u] = rec[i + u];
 #pragma unroll
-        for (int u = 0; u < CH; ++u) gl[u] = Row<VT>::load(go_base + e[u].q);
+        for (int u = 0; u < CH; ++u) gl[u] = Row<VT>::load(go_base + (OFFS ? (long long)e[u].q : (long long)e[u].q * row_stride));
 #pragma unroll
         for (int u = 0; u < CH; ++u) { while (i + u >= row_end) flush(); fma4(acc, e[u].w, gl[u]); }
     }
     if (i < i_stop) {                                        // last, partial batch
         SRec e[CH]; float4 gl[CH];
 #pragma unroll
-        for (int u = 0; u < CH; ++u) if (i + u < i_stop) { e[u] = rec[i + u]; gl[u] = Row<VT>::load(go_base + e[u].q); }
+        for (int u = 0; u < CH; ++u)
+            if (i + u < i_stop) { e[u] = rec[i + u]; gl[u] = Row<VT>::load(go_base + (OFFS ? (long long)e[u].q : (long long)e[u].q * row_stride)); }
 #pragma unroll
         for (int u = 0; u < CH; ++u) if (i + u < i_stop) { while (i + u >= row_end) flush(); fma4(acc, e[u].w, gl[u]); }
     }
@@ -686,13 +689,13 @@ __device__ __forceinline__ void bwd_value_body(
         return;
     }
     constexpr int NPC = PPT * kSBlock;                       // points per pass
-    // LDS: [tile: tp_cap*32 floats if kAccTile] [cnt tp_cap] [start tp_cap] [wsum 16] [rec] [ovf kOvfCap if FIXED]
+    // LDS: [tile: tp_cap*32 floats if kAccTile] [cnt tp_cap] [start tp_cap] [wsum 32] [rec] [ovf kOvfCap]
     float *tile = reinterpret_cast<float *>(smem);
     int *cnt = reinterpret_cast<int *>(smem + (ACC == kAccTile ? (size_t)tp_cap * kD * 4 : 0));
     int *start = cnt + tp_cap;
     int *wsum = start + tp_cap;
-    SRec *rec = reinterpret_cast<SRec *>(wsum + 16);
-    int *novf_p = wsum + 8, *total_p = wsum + 9;             // wsum[0..7]: per-wavefront sums of the prefix scan
+    SRec *rec = reinterpret_cast<SRec *>(wsum + 32);
+    int *novf_p = wsum + 8, *total_p = wsum + 9;             // wsum[0..7]: per-wavefront sums of the prefix scan, [16..23]: longest row
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     MSDA_STAMP(0);
@@ -817,19 +820,23 @@ __device__ __forceinline__ void bwd_value_body(
         // ---- 2. exclusive prefix sum over the rows (512 threads x CH consecutive rows) ----
         const int CH = (npx + kSBlock - 1) / kSBlock;
         const int r0 = tid * CH;
-        int mine = 0;
-        for (int k = 0; k < CH; ++k) if (r0 + k < npx) mine += cnt[r0 + k];
+        int mine = 0, big = 0;
+        for (int k = 0; k < CH; ++k) if (r0 + k < npx) { mine += cnt[r0 + k]; big = max(big, cnt[r0 + k]); }
         int incl = mine;
 #pragma unroll
         for (int o = 1; o < kWave; o <<= 1) { const int y = __shfl_up(incl, o, kWave); if (lane >= o) incl += y; }
-        if (lane == kWave - 1) wsum[wave] = incl;
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) big = max(big, __shfl_xor(big, o, kWave));
+        if (lane == kWave - 1) { wsum[wave] = incl; wsum[16 + wave] = big; }
         __syncthreads();
-        int excl = incl - mine, total = 0;
+        int excl = incl - mine, total = 0, longest = 0;
         {
             const int4 wa = *reinterpret_cast<const int4 *>(wsum), wb = *reinterpret_cast<const int4 *>(wsum + 4);
             const int ws[kSWaves] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
 #pragma unroll
             for (int w2 = 0; w2 < kSWaves; ++w2) { if (w2 < wave) excl += ws[w2]; total += ws[w2]; }
+            const int4 ma = *reinterpret_cast<const int4 *>(wsum + 16), mb = *reinterpret_cast<const int4 *>(wsum + 20);
+            longest = max(max(max(ma.x, ma.y), max(ma.z, ma.w)), max(max(mb.x, mb.y), max(mb.z, mb.w)));
         }
         for (int k = 0; k < CH; ++k) if (r0 + k < npx) { start[r0 + k] = excl; excl += cnt[r0 + k]; }
         __syncthreads();
@@ -843,6 +850,14 @@ __device__ __forceinline__ void bwd_value_body(
         __syncthreads();
         MSDA_STAMP(4);
         // ---- 4. gather; lanes per row chosen from the mean segment length (uniform) ----
+        // rows of comparable length (the longest no more than one lane group's share): the balanced walk
+        if (ACC != kAccTile && longest * 64 <= max(total, 1024)) {
+            gather_balanced<VT, GT, false, false>(go_base, gv_base, cnt, start, rec, reinterpret_cast<int *>(ovf), npx, row_stride,
+                                                  total, ACC == kAccNone || first);
+            if (ACC != kAccNone) __syncthreads();
+            MSDA_STAMP(5);
+            continue;
+        }
         const int mean2 = (2 * total) / npx;                                  // 2 x mean records per row
         if (mean2 <= 8)       gather_rows<1, ACC, VT, GT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
         else if (mean2 <= 16) gather_rows<2, ACC, VT, GT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
@@ -1076,7 +1091,7 @@ __device__ __forceinline__ void bwd_value_wide_body(
         MSDA_STAMP(4);
         // rows of comparable length (the longest no more than one lane group's share): the balanced walk
         if (longest_row() * 64 <= max(total, 1024)) {
-            gather_balanced<VT, GT>(go_base, gv_base, start, rec, reinterpret_cast<int *>(list), npx, row_stride, total, first);
+            gather_balanced<VT, GT, true, true>(go_base, gv_base, cnt, start, rec, reinterpret_cast<int *>(list), npx, row_stride, total, first);
             MSDA_STAMP(5);
             return;
         }
@@ -1345,7 +1360,7 @@ static ValuePlan plan_value(int N, int S, int M, int L, int Lq, int P, int targe
     }
     pl.tp_cap = (pl.tp_cap + 3) & ~3;                                 // keeps the LDS arrays 16-B aligned
     const int pass_points = min(NP, pl.ppt * kSBlock);
-    pl.lds = (pl.acc == kAccTile ? (size_t)pl.tp_cap * kD * 4 : 0) + (2 * (size_t)pl.tp_cap + 16) * 4 +
+    pl.lds = (pl.acc == kAccTile ? (size_t)pl.tp_cap * kD * 4 : 0) + (2 * (size_t)pl.tp_cap + 32) * 4 +
              (size_t)4 * pass_points * sizeof(SRec) + (size_t)kOvfCap * sizeof(SOvf);
     return pl;
 }
