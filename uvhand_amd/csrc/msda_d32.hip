@@ -636,15 +636,20 @@ __device__ __forceinline__ void gather_balanced(const VT *__restrict__ go_base, 
     if (r >= r_stop) return;                                 // (no barrier below)
     int i = r ? endv[r - 1] : 0;
     const int i_stop = endv[r_stop - 1];
-    int row_end = endv[r];
+    // the end of the row after the current one is read one flush ahead: a flush then waits for nothing (lane groups
+    // of a wavefront flush at different records, so each flush runs on its own under the execution mask — with an
+    // LDS round trip inside, 12 flushes per lane group cost more than the records; measured 14.8 -> see r02_notes §10)
+    int row_end = endv[r], next_end = r + 1 < r_stop ? endv[r + 1] : 0x7fffffff;
+    GT *prow = gv_base + (long long)r * row_stride;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     auto flush = [&]() {                                     // row r is complete (possibly empty)
-        GT *p = gv_base + (long long)r * row_stride;
-        if (!first_pass) add4(acc, Row<GT>::load(p));
-        Row<GT>::store(p, acc);
+        if (!first_pass) add4(acc, Row<GT>::load(prow));
+        Row<GT>::store(prow, acc);
         acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        prow += row_stride;
         ++r;
-        row_end = r < r_stop ? endv[r] : 0x7fffffff;
+        row_end = next_end;
+        next_end = r + 1 < r_stop ? endv[r + 1] : 0x7fffffff;
     };
     for (; i + CH <= i_stop; i += CH) {
         SRec e[CH]; float4 gl[CH];
