@@ -500,9 +500,12 @@ def test_full_size_properties(native, name):
     assert ana > 0 and abs(num - ana) < 5e-2 * ana
 
 
-def test_full_size_vs_oracle_subsample(native, oracle):
-    """cfg-2 decoder at full size against the C oracle (it finishes in well under a second)."""
-    z = make_case(0, *FULL["cfg2_decoder"])
+@pytest.mark.parametrize("name", list(FULL))
+def test_full_size_vs_oracle_subsample(native, oracle, name):
+    """The bench's own shapes at full size against the C oracle (about a second each on the host): cfg-2 decoder
+    (fixed-capacity sort), cfg-2 / cfg-4 encoder (one pass by kept taps, balanced gather), cfg-4 decoder (prefix-sum sort,
+    balanced gather)."""
+    z = make_case(0, *FULL[name])
     out, gv, gl, ga = run_hip(z, torch.float32)
     args = [z["value"], z["shapes"], z["level_start"], z["loc"], z["attn"]]
     r_gv, r_gl, r_ga = oracle.backward(z["grad_out"], *args)

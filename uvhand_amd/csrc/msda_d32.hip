@@ -1016,7 +1016,9 @@ __device__ __forceinline__ void bwd_value_wide_body(
         // 1b. histogram of the listed points' taps (dense lanes: ~4 atomics per 64 listed points)
         {
             const int kept = min(*kept_p, kWideListCap);
-            constexpr int UH = 4;
+            // up to 8 loads in flight per thread (a coarse level lists several thousand points); the slots past the
+            // list's end are skipped as a whole (uniform test)
+            constexpr int UH = 8;
             for (int base = 0; base < kept; base += kSBlock * UH) {
                 float2 xy[UH];
 #pragma unroll
@@ -1027,6 +1029,7 @@ __device__ __forceinline__ void bwd_value_wide_body(
                 }
 #pragma unroll
                 for (int u = 0; u < UH; ++u) {
+                    if (base + u * kSBlock >= kept) break;
                     int dest[4]; PointGeom<float> g;
                     taps_of(xy[u], dest, g);
 #pragma unroll
@@ -1068,7 +1071,7 @@ __device__ __forceinline__ void bwd_value_wide_body(
     // steps 3-4 for the listed points.  A record holds the ELEMENT offset of its grad_out row (q * row_stride).
     auto scatter_and_gather = [&](int p0, int total, bool first) {
         const int kept = *kept_p;
-        constexpr int U = 4;
+        constexpr int U = 8;
         for (int base = 0; base < kept; base += kSBlock * U) {
             float2 xy[U]; float at[U]; int qq[U];
 #pragma unroll
@@ -1082,6 +1085,7 @@ __device__ __forceinline__ void bwd_value_wide_body(
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
+                if (base + u * kSBlock >= kept) break;                           // uniform
                 int dest[4]; PointGeom<float> g;
                 taps_of(xy[u], dest, g);
                 const float hh = 1.f - g.lh, hw = 1.f - g.lw;
