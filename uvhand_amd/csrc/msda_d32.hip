@@ -605,8 +605,8 @@ __device__ __forceinline__ void gather_rows(const VT *__restrict__ go_base, GT *
     }
 }
 
-// Step 4, balanced (kAccWide): the SORTED record array is cut into 64 equal stretches, one per lane group, moved
-// to row boundaries (a row's records stay with one lane group: rows are stored once, no combining).  A lane group
+// Step 4, balanced (every prefix-sum path): the SORTED record array is cut into 64 stretches of equal weight, one per
+// lane group, at row boundaries (a row's records stay with one lane group: rows are stored once, no combining).  A lane group
 // walks its stretch eight records at a time — every load is a real record, where gather_rows pads a row's last
 // trip (21-record rows on 8 slots x 4: a third of the loads and FMAs) — and stores a row whenever the running
 // index passes its end.  endv[r] = end of row r's segment (segments are contiguous: row r starts at endv[r - 1]).
@@ -621,12 +621,14 @@ __device__ __forceinline__ void gather_balanced(const VT *__restrict__ go_base, 
     constexpr int G = kSBlock / 8, CH = 8;
     const int tid = threadIdx.x, g = tid >> 3;
     struct { const int *cnt, *start; __device__ int operator[](int r) const { return ENDS ? start[r] : start[r] + cnt[r]; } } endv{cnt, start};
-    // first row of this lane group: the smallest r whose segment starts at or after record g * total / G
-    const int lo = (g * total) / G;                          // total <= kWideRecCap: no overflow
+    // first row of this lane group: rows are dealt by weight = records + 2 (a row costs a store and a few
+    // instructions even when empty: without the "+ 2" the lane group after a cluster would inherit every empty row
+    // behind it), i.e. the smallest r with begin[r] + 2 r >= g * (total + 2 npx) / G
+    const int lo = (g * (total + 2 * npx)) / G;              // total <= 12 288 records, npx <= 1920 rows: no overflow
     int a = 0, b = npx;
     while (a < b) {
         const int mid = (a + b) >> 1;
-        if ((mid ? endv[mid - 1] : 0) >= lo) b = mid; else a = mid + 1;
+        if ((mid ? endv[mid - 1] : 0) + 2 * mid >= lo) b = mid; else a = mid + 1;
     }
     if ((tid & 7) == 0) firsts[g] = a;
     if (tid == 0) firsts[G] = npx;
@@ -636,9 +638,8 @@ __device__ __forceinline__ void gather_balanced(const VT *__restrict__ go_base, 
     if (r >= r_stop) return;                                 // (no barrier below)
     int i = r ? endv[r - 1] : 0;
     const int i_stop = endv[r_stop - 1];
-    // the end of the row after the current one is read one flush ahead: a flush then waits for nothing (lane groups
-    // of a wavefront flush at different records, so each flush runs on its own under the execution mask — with an
-    // LDS round trip inside, 12 flushes per lane group cost more than the records; measured 14.8 -> see r02_notes §10)
+    // the end of the row after the current one is read one flush ahead, so a flush waits for nothing (lane groups of a
+    // wavefront flush at different records: each flush runs on its own under the execution mask)
     int row_end = endv[r], next_end = r + 1 < r_stop ? endv[r + 1] : 0x7fffffff;
     GT *prow = gv_base + (long long)r * row_stride;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
