@@ -272,7 +272,10 @@ PILED = {"cfg2_decoder": (2, [(48, 48), (24, 24), (12, 12), (6, 6)], 8, 32, 300,
          # Lq*P beyond one pass: the kept-taps single pass (bwd_value_wide_body) and, when a workgroup's rows receive more
          # taps than its record array holds (small spreads), its chunked fall-back
          "many_queries": (2, [(16, 16), (8, 8)], 8, 32, 2100, 4),
-         "long_encoder": (1, [(40, 40), (20, 20), (10, 10), (5, 5)], 8, 32, 2125, 4)}
+         "long_encoder": (1, [(40, 40), (20, 20), (10, 10), (5, 5)], 8, 32, 2125, 4),
+         # Lq*P = 68 000 > 65 536: more than one attempt (16-bit chunk-relative list) and far more taps per workgroup than
+         # its record array holds at any spread (9 ranges where 43 would be needed): the count-sized chunks
+         "beyond_16bit": (1, [(12, 12)], 2, 32, 17000, 4)}
 
 
 @pytest.mark.parametrize("geometry", list(PILED))
