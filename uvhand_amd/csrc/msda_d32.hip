@@ -974,7 +974,7 @@ __device__ __forceinline__ void bwd_value_wide_body(
         // a superset — inside the map and one of the two tap pairs meets [0, npx) — in float arithmetic (exact: S < 2^24);
         // the exact taps are worked out for the listed points only.  The thread's point index advances by 512 per
         // step: (q, p) and the address follow by additions.
-        constexpr int U = 8;
+        constexpr int U = 9;                        // loads in flight per thread (4180 points = ONE trip); 10 crosses 128 VGPRs
         const int dq = fdiv(kSBlock, P, p_shift), dp = kSBlock - dq * P;        // 512 = dq*P + dp (uniform)
         const int doff = dq * MLP + dp, wrap = MLP - P;
         int q0;
@@ -993,6 +993,8 @@ __device__ __forceinline__ void bwd_value_wide_body(
             int n = 0;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
+                mask[u] = 0;
+                if (base + u * kSBlock >= p1) continue;                         // uniform: no point in this slot
                 const float h_im = xy[u].y * Hf - 0.5f, w_im = xy[u].x * Wf - 0.5f;
                 const float pixf = fmaf(floorf(h_im), Wf, floorf(w_im)) - px0f;  // tap (h0, w0), range-local
                 // taps sit at pix, pix + 1 and pix + W, pix + W + 1 (border validity ignored: a superset)
@@ -1184,8 +1186,10 @@ __global__ __launch_bounds__(kSBlock) void bwd_value_d32_kernel(
 // (grad_value), the rest role A (grad_sampling_loc / grad_attn_weight).  The two roles share no
 // data, so this is plain concurrency inside one grid — it removes a dependent kernel boundary
 // (~1.5 us) and lets role A's short workgroups fill the CUs around role B's longer ones.
+// (second launch bound: 4 wavefronts per SIMD = two 512-thread workgroups per CU.  The kAccWide instantiations sit at
+// 127-128 VGPRs; one more would silently halve the occupancy — measured: cfg-4 encoder 304 -> 442 us.)
 template <int SPLIT, int ACC, typename VT, bool FUSED = false, typename GT = VT, bool FIXED = false>
-__global__ __launch_bounds__(kSBlock) void bwd_fused_d32_kernel(
+__global__ __launch_bounds__(kSBlock, 4) void bwd_fused_d32_kernel(
     const VT *__restrict__ grad_out, const VT *__restrict__ value,
     const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
     const float *__restrict__ loc, const float *__restrict__ attn, int S, int M, int L, int Lq,
