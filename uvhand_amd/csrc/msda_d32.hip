@@ -672,6 +672,78 @@ __device__ __forceinline__ void gather_balanced(const VT *__restrict__ go_base, 
     while (r < r_stop) flush();                              // the row in progress and the empty rows after it
 }
 
+// Step 4 for rows of very different lengths (a coarse level: five rows of 1400 records): the sorted records are cut
+// into 64 EQUAL stretches whatever the rows are.  A lane group walks its stretch eight records at a time; rows that
+// end inside it are stored (the group that holds a row's FIRST record owns the row); the part of a row that began in
+// an earlier stretch goes to part[g] in LDS (a lane group has at most one: only its first row can have begun earlier),
+// and after one barrier the owner adds the parts of the groups behind it in group order — fixed association, no
+// atomics.  Rows without records are stored as zeros up front.  gather_rows gives such rows one wavefront each
+// (five of eight busy, 8 slots x 4 loads in flight): gather of a workgroup of cfg-2 encoder's 6x6 level 20.2 -> 11.3 us,
+// cfg-4 encoder backward 301 -> 272 us (half its workgroups belong to coarse levels); profiles/r02_notes.md §10.
+template <typename VT, typename GT, bool ENDS, bool OFFS>
+__device__ __forceinline__ void gather_split(const VT *__restrict__ go_base, GT *__restrict__ gv_base, const int *cnt,
+                                             const int *start, const SRec *rec, float4 *part, int npx, int row_stride,
+                                             int total, bool first_pass)
+{
+    constexpr int G = kSBlock / 8, CH = 8;
+    const int tid = threadIdx.x, g = tid >> 3, j = tid & 7;
+    struct { const int *cnt, *start; __device__ int operator[](int r) const { return ENDS ? start[r] : start[r] + cnt[r]; } } endv{cnt, start};
+    auto put = [&](int r, float4 v) {
+        GT *p = gv_base + (long long)r * row_stride;
+        if (!first_pass) add4(v, Row<GT>::load(p));
+        Row<GT>::store(p, v);
+    };
+    for (int r = g; r < npx; r += G)                          // rows nobody will visit
+        if (cnt[r] == 0 && first_pass) Row<GT>::store(gv_base + (long long)r * row_stride, make_float4(0.f, 0.f, 0.f, 0.f));
+    const int lo = (int)(((long long)g * total) / G), hi = (int)(((long long)(g + 1) * total) / G);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int r = 0, own_end = 0;                                   // own_end > 0: this group owns row r, which runs on to record own_end
+    if (lo < hi) {
+        int a = 0, b = npx - 1;                               // the row of record lo: smallest r with endv[r] > lo
+        while (a < b) { const int mid = (a + b) >> 1; if (endv[mid] > lo) b = mid; else a = mid + 1; }
+        r = a;
+        bool foreign = (r ? endv[r - 1] : 0) < lo;            // the row began in an earlier stretch
+        int row_end = endv[r];
+        auto close_row = [&]() {                              // row r's records in this stretch are all in acc
+            if (foreign) part[g * 8 + j] = acc; else put(r, acc);
+            acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            foreign = false;
+            do { ++r; } while (r < npx && endv[r] == row_end);    // skip rows without records
+            row_end = r < npx ? endv[r] : 0x7fffffff;
+        };
+        int i = lo;
+        for (; i + CH <= hi; i += CH) {
+            SRec e[CH]; float4 gl[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) e[u] = rec[i + u];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) gl[u] = Row<VT>::load(go_base + (OFFS ? (long long)e[u].q : (long long)e[u].q * row_stride));
+#pragma unroll
+            for (int u = 0; u < CH; ++u) { if (i + u >= row_end) close_row(); fma4(acc, e[u].w, gl[u]); }
+        }
+        if (i < hi) {
+            SRec e[CH]; float4 gl[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u)
+                if (i + u < hi) { e[u] = rec[i + u]; gl[u] = Row<VT>::load(go_base + (OFFS ? (long long)e[u].q : (long long)e[u].q * row_stride)); }
+#pragma unroll
+            for (int u = 0; u < CH; ++u) if (i + u < hi) { if (i + u >= row_end) close_row(); fma4(acc, e[u].w, gl[u]); }
+        }
+        // the row in progress: complete if it ends with the stretch, else it runs on into later stretches
+        if (row_end <= hi) close_row();
+        else if (foreign) part[g * 8 + j] = acc;              // the whole stretch lies inside a row owned further up
+        else own_end = row_end;
+    }
+    __syncthreads();
+    if (own_end > 0) {
+        for (int g2 = g + 1; g2 < G && (int)(((long long)g2 * total) / G) < own_end; ++g2) {
+            // a stretch may be empty (total < 64): it wrote nothing
+            if ((int)(((long long)g2 * total) / G) < (int)(((long long)(g2 + 1) * total) / G)) add4(acc, part[g2 * 8 + j]);
+        }
+        put(r, acc);
+    }
+}
+
 template <typename VT, typename GT>
 __device__ __forceinline__ void bwd_value_wide_body(const VT *__restrict__, const int64_t *__restrict__, const int64_t *__restrict__,
                                                     const float *__restrict__, const float *__restrict__, int, int, int, int, int,
@@ -900,6 +972,10 @@ __device__ __forceinline__ void bwd_value_body(
 constexpr int kWideRecCap = 7168;                   // records (56 KB)
 constexpr int kWideListCap = kWideRecCap;           // listed points (14 KB of 16-bit chunk-relative indices): a listed
                                                     // point has at least one tap here, so the records overflow first
+#ifndef MSDA_WIDE_SPLIT
+#define MSDA_WIDE_SPLIT 1
+#endif
+constexpr bool kWideSplitGather = MSDA_WIDE_SPLIT != 0;   // rows of very different lengths: gather_split (0: gather_rows)
 constexpr int kWideMaxStep = 65536;                 // points per attempt (what a 16-bit list entry can address)
 constexpr int kWideChunk = kWideRecCap / 4;         // points per fallback pass
 template <typename VT, typename GT>
@@ -1102,8 +1178,13 @@ __device__ __forceinline__ void bwd_value_wide_body(
         __syncthreads();
         MSDA_STAMP(4);
         // rows of comparable length (the longest no more than one lane group's share): the balanced walk
-        if (longest_row() * 64 <= max(total, 1024)) {
+        if (MSDA_WIDE_SPLIT < 2 && longest_row() * 64 <= max(total, 1024)) {
             gather_balanced<VT, GT, true, true>(go_base, gv_base, cnt, start, rec, reinterpret_cast<int *>(list), npx, row_stride, total, first);
+            MSDA_STAMP(5);
+            return;
+        }
+        if (kWideSplitGather) {
+            gather_split<VT, GT, true, true>(go_base, gv_base, cnt, start, rec, reinterpret_cast<float4 *>(list), npx, row_stride, total, first);
             MSDA_STAMP(5);
             return;
         }
