@@ -530,14 +530,12 @@ __device__ __forceinline__ void add4(float4 &a, const float4 &b) { a.x += b.x; a
 // CH*SLOTS records of two rows.  (A balanced "linear" variant — the sorted records cut evenly over
 // the lane groups, partial row runs combined in a fix-up phase — was measured and is not faster:
 // its per-record run bookkeeping costs what the load imbalance costs here; profiles/r01_notes.md.)
-// OFFS: a record's q is already the element offset of its grad_out row (q * row_stride), not the query index.
-template <int SLOTS, int ACC, typename VT, typename GT, bool OFFS = false>
+template <int SLOTS, int ACC, typename VT, typename GT>
 __device__ __forceinline__ void gather_rows(const VT *__restrict__ go_base, GT *__restrict__ gv_base,
                                             const int *cnt, const int *start, const SRec *rec, float *tile,
                                             int npx, int row_stride, bool first_pass, int cap_shift = -1,
-                                            const SOvf *ovf = nullptr, int novf = 0, bool ends = false)
+                                            const SOvf *ovf = nullptr, int novf = 0)
 {
-    // ends: start[d] holds the END of row d's segment (the scatter advanced it as its cursor)
     // cap_shift >= 0: fixed-capacity segments (row d at d << cap_shift, at most 1 << cap_shift records there,
     // the rest of a fuller row in ovf[0, novf)); cap_shift < 0: segments from the prefix sum (start[])
     constexpr int DPW = 8 / SLOTS;
@@ -551,8 +549,8 @@ __device__ __forceinline__ void gather_rows(const VT *__restrict__ go_base, GT *
         const int fullA = cnt[dA], fullB = hasB ? cnt[dB] : 0;
         const int nA = cap_shift >= 0 ? min(fullA, 1 << cap_shift) : fullA;
         const int nB = cap_shift >= 0 ? min(fullB, 1 << cap_shift) : fullB;
-        const SRec *rA = rec + (cap_shift >= 0 ? dA << cap_shift : start[dA] - (ends ? fullA : 0));
-        const SRec *rB = rec + (!hasB ? 0 : cap_shift >= 0 ? dB << cap_shift : start[dB] - (ends ? fullB : 0));
+        const SRec *rA = rec + (cap_shift >= 0 ? dA << cap_shift : start[dA]);
+        const SRec *rB = rec + (!hasB ? 0 : cap_shift >= 0 ? dB << cap_shift : start[dB]);
         float4 accA = make_float4(0.f, 0.f, 0.f, 0.f), accB = accA;
         const int nmax = max(nA, nB);
         for (int i0 = slot; i0 < nmax; i0 += CH * SLOTS) {
@@ -565,8 +563,8 @@ __device__ __forceinline__ void gather_rows(const VT *__restrict__ go_base, GT *
             }
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
-                const float4 ta = Row<VT>::load(go_base + (OFFS ? (long long)max(ra[u].q, 0) : (long long)max(ra[u].q, 0) * row_stride));
-                const float4 tb = Row<VT>::load(go_base + (OFFS ? (long long)max(rb[u].q, 0) : (long long)max(rb[u].q, 0) * row_stride));
+                const float4 ta = Row<VT>::load(go_base + (long long)max(ra[u].q, 0) * row_stride);
+                const float4 tb = Row<VT>::load(go_base + (long long)max(rb[u].q, 0) * row_stride);
                 const bool oa = ra[u].q >= 0, ob = rb[u].q >= 0;
                 ga[u] = make_float4(oa ? ta.x : 0.f, oa ? ta.y : 0.f, oa ? ta.z : 0.f, oa ? ta.w : 0.f);
                 gb[u] = make_float4(ob ? tb.x : 0.f, ob ? tb.y : 0.f, ob ? tb.z : 0.f, ob ? tb.w : 0.f);
@@ -612,7 +610,8 @@ __device__ __forceinline__ void gather_rows(const VT *__restrict__ go_base, GT *
 // index passes its end.  endv[r] = end of row r's segment (segments are contiguous: row r starts at endv[r - 1]).
 // For rows of comparable length; a row with thousands of records would leave most
 // lane groups idle, so the caller keeps gather_rows for those.
-// ENDS: start[r] is the END of row r's segment (kAccWide's scatter cursor), else its beginning; OFFS as in gather_rows.
+// ENDS: start[r] is the END of row r's segment (kAccWide's scatter cursor), else its beginning; OFFS: a record's q is
+// already the element offset of its grad_out row (q * row_stride), not the query index.
 template <typename VT, typename GT, bool ENDS, bool OFFS>
 __device__ __forceinline__ void gather_balanced(const VT *__restrict__ go_base, GT *__restrict__ gv_base,
                                                 const int *cnt, const int *start, const SRec *rec, int *firsts, int npx,
@@ -972,10 +971,6 @@ __device__ __forceinline__ void bwd_value_body(
 constexpr int kWideRecCap = 7168;                   // records (56 KB)
 constexpr int kWideListCap = kWideRecCap;           // listed points (14 KB of 16-bit chunk-relative indices): a listed
                                                     // point has at least one tap here, so the records overflow first
-#ifndef MSDA_WIDE_SPLIT
-#define MSDA_WIDE_SPLIT 1
-#endif
-constexpr bool kWideSplitGather = MSDA_WIDE_SPLIT != 0;   // rows of very different lengths: gather_split (0: gather_rows)
 constexpr int kWideMaxStep = 65536;                 // points per attempt (what a 16-bit list entry can address)
 constexpr int kWideChunk = kWideRecCap / 4;         // points per fallback pass
 template <typename VT, typename GT>
@@ -1178,21 +1173,15 @@ __device__ __forceinline__ void bwd_value_wide_body(
         __syncthreads();
         MSDA_STAMP(4);
         // rows of comparable length (the longest no more than one lane group's share): the balanced walk
-        if (MSDA_WIDE_SPLIT < 2 && longest_row() * 64 <= max(total, 1024)) {
+        if (longest_row() * 64 <= max(total, 1024)) {
             gather_balanced<VT, GT, true, true>(go_base, gv_base, cnt, start, rec, reinterpret_cast<int *>(list), npx, row_stride, total, first);
             MSDA_STAMP(5);
             return;
         }
-        if (kWideSplitGather) {
-            gather_split<VT, GT, true, true>(go_base, gv_base, cnt, start, rec, reinterpret_cast<float4 *>(list), npx, row_stride, total, first);
-            MSDA_STAMP(5);
-            return;
-        }
-        const int mean2 = (2 * total) / npx;                                  // 2 x mean records per row
-        if (mean2 <= 8)       gather_rows<1, kAccRmw, VT, GT, true>(go_base, gv_base, cnt, start, rec, nullptr, npx, row_stride, first, -1, nullptr, 0, true);
-        else if (mean2 <= 16) gather_rows<2, kAccRmw, VT, GT, true>(go_base, gv_base, cnt, start, rec, nullptr, npx, row_stride, first, -1, nullptr, 0, true);
-        else if (mean2 <= 32) gather_rows<4, kAccRmw, VT, GT, true>(go_base, gv_base, cnt, start, rec, nullptr, npx, row_stride, first, -1, nullptr, 0, true);
-        else                  gather_rows<8, kAccRmw, VT, GT, true>(go_base, gv_base, cnt, start, rec, nullptr, npx, row_stride, first, -1, nullptr, 0, true);
+        // rows of very different lengths (coarse levels): equal stretches of records, parts combined by the row's owner.
+        // (Measured against it: the split gather for every row mix — same at cfg-2 / cfg-4 encoder, but on the single-pass
+        // path 784 six-record rows cost 19.5 instead of 14.5 us; gather_rows here: 20.2 instead of 11.3 us per workgroup.)
+        gather_split<VT, GT, true, true>(go_base, gv_base, cnt, start, rec, reinterpret_cast<float4 *>(list), npx, row_stride, total, first);
         MSDA_STAMP(5);
     };
 
