@@ -458,783 +458,9 @@ __global__ __launch_bounds__(kBlock) void bwd_query_d32_kernel(
                                                  xcd ? xcd_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x, smem, pro);
 }
 
-// ------------------------------------------------------------------------------------------
-// backward, role B — destination-major: grad_value with no float atomics at all.
-//
-// grad_value[b, s, m, :] = sum over the taps that land on pixel s of (bilinear weight * attention
-// weight) * grad_out[b, q, m, :] — a sparse-matrix x dense-matrix product whose sparse factor is
-// only known at run time.  Float atomics are the wrong tool for it on this chip: global float
-// atomics run at ~1.3 TB/s of added bytes chip-wide (MI355X_MICROARCH.md), and LDS float atomics
-// are slower still — ds_add_f32 measured ~200 cycles per wavefront instruction whatever the
-// address pattern (tools/micro/lds_atomic_bench.hip), i.e. ~0.8 TB/s chip-wide, while LDS
-// INTEGER atomics are >6x faster.  So each workgroup sorts instead of scattering:
-//
-//   a workgroup owns the rows of (batch b, head m, level l, pixel range [px0, px1)) and
-//   1. scans the level's Lq*P sampling points of (b, m), one lane per point, and counts the taps
-//      that land on each of its rows        (LDS integer atomics: histogram)
-//   2. prefix-sums the histogram            (row -> segment of the record array)
-//   3. scans again and drops a record {weight, query} into the row's segment
-//      (counting sort, LDS integer atomics for the cursor)
-//   4. gathers: SLOTS x 8 lanes per row walk the row's segment, each record one coalesced 128-B
-//      read of grad_out, accumulate in registers, combine the SLOTS partial sums with cross-lane
-//      shuffles, and store the row once (zeros included) — no zero-fill pass, no atomics, every
-//      element of grad_value written exactly once by exactly one workgroup.
-//
-// Every level is cut into the same number W of pixel ranges: all levels receive the same number
-// of points, so equal counts of workgroups per level balance the gather work even though a coarse
-// level has 4x fewer pixels.  W comes from the host (it only needs S and the batch size); the
-// ranges come from spatial_shapes on the device.
-// ACC (accumulation mode when Lq*P exceeds one pass's record array and queries go in chunks):
-//   kAccNone  single pass: each row is stored once from registers;
-//   kAccRmw   fp32 storage: pass 0 stores the rows, later passes read-add-write them in global memory
-//             (the rows belong to this workgroup alone, passes are separated by __syncthreads, and
-//             they stay in L2) — no LDS tile, so several workgroups fit per CU;
-//   kAccTile  bf16 storage: rows accumulate in an fp32 LDS tile and are rounded ONCE at the flush.
-//   kAccWide  fp32 grad_value, Lq*P beyond one pass: bwd_value_wide_body below — ONE pass over all Lq*P points
-//             whenever the taps this workgroup KEEPS fit the record array (a workgroup owns 1/W of a level, so
-//             it keeps ~1/W of the level's taps), chunked kAccRmw passes otherwise.
-// ------------------------------------------------------------------------------------------
-constexpr int kSBlock = 512;
-constexpr int kSWaves = kSBlock / kWave;
-constexpr int kAccNone = 0, kAccRmw = 1, kAccTile = 2, kAccWide = 3;
-struct alignas(8) SRec { float w; int q; };
-// Fixed-capacity segments (FIXED = true: steps 1-3 in one scan, for problems small enough that every workgroup
-// is resident at once and the backward is one latency chain): row d owns the record slots [d*CAP, (d+1)*CAP),
-// CAP = the largest power of two with rows*CAP <= the record array, so a tap's record goes straight to
-// d*CAP + (its rank from the histogram atomic) — no prefix sum, no second scan, two barriers fewer.  The few
-// taps whose row is already full go to a short overflow list that the gather of exactly those rows also walks;
-// a workgroup whose overflow list fills up (many taps piled on few pixels) starts over on the prefix-sum path.
-// Not used on large problems: there the sort phases hide behind other workgroups' gathers, and clustered
-// locations make many rows walk the overflow list (profiles/r01_notes.md).
-struct SOvf { float w; int q; int row; };
-constexpr int kOvfCap = 256;                // overflow entries per workgroup (3 KB of LDS)
-
-// role-B sizing: single pass while 4*Lq*P records (8 B) fit beside the histogram in 64 KB of LDS
-constexpr int kSinglePPT = 3;               // points per thread: 3*512 = 1536 points, 48 KB of records
-constexpr int kSingleMaxPoints = kSinglePPT * 512;
-constexpr int kSingleMaxRows = 1920;        // 15 KB of histogram + prefix (rows per workgroup)
-constexpr int kMultiRows = 256;             // 32 KB LDS tile
-constexpr int kMultiPPT = 6;                // 3072 points per pass, 96 KB of records
-
-
-__device__ __forceinline__ float4 shfl_xor4(const float4 &v, int m)
-{
-    return make_float4(__shfl_xor(v.x, m, kWave), __shfl_xor(v.y, m, kWave), __shfl_xor(v.z, m, kWave),
-                       __shfl_xor(v.w, m, kWave));
-}
-__device__ __forceinline__ void add4(float4 &a, const float4 &b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
-
-// Step 4.  SLOTS lane-groups of 8 lanes share one row's segment; 8/SLOTS rows per wavefront trip and
-// TWO trips' rows in flight (A and B).  A lane group takes CH records of each row at a time: the
-// record reads, then 2*CH independent 128-B row loads, then the FMAs — one memory round trip per
-// CH*SLOTS records of two rows.  (A balanced "linear" variant — the sorted records cut evenly over
-// the lane groups, partial row runs combined in a fix-up phase — was measured and is not faster:
-// its per-record run bookkeeping costs what the load imbalance costs here; profiles/r01_notes.md.)
-template <int SLOTS, int ACC, typename VT, typename GT>
-__device__ __forceinline__ void gather_rows(const VT *__restrict__ go_base, GT *__restrict__ gv_base,
-                                            const int *cnt, const int *start, const SRec *rec, float *tile,
-                                            int npx, int row_stride, bool first_pass, int cap_shift = -1,
-                                            const SOvf *ovf = nullptr, int novf = 0)
-{
-    // cap_shift >= 0: fixed-capacity segments (row d at d << cap_shift, at most 1 << cap_shift records there,
-    // the rest of a fuller row in ovf[0, novf)); cap_shift < 0: segments from the prefix sum (start[])
-    constexpr int DPW = 8 / SLOTS;
-    constexpr int CH = 4;
-    constexpr int RSTEP = kSWaves * DPW;                     // rows per workgroup trip
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int dsub = lane / (SLOTS * 8), slot = (lane >> 3) % SLOTS, j = lane & 7;
-    for (int dA = wave * DPW + dsub; dA < npx; dA += 2 * RSTEP) {
-        const int dB = dA + RSTEP;
-        const bool hasB = dB < npx;
-        const int fullA = cnt[dA], fullB = hasB ? cnt[dB] : 0;
-        const int nA = cap_shift >= 0 ? min(fullA, 1 << cap_shift) : fullA;
-        const int nB = cap_shift >= 0 ? min(fullB, 1 << cap_shift) : fullB;
-        const SRec *rA = rec + (cap_shift >= 0 ? dA << cap_shift : start[dA]);
-        const SRec *rB = rec + (!hasB ? 0 : cap_shift >= 0 ? dB << cap_shift : start[dB]);
-        float4 accA = make_float4(0.f, 0.f, 0.f, 0.f), accB = accA;
-        const int nmax = max(nA, nB);
-        for (int i0 = slot; i0 < nmax; i0 += CH * SLOTS) {
-            SRec ra[CH], rb[CH]; float4 ga[CH], gb[CH];
-#pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                ra[u].w = 0.f; ra[u].q = -1; rb[u] = ra[u];
-                if (i0 + u * SLOTS < nA) ra[u] = rA[i0 + u * SLOTS];
-                if (i0 + u * SLOTS < nB) rb[u] = rB[i0 + u * SLOTS];
-            }
-#pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                const float4 ta = Row<VT>::load(go_base + (long long)max(ra[u].q, 0) * row_stride);
-                const float4 tb = Row<VT>::load(go_base + (long long)max(rb[u].q, 0) * row_stride);
-                const bool oa = ra[u].q >= 0, ob = rb[u].q >= 0;
-                ga[u] = make_float4(oa ? ta.x : 0.f, oa ? ta.y : 0.f, oa ? ta.z : 0.f, oa ? ta.w : 0.f);
-                gb[u] = make_float4(ob ? tb.x : 0.f, ob ? tb.y : 0.f, ob ? tb.z : 0.f, ob ? tb.w : 0.f);
-            }
-#pragma unroll
-            for (int u = 0; u < CH; ++u) { fma4(accA, ra[u].w, ga[u]); fma4(accB, rb[u].w, gb[u]); }
-        }
-        if (novf > 0 && (fullA > nA || fullB > nB)) {                  // rare: this lane group's row overflowed
-            for (int i = slot; i < novf; i += SLOTS) {
-                const SOvf e = ovf[i];
-                if (e.row == dA) fma4(accA, e.w, Row<VT>::load(go_base + (long long)e.q * row_stride));
-                else if (hasB && e.row == dB) fma4(accB, e.w, Row<VT>::load(go_base + (long long)e.q * row_stride));
-            }
-        }
-        if (SLOTS >= 2) { add4(accA, shfl_xor4(accA, 8)); add4(accB, shfl_xor4(accB, 8)); }
-        if (SLOTS >= 4) { add4(accA, shfl_xor4(accA, 16)); add4(accB, shfl_xor4(accB, 16)); }
-        if (SLOTS >= 8) { add4(accA, shfl_xor4(accA, 32)); add4(accB, shfl_xor4(accB, 32)); }
-        if (slot == 0) {
-            if (ACC == kAccTile) {
-                float4 *tA = reinterpret_cast<float4 *>(tile) + dA * 8 + j;
-                if (first_pass) *tA = accA; else { float4 o = *tA; add4(o, accA); *tA = o; }
-                if (hasB) {
-                    float4 *tB = reinterpret_cast<float4 *>(tile) + dB * 8 + j;
-                    if (first_pass) *tB = accB; else { float4 o = *tB; add4(o, accB); *tB = o; }
-                }
-            } else {
-                GT *pA = gv_base + (long long)dA * row_stride, *pB = gv_base + (long long)dB * row_stride;
-                if (ACC == kAccRmw && !first_pass) {
-                    add4(accA, Row<GT>::load(pA));
-                    if (hasB) add4(accB, Row<GT>::load(pB));
-                }
-                Row<GT>::store(pA, accA);
-                if (hasB) Row<GT>::store(pB, accB);
-            }
-        }
-    }
-}
-
-// Step 4, balanced (every prefix-sum path): the SORTED record array is cut into 64 stretches of equal weight, one per
-// lane group, at row boundaries (a row's records stay with one lane group: rows are stored once, no combining).  A lane group
-// walks its stretch eight records at a time — every load is a real record, where gather_rows pads a row's last
-// trip (21-record rows on 8 slots x 4: a third of the loads and FMAs) — and stores a row whenever the running
-// index passes its end.  endv[r] = end of row r's segment (segments are contiguous: row r starts at endv[r - 1]).
-// For rows of comparable length; a row with thousands of records would leave most
-// lane groups idle, so the caller keeps gather_rows for those.
-// ENDS: start[r] is the END of row r's segment (kAccWide's scatter cursor), else its beginning; OFFS: a record's q is
-// already the element offset of its grad_out row (q * row_stride), not the query index.
-template <typename VT, typename GT, bool ENDS, bool OFFS>
-__device__ __forceinline__ void gather_balanced(const VT *__restrict__ go_base, GT *__restrict__ gv_base,
-                                                const int *cnt, const int *start, const SRec *rec, int *firsts, int npx,
-                                                int row_stride, int total, bool first_pass)
-{
-    constexpr int G = kSBlock / 8, CH = 8;
-    const int tid = threadIdx.x, g = tid >> 3;
-    struct { const int *cnt, *start; __device__ int operator[](int r) const { return ENDS ? start[r] : start[r] + cnt[r]; } } endv{cnt, start};
-    // first row of this lane group: rows are dealt by weight = records + 2 (a row costs a store and a few
-    // instructions even when empty: without the "+ 2" the lane group after a cluster would inherit every empty row
-    // behind it), i.e. the smallest r with begin[r] + 2 r >= g * (total + 2 npx) / G
-    const int lo = (g * (total + 2 * npx)) / G;              // total <= 12 288 records, npx <= 1920 rows: no overflow
-    int a = 0, b = npx;
-    while (a < b) {
-        const int mid = (a + b) >> 1;
-        if ((mid ? endv[mid - 1] : 0) + 2 * mid >= lo) b = mid; else a = mid + 1;
-    }
-    if ((tid & 7) == 0) firsts[g] = a;
-    if (tid == 0) firsts[G] = npx;
-    __syncthreads();
-    int r = a;
-    const int r_stop = firsts[g + 1];
-    if (r >= r_stop) return;                                 // (no barrier below)
-    int i = r ? endv[r - 1] : 0;
-    const int i_stop = endv[r_stop - 1];
-    // the end of the row after the current one is read one flush ahead, so a flush waits for nothing (lane groups of a
-    // wavefront flush at different records: each flush runs on its own under the execution mask)
-    int row_end = endv[r], next_end = r + 1 < r_stop ? endv[r + 1] : 0x7fffffff;
-    GT *prow = gv_base + (long long)r * row_stride;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto flush = [&]() {                                     // row r is complete (possibly empty)
-        if (!first_pass) add4(acc, Row<GT>::load(prow));
-        Row<GT>::store(prow, acc);
-        acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        prow += row_stride;
-        ++r;
-        row_end = next_end;
-        next_end = r + 1 < r_stop ? endv[r + 1] : 0x7fffffff;
-    };
-    for (; i + CH <= i_stop; i += CH) {
-        SRec e[CH]; float4 gl[CH];
-#pragma unroll
-        for (int u = 0; u < CH; ++u) e[u] = rec[i + u];
-#pragma unroll
-        for (int u = 0; u < CH; ++u) gl[u] = Row<VT>::load(go_base + (OFFS ? (long long)e[u].q : (long long)e[u].q * row_stride));
-#pragma unroll
-        for (int u = 0; u < CH; ++u) { while (i + u >= row_end) flush(); fma4(acc, e[u].w, gl[u]); }
-    }
-    if (i < i_stop) {                                        // last, partial batch
-        SRec e[CH]; float4 gl[CH];
-#pragma unroll
-        for (int u = 0; u < CH; ++u)
-            if (i + u < i_stop) { e[u] = rec[i + u]; gl[u] = Row<VT>::load(go_base + (OFFS ? (long long)e[u].q : (long long)e[u].q * row_stride)); }
-#pragma unroll
-        for (int u = 0; u < CH; ++u) if (i + u < i_stop) { while (i + u >= row_end) flush(); fma4(acc, e[u].w, gl[u]); }
-    }
-    while (r < r_stop) flush();                              // the row in progress and the empty rows after it
-}
-
-// Step 4 for rows of very different lengths (a coarse level: five rows of 1400 records): the sorted records are cut
-// into 64 EQUAL stretches whatever the rows are.  A lane group walks its stretch eight records at a time; rows that
-// end inside it are stored (the group that holds a row's FIRST record owns the row); the part of a row that began in
-// an earlier stretch goes to part[g] in LDS (a lane group has at most one: only its first row can have begun earlier),
-// and after one barrier the owner adds the parts of the groups behind it in group order — fixed association, no
-// atomics.  Rows without records are stored as zeros up front.  gather_rows gives such rows one wavefront each
-// (five of eight busy, 8 slots x 4 loads in flight): gather of a workgroup of cfg-2 encoder's 6x6 level 20.2 -> 11.3 us,
-// cfg-4 encoder backward 301 -> 272 us (half its workgroups belong to coarse levels); profiles/r02_notes.md §10.
-template <typename VT, typename GT, bool ENDS, bool OFFS>
-__device__ __forceinline__ void gather_split(const VT *__restrict__ go_base, GT *__restrict__ gv_base, const int *cnt,
-                                             const int *start, const SRec *rec, float4 *part, int npx, int row_stride,
-                                             int total, bool first_pass)
-{
-    constexpr int G = kSBlock / 8, CH = 8;
-    const int tid = threadIdx.x, g = tid >> 3, j = tid & 7;
-    struct { const int *cnt, *start; __device__ int operator[](int r) const { return ENDS ? start[r] : start[r] + cnt[r]; } } endv{cnt, start};
-    auto put = [&](int r, float4 v) {
-        GT *p = gv_base + (long long)r * row_stride;
-        if (!first_pass) add4(v, Row<GT>::load(p));
-        Row<GT>::store(p, v);
-    };
-    for (int r = g; r < npx; r += G)                          // rows nobody will visit
-        if (cnt[r] == 0 && first_pass) Row<GT>::store(gv_base + (long long)r * row_stride, make_float4(0.f, 0.f, 0.f, 0.f));
-    const int lo = (int)(((long long)g * total) / G), hi = (int)(((long long)(g + 1) * total) / G);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    int r = 0, own_end = 0;                                   // own_end > 0: this group owns row r, which runs on to record own_end
-    if (lo < hi) {
-        int a = 0, b = npx - 1;                               // the row of record lo: smallest r with endv[r] > lo
-        while (a < b) { const int mid = (a + b) >> 1; if (endv[mid] > lo) b = mid; else a = mid + 1; }
-        r = a;
-        bool foreign = (r ? endv[r - 1] : 0) < lo;            // the row began in an earlier stretch
-        int row_end = endv[r];
-        auto close_row = [&]() {                              // row r's records in this stretch are all in acc
-            if (foreign) part[g * 8 + j] = acc; else put(r, acc);
-            acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            foreign = false;
-            do { ++r; } while (r < npx && endv[r] == row_end);    // skip rows without records
-            row_end = r < npx ? endv[r] : 0x7fffffff;
-        };
-        int i = lo;
-        for (; i + CH <= hi; i += CH) {
-            SRec e[CH]; float4 gl[CH];
-#pragma unroll
-            for (int u = 0; u < CH; ++u) e[u] = rec[i + u];
-#pragma unroll
-            for (int u = 0; u < CH; ++u) gl[u] = Row<VT>::load(go_base + (OFFS ? (long long)e[u].q : (long long)e[u].q * row_stride));
-#pragma unroll
-            for (int u = 0; u < CH; ++u) { if (i + u >= row_end) close_row(); fma4(acc, e[u].w, gl[u]); }
-        }
-        if (i < hi) {
-            SRec e[CH]; float4 gl[CH];
-#pragma unroll
-            for (int u = 0; u < CH; ++u)
-                if (i + u < hi) { e[u] = rec[i + u]; gl[u] = Row<VT>::load(go_base + (OFFS ? (long long)e[u].q : (long long)e[u].q * row_stride)); }
-#pragma unroll
-            for (int u = 0; u < CH; ++u) if (i + u < hi) { if (i + u >= row_end) close_row(); fma4(acc, e[u].w, gl[u]); }
-        }
-        // the row in progress: complete if it ends with the stretch, else it runs on into later stretches
-        if (row_end <= hi) close_row();
-        else if (foreign) part[g * 8 + j] = acc;              // the whole stretch lies inside a row owned further up
-        else own_end = row_end;
-    }
-    __syncthreads();
-    if (own_end > 0) {
-        for (int g2 = g + 1; g2 < G && (int)(((long long)g2 * total) / G) < own_end; ++g2) {
-            // a stretch may be empty (total < 64): it wrote nothing
-            if ((int)(((long long)g2 * total) / G) < (int)(((long long)(g2 + 1) * total) / G)) add4(acc, part[g2 * 8 + j]);
-        }
-        put(r, acc);
-    }
-}
-
-template <typename VT, typename GT>
-__device__ __forceinline__ void bwd_value_wide_body(const VT *__restrict__, const int64_t *__restrict__, const int64_t *__restrict__,
-                                                    const float *__restrict__, const float *__restrict__, int, int, int, int, int,
-                                                    int, int, GT *__restrict__, int, int, int, int, unsigned char *);   // kAccWide, below
-
-// PPT = sampling points per thread per pass: all of a thread's points are loaded up front (2*PPT
-// independent global loads in flight), their taps and histogram ranks stay in registers between
-// step 1 and step 3, so loc / attn are read exactly once and step 3 needs no atomics.
-// VT = storage type of grad_out, GT = storage type of grad_value (the same, or float for bf16 rows with an
-// fp32 grad_value: no rounding between passes, kAccRmw instead of the LDS tile).
-template <int ACC, int PPT, typename VT, typename GT = VT, bool FIXED = false>
-__device__ __forceinline__ void bwd_value_body(
-    const VT *__restrict__ grad_out, const int64_t *__restrict__ shapes,
-    const int64_t *__restrict__ level_start, const float *__restrict__ loc,
-    const float *__restrict__ attn, int S, int M, int L, int Lq, int P, int p_shift, int tp_cap,
-    GT *__restrict__ grad_value, int ti, int W, int l, int pr, unsigned char *smem)
-{
-    if constexpr (ACC == kAccWide) {
-        bwd_value_wide_body<VT, GT>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, tp_cap, grad_value,
-                                    ti, W, l, pr, smem);
-        return;
-    }
-    constexpr int NPC = PPT * kSBlock;                       // points per pass
-    // LDS: [tile: tp_cap*32 floats if kAccTile] [cnt tp_cap] [start tp_cap] [wsum 32] [rec] [ovf kOvfCap]
-    float *tile = reinterpret_cast<float *>(smem);
-    int *cnt = reinterpret_cast<int *>(smem + (ACC == kAccTile ? (size_t)tp_cap * kD * 4 : 0));
-    int *start = cnt + tp_cap;
-    int *wsum = start + tp_cap;
-    SRec *rec = reinterpret_cast<SRec *>(wsum + 32);
-    int *novf_p = wsum + 8, *total_p = wsum + 9;             // wsum[0..7]: per-wavefront sums of the prefix scan, [16..23]: longest row
-
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    MSDA_STAMP(0);
-    // (ti of W ranges, level l, pair pr = b*M + m): all uniform, scalar unit; 32-bit on purpose (the
-    // host checks S*W < 2^31).
-    const int H = (int)shapes[2 * l], Wd = (int)shapes[2 * l + 1], lstart = (int)level_start[l];
-    const int HW = H * Wd;
-    const int px0 = (int)((unsigned)(ti * HW) / (unsigned)W), px1 = (int)((unsigned)((ti + 1) * HW) / (unsigned)W);
-    const int npx = px1 - px0;
-    const int b = pr / M, m = pr - b * M;
-    if (l == 0 && ti == 0) {
-        // pixels past the last level that fits (inconsistent shapes only) get zeros; with level_start the running
-        // sum of H*W, as the reference's callers build it (models/arctic_transformer.py:176-177), there are none
-        long long cover = 0;
-        for (int k = 0; k < L; ++k)
-            if (level_fits(shapes[2 * k], shapes[2 * k + 1], level_start[k], S))
-                cover = max(cover, (long long)level_start[k] + shapes[2 * k] * shapes[2 * k + 1]);
-        for (int i = threadIdx.x; i < (S - (int)cover) * 8; i += kSBlock)
-            Row<GT>::store(grad_value + ((long long)(b * S + (int)cover + (i >> 3)) * M + m) * kD + (i & 7) * 4,
-                           make_float4(0.f, 0.f, 0.f, 0.f));
-    }
-    // empty range, or a level that does not fit in S (then nothing of it is touched).  A level that fits has
-    // npx <= tp_cap by construction of the ranges (plan_value: tp_cap = ceil(S / W) >= ceil(H*W / W_l)).
-    if (npx <= 0 || npx > tp_cap || !level_fits(shapes[2 * l], shapes[2 * l + 1], level_start[l], S)) return;
-    const int NP = Lq * P;
-    const long long item_base = (long long)b * Lq * M + m;                   // item(q) = item_base + q*M
-    const int row_stride = M * kD;
-    const int rec_cap = 4 * min(NP, NPC);                                    // records the host sized `rec` for
-    SOvf *ovf = reinterpret_cast<SOvf *>(rec + rec_cap);
-    // fixed-capacity segments need a few slots per row (uniform; small maps with few queries go the prefix way)
-    const int cap_shift = (FIXED && rec_cap >= 4 * npx) ? 31 - __clz(rec_cap / npx) : -1;
-    const VT *go_base = grad_out + item_base * kD + (lane & 7) * 4;
-    GT *gv_base = grad_value + ((long long)(b * S + lstart + px0) * M + m) * kD + (lane & 7) * 4;
-
-    // single-pass kernels (the host only picks them when NP <= NPC): a visible trip count of one lets the
-    // compiler keep the per-pass arrays out of the loop-carried state (103 -> 90 VGPRs)
-    const int np_loop = ACC == kAccNone ? min(NP, NPC) : NP;
-    for (int c0 = 0; c0 < np_loop; c0 += NPC) {
-        // ---- loads of this pass's points first: they overlap the histogram reset ----
-        float2 xy[PPT]; float at[PPT]; int qq[PPT];
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const int idx = c0 + tid + k * kSBlock;
-            qq[k] = -1; xy[k] = make_float2(-8.f, -8.f); at[k] = 0.f;
-            if (idx < NP) {
-                const int q = fdiv(idx, P, p_shift), p = idx - q * P;
-                const long long pi = ((item_base + (long long)q * M) * L + l) * P + p;
-                xy[k] = reinterpret_cast<const float2 *>(loc)[pi];
-                at[k] = attn[pi];
-                qq[k] = q;
-            }
-        }
-        for (int i = tid; i < npx; i += kSBlock) cnt[i] = 0;
-        if (FIXED && tid == 0) { *novf_p = 0; *total_p = 0; }
-        __syncthreads();
-        MSDA_STAMP(1);
-        // ---- 1. taps of each point ----
-        int dest[PPT][4]; float tw[PPT][4];
-        const bool first = (c0 == 0);
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const PointGeom<float> g = point_geom<float>(xy[k].x, xy[k].y, H, Wd);
-            const int pix = g.h0 * Wd + g.w0 - px0;                          // range-local index of tap (h0, w0)
-            const int p01 = pix + 1, p10 = pix + Wd, p11 = pix + Wd + 1;
-            const bool live = g.inside && qq[k] >= 0;
-            dest[k][0] = (live && g.ok00 && pix >= 0 && pix < npx) ? pix : -1;
-            dest[k][1] = (live && g.ok01 && p01 >= 0 && p01 < npx) ? p01 : -1;
-            dest[k][2] = (live && g.ok10 && p10 >= 0 && p10 < npx) ? p10 : -1;
-            dest[k][3] = (live && g.ok11 && p11 >= 0 && p11 < npx) ? p11 : -1;
-            const float hh = 1.f - g.lh, hw = 1.f - g.lw;
-            tw[k][0] = hh * hw * at[k]; tw[k][1] = hh * g.lw * at[k];
-            tw[k][2] = g.lh * hw * at[k]; tw[k][3] = g.lh * g.lw * at[k];
-        }
-        // ---- 1-3 the short way: fixed-capacity segments, a tap's record goes straight to its slot ----
-        if (FIXED && cap_shift >= 0) {
-            // all the histogram atomics first (they pipeline: nothing waits on a returned rank yet), then the
-            // record writes
-            int mine_taps = 0, rk[PPT][4];
-#pragma unroll
-            for (int k = 0; k < PPT; ++k)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) { rk[k][t] = 0; if (dest[k][t] >= 0) { rk[k][t] = atomicAdd(&cnt[dest[k][t]], 1); ++mine_taps; } }
-#pragma unroll
-            for (int k = 0; k < PPT; ++k)
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    if (dest[k][t] >= 0) {
-                        const int r = rk[k][t];
-                        if (r < (1 << cap_shift)) { SRec e; e.w = tw[k][t]; e.q = qq[k]; rec[(dest[k][t] << cap_shift) + r] = e; }
-                        else {
-                            const int o = atomicAdd(novf_p, 1);
-                            if (o < kOvfCap) { SOvf e; e.w = tw[k][t]; e.q = qq[k]; e.row = dest[k][t]; ovf[o] = e; }
-                        }
-                    }
-            mine_taps = wave_sum(mine_taps);
-            if (lane == 0) atomicAdd(total_p, mine_taps);
-            __syncthreads();
-            const int novf = *novf_p;
-            if (novf <= kOvfCap) {
-                MSDA_STAMP(2); MSDA_STAMP(3); MSDA_STAMP(4);
-                const int mean2f = (2 * *total_p) / npx;
-                if (mean2f <= 8)       gather_rows<1, ACC, VT, GT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first, cap_shift, ovf, novf);
-                else if (mean2f <= 16) gather_rows<2, ACC, VT, GT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first, cap_shift, ovf, novf);
-                else if (mean2f <= 32) gather_rows<4, ACC, VT, GT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first, cap_shift, ovf, novf);
-                else                   gather_rows<8, ACC, VT, GT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first, cap_shift, ovf, novf);
-                if (ACC != kAccNone) __syncthreads();
-                MSDA_STAMP(5);
-                continue;
-            }
-            // the overflow list filled up (taps piled on few pixels): start over on the prefix-sum path
-            for (int i = tid; i < npx; i += kSBlock) cnt[i] = 0;
-            __syncthreads();
-        }
-        // ---- 1. histogram rank of each tap on its row ----
-        int rank[PPT][4];
-#pragma unroll
-        for (int k = 0; k < PPT; ++k)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) { rank[k][t] = 0; if (dest[k][t] >= 0) rank[k][t] = atomicAdd(&cnt[dest[k][t]], 1); }
-        __syncthreads();
-        MSDA_STAMP(2);
-        // ---- 2. exclusive prefix sum over the rows (512 threads x CH consecutive rows) ----
-        const int CH = (npx + kSBlock - 1) / kSBlock;
-        const int r0 = tid * CH;
-        int mine = 0, big = 0;
-        for (int k = 0; k < CH; ++k) if (r0 + k < npx) { mine += cnt[r0 + k]; big = max(big, cnt[r0 + k]); }
-        int incl = mine;
-#pragma unroll
-        for (int o = 1; o < kWave; o <<= 1) { const int y = __shfl_up(incl, o, kWave); if (lane >= o) incl += y; }
-#pragma unroll
-        for (int o = kWave / 2; o > 0; o >>= 1) big = max(big, __shfl_xor(big, o, kWave));
-        if (lane == kWave - 1) { wsum[wave] = incl; wsum[16 + wave] = big; }
-        __syncthreads();
-        int excl = incl - mine, total = 0, longest = 0;
-        {
-            const int4 wa = *reinterpret_cast<const int4 *>(wsum), wb = *reinterpret_cast<const int4 *>(wsum + 4);
-            const int ws[kSWaves] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
-#pragma unroll
-            for (int w2 = 0; w2 < kSWaves; ++w2) { if (w2 < wave) excl += ws[w2]; total += ws[w2]; }
-            const int4 ma = *reinterpret_cast<const int4 *>(wsum + 16), mb = *reinterpret_cast<const int4 *>(wsum + 20);
-            longest = max(max(max(ma.x, ma.y), max(ma.z, ma.w)), max(max(mb.x, mb.y), max(mb.z, mb.w)));
-        }
-        for (int k = 0; k < CH; ++k) if (r0 + k < npx) { start[r0 + k] = excl; excl += cnt[r0 + k]; }
-        __syncthreads();
-        MSDA_STAMP(3);
-        // ---- 3. counting sort: each tap's record goes to start[row] + rank ----
-#pragma unroll
-        for (int k = 0; k < PPT; ++k)
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-                if (dest[k][t] >= 0) { SRec r; r.w = tw[k][t]; r.q = qq[k]; rec[start[dest[k][t]] + rank[k][t]] = r; }
-        __syncthreads();
-        MSDA_STAMP(4);
-        // ---- 4. gather; lanes per row chosen from the mean segment length (uniform) ----
-        // rows of comparable length (the longest no more than one lane group's share): the balanced walk
-        if (ACC != kAccTile && longest * 64 <= max(total, 1024)) {
-            gather_balanced<VT, GT, false, false>(go_base, gv_base, cnt, start, rec, reinterpret_cast<int *>(ovf), npx, row_stride,
-                                                  total, ACC == kAccNone || first);
-            if (ACC != kAccNone) __syncthreads();
-            MSDA_STAMP(5);
-            continue;
-        }
-        const int mean2 = (2 * total) / npx;                                  // 2 x mean records per row
-        if (mean2 <= 8)       gather_rows<1, ACC, VT, GT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
-        else if (mean2 <= 16) gather_rows<2, ACC, VT, GT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
-        else if (mean2 <= 32) gather_rows<4, ACC, VT, GT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
-        else                  gather_rows<8, ACC, VT, GT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
-        if (ACC != kAccNone) __syncthreads();                // next pass reuses the LDS arrays / re-reads rows
-        MSDA_STAMP(5);
-    }
-
-    if (ACC == kAccTile) {
-        // ---- flush the LDS tile: each row once, coalesced ----
-        for (int i = tid; i < npx * 8; i += kSBlock) {
-            const int d = i >> 3, jj = i & 7;
-            const float4 v = NP > 0 ? reinterpret_cast<const float4 *>(tile)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-            Row<GT>::store(grad_value + ((long long)(b * S + lstart + px0 + d) * M + m) * kD + jj * 4, v);
-        }
-    }
-}
-
-
-// ---- kAccWide: single pass by KEPT taps ----------------------------------------------------------------------
-// The chunked passes above size a pass by the points it SCANS (4 records per point), although a workgroup that
-// owns 1/W of a level keeps ~1/W of them: cfg-2 encoder took 8 passes of 1536 points, each a chain of five
-// barrier-separated phases that kept ~770 records (profiles/r02_notes.md §10).  Here a workgroup
-//   1. scans ALL Lq*P points of its (batch, head, level) once: histogram of the taps that land on its rows
-//      (LDS integer atomics, no return value) and a compact list of the points that have such a tap
-//      (wavefront ballot + one LDS atomic per wavefront);
-//   2. prefix-sums the histogram;
-//   3. revisits only the listed points (~1/W of them), recomputes their taps and drops the records into the
-//      rows' segments (the prefix array is the cursor: it ends up holding segment ENDS);
-//   4. gathers as before and stores every row once.
-// If the kept taps exceed the record array or the list (locations piled on this workgroup's rows), it starts
-// over in chunks of kWideChunk points — whose taps always fit — accumulating like kAccRmw.
-constexpr int kWideRecCap = 7168;                   // records (56 KB)
-constexpr int kWideListCap = kWideRecCap;           // listed points (14 KB of 16-bit chunk-relative indices): a listed
-                                                    // point has at least one tap here, so the records overflow first
-constexpr int kWideMaxStep = 65536;                 // points per attempt (what a 16-bit list entry can address)
-constexpr int kWideChunk = kWideRecCap / 4;         // points per fallback pass
-template <typename VT, typename GT>
-__device__ __forceinline__ void bwd_value_wide_body(
-    const VT *__restrict__ grad_out, const int64_t *__restrict__ shapes,
-    const int64_t *__restrict__ level_start, const float *__restrict__ loc,
-    const float *__restrict__ attn, int S, int M, int L, int Lq, int P, int p_shift, int tp_cap,
-    GT *__restrict__ grad_value, int ti, int W, int l, int pr, unsigned char *smem)
-{
-    // LDS: [cnt tp_cap] [start tp_cap] [wsum 32] [list kWideListCap x u16] [rec kWideRecCap]
-    int *cnt = reinterpret_cast<int *>(smem);
-    int *start = cnt + tp_cap;
-    int *wsum = start + tp_cap;
-    uint16_t *list = reinterpret_cast<uint16_t *>(wsum + 32);             // wsum[16..23]: per-wavefront longest row
-    SRec *rec = reinterpret_cast<SRec *>(list + kWideListCap);
-    int *kept_p = wsum + 8;                                  // wsum[0..7]: per-wavefront sums of the prefix scan
-
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    MSDA_STAMP(0);
-    const int H = (int)shapes[2 * l], Wd = (int)shapes[2 * l + 1], lstart = (int)level_start[l];
-    const int HW = H * Wd;
-    const int px0 = (int)((unsigned)(ti * HW) / (unsigned)W), px1 = (int)((unsigned)((ti + 1) * HW) / (unsigned)W);
-    const int npx = px1 - px0;
-    const int b = pr / M, m = pr - b * M;
-    if (l == 0 && ti == 0) {                                 // pixels past the last level that fits: see bwd_value_body
-        long long cover = 0;
-        for (int k = 0; k < L; ++k)
-            if (level_fits(shapes[2 * k], shapes[2 * k + 1], level_start[k], S))
-                cover = max(cover, (long long)level_start[k] + shapes[2 * k] * shapes[2 * k + 1]);
-        for (int i = threadIdx.x; i < (S - (int)cover) * 8; i += kSBlock)
-            Row<GT>::store(grad_value + ((long long)(b * S + (int)cover + (i >> 3)) * M + m) * kD + (i & 7) * 4,
-                           make_float4(0.f, 0.f, 0.f, 0.f));
-    }
-    if (npx <= 0 || npx > tp_cap || !level_fits(shapes[2 * l], shapes[2 * l + 1], level_start[l], S)) return;
-    const int NP = Lq * P;
-    const long long item_base = (long long)b * Lq * M + m;
-    const int row_stride = M * kD;
-    const VT *go_base = grad_out + item_base * kD + (lane & 7) * 4;
-    GT *gv_base = grad_value + ((long long)(b * S + lstart + px0) * M + m) * kD + (lane & 7) * 4;
-    const float2 *loc2 = reinterpret_cast<const float2 *>(loc);
-    // Everything below is written for INSTRUCTION COUNT: a CU issues about one wavefront instruction per clock
-    // (4 SIMDs x 4 cycles per wave64 op; 32-bit integer multiplies take four times that), and the first version of
-    // this scan — 64-bit index arithmetic and the full tap geometry for every point — spent 18 us on 12 240 points.
-    // 32-bit indices throughout: d32_supported() bounds N*Lq*M*L*P*2 and N*S*M*D below 2^31 and S below 2^19.
-    const int MLP = M * L * P;
-    const unsigned off0 = (unsigned)((item_base * L + l) * P);                 // float2 index of (b, q = 0, m, l, p = 0)
-    const float Hf = (float)H, Wf = (float)Wd, px0f = (float)px0, npxf = (float)npx;
-
-    // range-local destinations of a point's four taps (-1: outside the map or not one of this workgroup's rows)
-    auto taps_of = [&](const float2 xy, int (&dest)[4], PointGeom<float> &g) {
-        g = point_geom<float>(xy.x, xy.y, H, Wd);
-        const int pix = g.h0 * Wd + g.w0 - px0;
-        const int p01 = pix + 1, p10 = pix + Wd, p11 = pix + Wd + 1;
-        dest[0] = (g.ok00 && pix >= 0 && pix < npx) ? pix : -1;
-        dest[1] = (g.ok01 && p01 >= 0 && p01 < npx) ? p01 : -1;
-        dest[2] = (g.ok10 && p10 >= 0 && p10 < npx) ? p10 : -1;
-        dest[3] = (g.ok11 && p11 >= 0 && p11 < npx) ? p11 : -1;
-    };
-    // float2 index of point idx = q*P + p, and q
-    auto point_of = [&](int idx, int &q) -> unsigned {
-        q = fdiv(idx, P, p_shift);
-        return off0 + (unsigned)(q * MLP + (idx - q * P));
-    };
-
-    // steps 1-2 for the points [p0, p1); returns the number of kept taps
-    auto count_points = [&](int p0, int p1) -> int {
-        for (int i = tid; i < npx; i += kSBlock) cnt[i] = 0;
-        if (tid == 0) *kept_p = 0;
-        __syncthreads();
-        // 1a. the points that MAY have a tap on this workgroup's rows -> list.  No histogram yet (an LDS atomic costs
-        // ~30 cycles per wavefront instruction however few lanes take part, and here ~1/W of them would); the test is
-        // a superset — inside the map and one of the two tap pairs meets [0, npx) — in float arithmetic (exact: S < 2^24);
-        // the exact taps are worked out for the listed points only.  The thread's point index advances by 512 per
-        // step: (q, p) and the address follow by additions.
-        constexpr int U = 9;                        // loads in flight per thread (4180 points = ONE trip); 10 crosses 128 VGPRs
-        const int dq = fdiv(kSBlock, P, p_shift), dp = kSBlock - dq * P;        // 512 = dq*P + dp (uniform)
-        const int doff = dq * MLP + dp, wrap = MLP - P;
-        int q0;
-        unsigned off = point_of(p0 + tid, q0);
-        int p = p0 + tid - q0 * P;
-        for (int base = p0; base < p1; base += kSBlock * U) {
-            float2 xy[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                xy[u] = make_float2(-8.f, -8.f);                                // outside every map
-                if (base + u * kSBlock + tid < p1) xy[u] = loc2[off];
-                p += dp; off += doff;
-                if (p >= P) { p -= P; off += wrap; }
-            }
-            unsigned long long mask[U];
-            int n = 0;
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                mask[u] = 0;
-                if (base + u * kSBlock >= p1) continue;                         // uniform: no point in this slot
-                const float h_im = xy[u].y * Hf - 0.5f, w_im = xy[u].x * Wf - 0.5f;
-                const float pixf = fmaf(floorf(h_im), Wf, floorf(w_im)) - px0f;  // tap (h0, w0), range-local
-                // taps sit at pix, pix + 1 and pix + W, pix + W + 1 (border validity ignored: a superset)
-                const bool keep = h_im > -1.f && w_im > -1.f && h_im < Hf && w_im < Wf &&
-                                  ((pixf + 1.f >= 0.f && pixf < npxf) || (pixf + Wf + 1.f >= 0.f && pixf + Wf < npxf));
-                mask[u] = __ballot(keep);
-                n += __popcll(mask[u]);
-            }
-            if (n == 0) continue;                                               // uniform
-            int wbase = 0;
-            if (lane == 0) wbase = atomicAdd(kept_p, n);
-            wbase = __shfl(wbase, 0, kWave);
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int pos = wbase + __popcll(mask[u] & ((1ull << lane) - 1ull));
-                if (((mask[u] >> lane) & 1ull) && pos < kWideListCap) list[pos] = (uint16_t)(base - p0 + u * kSBlock + tid);
-                wbase += __popcll(mask[u]);
-            }
-        }
-        __syncthreads();
-        MSDA_STAMP(1);
-        // 1b. histogram of the listed points' taps (dense lanes: ~4 atomics per 64 listed points)
-        {
-            const int kept = min(*kept_p, kWideListCap);
-            // up to 8 loads in flight per thread (a coarse level lists several thousand points); the slots past the
-            // list's end are skipped as a whole (uniform test)
-            constexpr int UH = 8;
-            for (int base = 0; base < kept; base += kSBlock * UH) {
-                float2 xy[UH];
-#pragma unroll
-                for (int u = 0; u < UH; ++u) {
-                    const int i = base + u * kSBlock + tid;
-                    xy[u] = make_float2(-8.f, -8.f);
-                    if (i < kept) { int q; xy[u] = loc2[point_of(p0 + list[i], q)]; }
-                }
-#pragma unroll
-                for (int u = 0; u < UH; ++u) {
-                    if (base + u * kSBlock >= kept) break;
-                    int dest[4]; PointGeom<float> g;
-                    taps_of(xy[u], dest, g);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) if (dest[t] >= 0) atomicAdd(&cnt[dest[t]], 1);
-                }
-            }
-        }
-        __syncthreads();
-        MSDA_STAMP(2);
-        // exclusive prefix sum over the rows (512 threads x CH consecutive rows)
-        const int CH = (npx + kSBlock - 1) / kSBlock;
-        const int r0 = tid * CH;
-        int mine = 0, big = 0;
-        for (int k = 0; k < CH; ++k) if (r0 + k < npx) { mine += cnt[r0 + k]; big = max(big, cnt[r0 + k]); }
-        int incl = mine;
-#pragma unroll
-        for (int o = 1; o < kWave; o <<= 1) { const int y = __shfl_up(incl, o, kWave); if (lane >= o) incl += y; }
-#pragma unroll
-        for (int o = kWave / 2; o > 0; o >>= 1) big = max(big, __shfl_xor(big, o, kWave));
-        if (lane == kWave - 1) { wsum[wave] = incl; wsum[16 + wave] = big; }
-        __syncthreads();
-        int excl = incl - mine, total = 0;
-        {
-            const int4 wa = *reinterpret_cast<const int4 *>(wsum), wb = *reinterpret_cast<const int4 *>(wsum + 4);
-            const int ws[kSWaves] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
-#pragma unroll
-            for (int w2 = 0; w2 < kSWaves; ++w2) { if (w2 < wave) excl += ws[w2]; total += ws[w2]; }
-        }
-        for (int k = 0; k < CH; ++k) if (r0 + k < npx) { start[r0 + k] = excl; excl += cnt[r0 + k]; }
-        __syncthreads();
-        MSDA_STAMP(3);
-        return total;
-    };
-    auto longest_row = [&]() {
-        const int4 wa = *reinterpret_cast<const int4 *>(wsum + 16), wb = *reinterpret_cast<const int4 *>(wsum + 20);
-        return max(max(max(wa.x, wa.y), max(wa.z, wa.w)), max(max(wb.x, wb.y), max(wb.z, wb.w)));
-    };
-
-    // steps 3-4 for the listed points.  A record holds the ELEMENT offset of its grad_out row (q * row_stride).
-    auto scatter_and_gather = [&](int p0, int total, bool first) {
-        const int kept = *kept_p;
-        constexpr int U = 8;
-        for (int base = 0; base < kept; base += kSBlock * U) {
-            float2 xy[U]; float at[U]; int qq[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int i = base + u * kSBlock + tid;
-                xy[u] = make_float2(-8.f, -8.f); at[u] = 0.f; qq[u] = 0;
-                if (i < kept) {
-                    const unsigned pi = point_of(p0 + list[i], qq[u]);
-                    xy[u] = loc2[pi]; at[u] = attn[pi];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (base + u * kSBlock >= kept) break;                           // uniform
-                int dest[4]; PointGeom<float> g;
-                taps_of(xy[u], dest, g);
-                const float hh = 1.f - g.lh, hw = 1.f - g.lw;
-                const float tw[4] = {hh * hw * at[u], hh * g.lw * at[u], g.lh * hw * at[u], g.lh * g.lw * at[u]};
-                const int qoff = qq[u] * row_stride;
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    if (dest[t] >= 0) { SRec r; r.w = tw[t]; r.q = qoff; rec[atomicAdd(&start[dest[t]], 1)] = r; }
-            }
-        }
-        __syncthreads();
-        MSDA_STAMP(4);
-        // rows of comparable length (the longest no more than one lane group's share): the balanced walk
-        if (longest_row() * 64 <= max(total, 1024)) {
-            gather_balanced<VT, GT, true, true>(go_base, gv_base, cnt, start, rec, reinterpret_cast<int *>(list), npx, row_stride, total, first);
-            MSDA_STAMP(5);
-            return;
-        }
-        // rows of very different lengths (coarse levels): equal stretches of records, parts combined by the row's owner.
-        // (Measured against it: the split gather for every row mix — same at cfg-2 / cfg-4 encoder, but on the single-pass
-        // path 784 six-record rows cost 19.5 instead of 14.5 us; gather_rows here: 20.2 instead of 11.3 us per workgroup.)
-        gather_split<VT, GT, true, true>(go_base, gv_base, cnt, start, rec, reinterpret_cast<float4 *>(list), npx, row_stride, total, first);
-        MSDA_STAMP(5);
-    };
-
-    // All points at once; if this workgroup's rows receive more taps than the record array holds, a chunk sized
-    // from the count just taken (7/8 full if the points spread evenly), halved while it still does not fit.
-    // A chunk of kWideChunk points always fits (4 taps per point), so the loop ends.
-    int a = 0, step = min(NP, kWideMaxStep);
-    bool first = true;
-    while (a < NP) {
-        const int a1 = min(NP, a + step);
-        __syncthreads();                                     // the previous attempt / gather still reads the LDS arrays
-        const int t = count_points(a, a1);
-        if (t > kWideRecCap || *kept_p > kWideListCap) {     // uniform: LDS values read after a barrier
-            const long long even = (long long)(a1 - a) * (kWideRecCap - kWideRecCap / 8) / max(t, 1);
-            step = max(kWideChunk, (int)min(even, (long long)(a1 - a) / 2));
-            continue;
-        }
-        scatter_and_gather(a, t, first);
-        first = false;
-        a = a1;
-    }
-}
-
-
-// Role-B workgroup id -> (pair, level, range, ranges of that level).  A (batch, head) pair has W*L workgroups.
-// They are dealt W per level, except that on a pyramid (the level with the most pixels has >= 4x the pixels
-// of the one with the fewest; W >= 2) the largest level takes one range from the smallest: every level
-// receives the same number of taps, but a fine level's gather also walks 4-64x more rows, and the launch ends
-// with its slowest workgroup (cfg-2 decoder: level 0 gather 5.9 us vs 3.6 us for level 3 with W = 4 each).
-// Uniform (scalar) arithmetic; the shapes come from the scalar cache.
-__device__ __forceinline__ void value_block_to_range(int bid, int W, int L, const int64_t *__restrict__ shapes,
-                                                     int &pr, int &l, int &ti, int &Wl, bool may_skew = true)
-{
-    const int T = W * L;
-    pr = bid / T;
-    const int s = bid - pr * T;
-    int lmax = 0, lmin = 0;
-    long long rmax = shapes[0] * shapes[1], rmin = rmax;
-    for (int k = 1; k < L; ++k) {
-        const long long r = shapes[2 * k] * shapes[2 * k + 1];
-        if (r > rmax) { rmax = r; lmax = k; }
-        if (r <= rmin) { rmin = r; lmin = k; }
-    }
-    // (kAccWide deals W to every level: there the RECORDS a workgroup keeps are what must stay equal)
-    const bool skew = may_skew && L >= 2 && W >= 2 && lmax != lmin && rmax >= 4 * rmin;
-    int base = 0;
-    l = 0; ti = 0; Wl = W;
-    for (int k = 0; k < L; ++k) {
-        const int wk = W + (skew ? (int)(k == lmax) - (int)(k == lmin) : 0);
-        if (s < base + wk) { l = k; ti = s - base; Wl = wk; return; }
-        base += wk;
-    }
-}
+}  // namespace msda
+#include "msda_d32_value.h"      // role B, per-tap records: gathers, bwd_value_body, bwd_value_wide_body, value_block_to_range
+namespace msda {
 
 template <int ACC, int PPT, typename VT, typename GT = VT>
 __global__ __launch_bounds__(kSBlock) void bwd_value_d32_kernel(
