@@ -646,12 +646,16 @@ static ValuePlan plan_value(int N, int S, int M, int L, int Lq, int P, int targe
         // enough ranges per level that the taps a workgroup keeps (4*NP/W on average) fit its record array with
         // 15 % to spare, and at least as many workgroups as the chunked plan would launch
         static const int wide_wgs = env_int("MSDA_WIDE_WGS", 2);     // x target_wgs
-        const long long need = ((long long)4 * NP * 115 / 100 + kWideRecCap - 1) / kWideRecCap;
-        pl.W = max(max(ceil_div(S, kSingleMaxRows), ceil_div(wide_wgs * target_wgs, pairs_levels)), (int)min(need, (long long)S));
-        pl.W = max(1, min(pl.W, max(1, S / 16)));
-        pl.tp_cap = (ceil_div(S, pl.W) + 3) & ~3;
+        const int w_max = max(1, S / 16);
+        pl.W = max(1, min(max(ceil_div(S, kSingleMaxRows), ceil_div(wide_wgs * target_wgs, pairs_levels)), w_max));
+        for (;; ++pl.W) {                                            // the record capacity depends on the rows per range
+            pl.tp_cap = (ceil_div(S, pl.W) + 3) & ~3;
+            int rec_cap, list_cap;
+            wide_caps(pl.tp_cap, NP, rec_cap, list_cap);
+            if (pl.W >= w_max || (long long)4 * NP * 115 / 100 <= (long long)rec_cap * pl.W) break;
+        }
         pl.ppt = kSinglePPT;
-        pl.lds = (2 * (size_t)pl.tp_cap + 32) * 4 + (size_t)kWideListCap * 2 + (size_t)kWideRecCap * sizeof(SRec);
+        pl.lds = (size_t)wide_lds_bytes(pl.tp_cap, NP);
         return pl;
     }
     if (pl.acc == kAccTile) {

@@ -166,11 +166,23 @@ __device__ __forceinline__ void gather_rows(const VT *__restrict__ go_base, GT *
 // index passes its end.  endv[r] = end of row r's segment (segments are contiguous: row r starts at endv[r - 1]).
 // For rows of comparable length; a row with thousands of records would leave most
 // lane groups idle, so the caller keeps gather_rows for those.
-// ENDS: start[r] is the END of row r's segment (kAccWide's scatter cursor), else its beginning; OFFS: a record's q is
-// already the element offset of its grad_out row (q * row_stride), not the query index.
-template <typename VT, typename GT, bool ENDS, bool OFFS>
+// How a gather reads record i: {weight, element offset of its grad_out row}.  RecAos: the 8-byte {weight, query}
+// records of the chunked / single-pass paths.  RecSoa (kAccWide): a float weight array and a 16-bit array of queries
+// relative to the chunk's first query — 6 bytes per record, so a third more records fit the same LDS and batch-heavy
+// shapes need fewer pixel ranges per level (cfg-4 encoder: 2 instead of 3, each range re-scans the level).
+struct RecAos {
+    const SRec *r; int stride;
+    __device__ __forceinline__ void get(int i, float &w, long long &off) const { const SRec e = r[i]; w = e.w; off = (long long)e.q * stride; }
+};
+struct RecSoa {
+    const float *w; const uint16_t *q; int qbase, stride;
+    __device__ __forceinline__ void get(int i, float &wt, long long &off) const { wt = w[i]; off = (long long)((qbase + (int)q[i]) * stride); }
+};
+
+// ENDS: start[r] is the END of row r's segment (kAccWide's scatter cursor), else its beginning.
+template <typename VT, typename GT, bool ENDS, typename RV>
 __device__ __forceinline__ void gather_balanced(const VT *__restrict__ go_base, GT *__restrict__ gv_base,
-                                                const int *cnt, const int *start, const SRec *rec, int *firsts, int npx,
+                                                const int *cnt, const int *start, const RV rec, int *firsts, int npx,
                                                 int row_stride, int total, bool first_pass)
 {
     constexpr int G = kSBlock / 8, CH = 8;
@@ -208,21 +220,21 @@ __device__ __forceinline__ void gather_balanced(const VT *__restrict__ go_base, 
         next_end = r + 1 < r_stop ? endv[r + 1] : 0x7fffffff;
     };
     for (; i + CH <= i_stop; i += CH) {
-        SRec e[CH]; float4 gl[CH];
+        float ew[CH]; long long eo[CH]; float4 gl[CH];
 #pragma unroll
-        for (int u = 0; u < CH; ++u) e[u] = rec[i + u];
+        for (int u = 0; u < CH; ++u) rec.get(i + u, ew[u], eo[u]);
 #pragma unroll
-        for (int u = 0; u < CH; ++u) gl[u] = Row<VT>::load(go_base + (OFFS ? (long long)e[u].q : (long long)e[u].q * row_stride));
+        for (int u = 0; u < CH; ++u) gl[u] = Row<VT>::load(go_base + eo[u]);
 #pragma unroll
-        for (int u = 0; u < CH; ++u) { while (i + u >= row_end) flush(); fma4(acc, e[u].w, gl[u]); }
+        for (int u = 0; u < CH; ++u) { while (i + u >= row_end) flush(); fma4(acc, ew[u], gl[u]); }
     }
     if (i < i_stop) {                                        // last, partial batch
-        SRec e[CH]; float4 gl[CH];
+        float ew[CH]; long long eo[CH]; float4 gl[CH];
 #pragma unroll
         for (int u = 0; u < CH; ++u)
-            if (i + u < i_stop) { e[u] = rec[i + u]; gl[u] = Row<VT>::load(go_base + (OFFS ? (long long)e[u].q : (long long)e[u].q * row_stride)); }
+            if (i + u < i_stop) { rec.get(i + u, ew[u], eo[u]); gl[u] = Row<VT>::load(go_base + eo[u]); }
 #pragma unroll
-        for (int u = 0; u < CH; ++u) if (i + u < i_stop) { while (i + u >= row_end) flush(); fma4(acc, e[u].w, gl[u]); }
+        for (int u = 0; u < CH; ++u) if (i + u < i_stop) { while (i + u >= row_end) flush(); fma4(acc, ew[u], gl[u]); }
     }
     while (r < r_stop) flush();                              // the row in progress and the empty rows after it
 }
@@ -235,9 +247,9 @@ __device__ __forceinline__ void gather_balanced(const VT *__restrict__ go_base, 
 // atomics.  Rows without records are stored as zeros up front.  gather_rows gives such rows one wavefront each
 // (five of eight busy, 8 slots x 4 loads in flight): gather of a workgroup of cfg-2 encoder's 6x6 level 20.2 -> 11.3 us,
 // cfg-4 encoder backward 301 -> 272 us (half its workgroups belong to coarse levels); profiles/r02_notes.md §10.
-template <typename VT, typename GT, bool ENDS, bool OFFS>
+template <typename VT, typename GT, bool ENDS, typename RV>
 __device__ __forceinline__ void gather_split(const VT *__restrict__ go_base, GT *__restrict__ gv_base, const int *cnt,
-                                             const int *start, const SRec *rec, float4 *part, int npx, int row_stride,
+                                             const int *start, const RV rec, float4 *part, int npx, int row_stride,
                                              int total, bool first_pass)
 {
     constexpr int G = kSBlock / 8, CH = 8;
@@ -268,21 +280,21 @@ __device__ __forceinline__ void gather_split(const VT *__restrict__ go_base, GT 
         };
         int i = lo;
         for (; i + CH <= hi; i += CH) {
-            SRec e[CH]; float4 gl[CH];
+            float ew[CH]; long long eo[CH]; float4 gl[CH];
 #pragma unroll
-            for (int u = 0; u < CH; ++u) e[u] = rec[i + u];
+            for (int u = 0; u < CH; ++u) rec.get(i + u, ew[u], eo[u]);
 #pragma unroll
-            for (int u = 0; u < CH; ++u) gl[u] = Row<VT>::load(go_base + (OFFS ? (long long)e[u].q : (long long)e[u].q * row_stride));
+            for (int u = 0; u < CH; ++u) gl[u] = Row<VT>::load(go_base + eo[u]);
 #pragma unroll
-            for (int u = 0; u < CH; ++u) { if (i + u >= row_end) close_row(); fma4(acc, e[u].w, gl[u]); }
+            for (int u = 0; u < CH; ++u) { if (i + u >= row_end) close_row(); fma4(acc, ew[u], gl[u]); }
         }
         if (i < hi) {
-            SRec e[CH]; float4 gl[CH];
+            float ew[CH]; long long eo[CH]; float4 gl[CH];
 #pragma unroll
             for (int u = 0; u < CH; ++u)
-                if (i + u < hi) { e[u] = rec[i + u]; gl[u] = Row<VT>::load(go_base + (OFFS ? (long long)e[u].q : (long long)e[u].q * row_stride)); }
+                if (i + u < hi) { rec.get(i + u, ew[u], eo[u]); gl[u] = Row<VT>::load(go_base + eo[u]); }
 #pragma unroll
-            for (int u = 0; u < CH; ++u) if (i + u < hi) { if (i + u >= row_end) close_row(); fma4(acc, e[u].w, gl[u]); }
+            for (int u = 0; u < CH; ++u) if (i + u < hi) { if (i + u >= row_end) close_row(); fma4(acc, ew[u], gl[u]); }
         }
         // the row in progress: complete if it ends with the stretch, else it runs on into later stretches
         if (row_end <= hi) close_row();
@@ -485,8 +497,8 @@ __device__ __forceinline__ void bwd_value_body(
         // ---- 4. gather; lanes per row chosen from the mean segment length (uniform) ----
         // rows of comparable length (the longest no more than one lane group's share): the balanced walk
         if (ACC != kAccTile && longest * 64 <= max(total, 1024)) {
-            gather_balanced<VT, GT, false, false>(go_base, gv_base, cnt, start, rec, reinterpret_cast<int *>(ovf), npx, row_stride,
-                                                  total, ACC == kAccNone || first);
+            gather_balanced<VT, GT, false>(go_base, gv_base, cnt, start, RecAos{rec, row_stride}, reinterpret_cast<int *>(ovf), npx,
+                                           row_stride, total, ACC == kAccNone || first);
             if (ACC != kAccNone) __syncthreads();
             MSDA_STAMP(5);
             continue;
@@ -523,12 +535,29 @@ __device__ __forceinline__ void bwd_value_body(
 //      rows' segments (the prefix array is the cursor: it ends up holding segment ENDS);
 //   4. gathers as before and stores every row once.
 // If the kept taps exceed the record array or the list (locations piled on this workgroup's rows), it starts
-// over in chunks of kWideChunk points — whose taps always fit — accumulating like kAccRmw.
-constexpr int kWideRecCap = 7168;                   // records (56 KB)
-constexpr int kWideListCap = kWideRecCap;           // listed points (14 KB of 16-bit chunk-relative indices): a listed
-                                                    // point has at least one tap here, so the records overflow first
-constexpr int kWideMaxStep = 65536;                 // points per attempt (what a 16-bit list entry can address)
-constexpr int kWideChunk = kWideRecCap / 4;         // points per fallback pass
+// over in chunks whose taps always fit, accumulating like kAccRmw.
+constexpr int kWideMaxStep = 65536;                 // points per attempt (what a 16-bit list entry / relative query can address)
+constexpr int kWideLdsBudget = 80 * 1024;           // two workgroups per CU
+// Capacities of a kAccWide workgroup, the same on the host (plan_value) and on the device: what is left of the LDS budget
+// after the row arrays goes to the list (16-bit entries, one per listed point; at least the 8 KB the gathers use as
+// scratch once the list is dead) and to the 6-byte records.
+__host__ __device__ inline void wide_caps(int tp_cap, int NP, int &rec_cap, int &list_cap)
+{
+    const int fixed = 8 * tp_cap + 128;                                       // cnt, start, wsum
+    int lc = ((NP < kWideMaxStep ? NP : kWideMaxStep) + 7) & ~7;
+    const int list_bytes = 2 * lc > 8192 ? 2 * lc : 8192;
+    int rc = (kWideLdsBudget - fixed - list_bytes) / 6;
+    if (lc > rc) { rc = (kWideLdsBudget - fixed) / 8; lc = rc; }              // a listed point has at least one record
+    rec_cap = rc & ~7;
+    list_cap = (lc < rec_cap ? lc : rec_cap) & ~7;
+}
+__host__ __device__ inline int wide_lds_bytes(int tp_cap, int NP)
+{
+    int rc, lc;
+    wide_caps(tp_cap, NP, rc, lc);
+    return 8 * tp_cap + 128 + (2 * lc > 8192 ? 2 * lc : 8192) + 6 * rc;
+}
+
 template <typename VT, typename GT>
 __device__ __forceinline__ void bwd_value_wide_body(
     const VT *__restrict__ grad_out, const int64_t *__restrict__ shapes,
@@ -536,12 +565,16 @@ __device__ __forceinline__ void bwd_value_wide_body(
     const float *__restrict__ attn, int S, int M, int L, int Lq, int P, int p_shift, int tp_cap,
     GT *__restrict__ grad_value, int ti, int W, int l, int pr, unsigned char *smem)
 {
-    // LDS: [cnt tp_cap] [start tp_cap] [wsum 32] [list kWideListCap x u16] [rec kWideRecCap]
+    // LDS: [cnt tp_cap] [start tp_cap] [wsum 32] [list: list_cap x u16, at least 8 KB] [weights rec_cap x f32] [queries rec_cap x u16]
+    int rec_cap, list_cap;
+    wide_caps(tp_cap, Lq * P, rec_cap, list_cap);
     int *cnt = reinterpret_cast<int *>(smem);
     int *start = cnt + tp_cap;
     int *wsum = start + tp_cap;
     uint16_t *list = reinterpret_cast<uint16_t *>(wsum + 32);             // wsum[16..23]: per-wavefront longest row
-    SRec *rec = reinterpret_cast<SRec *>(list + kWideListCap);
+    float *rw = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(list) + (2 * list_cap > 8192 ? 2 * list_cap : 8192));
+    uint16_t *rq = reinterpret_cast<uint16_t *>(rw + rec_cap);
+    const int wide_chunk = min(rec_cap / 4, list_cap);       // points whose taps and list entries always fit
     int *kept_p = wsum + 8;                                  // wsum[0..7]: per-wavefront sums of the prefix scan
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -637,7 +670,7 @@ __device__ __forceinline__ void bwd_value_wide_body(
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int pos = wbase + __popcll(mask[u] & ((1ull << lane) - 1ull));
-                if (((mask[u] >> lane) & 1ull) && pos < kWideListCap) list[pos] = (uint16_t)(base - p0 + u * kSBlock + tid);
+                if (((mask[u] >> lane) & 1ull) && pos < list_cap) list[pos] = (uint16_t)(base - p0 + u * kSBlock + tid);
                 wbase += __popcll(mask[u]);
             }
         }
@@ -645,7 +678,7 @@ __device__ __forceinline__ void bwd_value_wide_body(
         MSDA_STAMP(1);
         // 1b. histogram of the listed points' taps (dense lanes: ~4 atomics per 64 listed points)
         {
-            const int kept = min(*kept_p, kWideListCap);
+            const int kept = min(*kept_p, list_cap);
             // up to 8 loads in flight per thread (a coarse level lists several thousand points); the slots past the
             // list's end are skipped as a whole (uniform test)
             constexpr int UH = 8;
@@ -698,9 +731,10 @@ __device__ __forceinline__ void bwd_value_wide_body(
         return max(max(max(wa.x, wa.y), max(wa.z, wa.w)), max(max(wb.x, wb.y), max(wb.z, wb.w)));
     };
 
-    // steps 3-4 for the listed points.  A record holds the ELEMENT offset of its grad_out row (q * row_stride).
+    // steps 3-4 for the listed points.  A record = {weight, query relative to the chunk's first query (16 bits)}.
     auto scatter_and_gather = [&](int p0, int total, bool first) {
         const int kept = *kept_p;
+        const int qbase = fdiv(p0, P, p_shift);
         constexpr int U = 8;
         for (int base = 0; base < kept; base += kSBlock * U) {
             float2 xy[U]; float at[U]; int qq[U];
@@ -720,39 +754,41 @@ __device__ __forceinline__ void bwd_value_wide_body(
                 taps_of(xy[u], dest, g);
                 const float hh = 1.f - g.lh, hw = 1.f - g.lw;
                 const float tw[4] = {hh * hw * at[u], hh * g.lw * at[u], g.lh * hw * at[u], g.lh * g.lw * at[u]};
-                const int qoff = qq[u] * row_stride;
+                const uint16_t qrel = (uint16_t)(qq[u] - qbase);
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
-                    if (dest[t] >= 0) { SRec r; r.w = tw[t]; r.q = qoff; rec[atomicAdd(&start[dest[t]], 1)] = r; }
+                    if (dest[t] >= 0) { const int pos = atomicAdd(&start[dest[t]], 1); rw[pos] = tw[t]; rq[pos] = qrel; }
             }
         }
         __syncthreads();
         MSDA_STAMP(4);
         // rows of comparable length (the longest no more than one lane group's share): the balanced walk
         if (longest_row() * 64 <= max(total, 1024)) {
-            gather_balanced<VT, GT, true, true>(go_base, gv_base, cnt, start, rec, reinterpret_cast<int *>(list), npx, row_stride, total, first);
+            gather_balanced<VT, GT, true>(go_base, gv_base, cnt, start, RecSoa{rw, rq, qbase, row_stride}, reinterpret_cast<int *>(list), npx,
+                                          row_stride, total, first);
             MSDA_STAMP(5);
             return;
         }
         // rows of very different lengths (coarse levels): equal stretches of records, parts combined by the row's owner.
         // (Measured against it: the split gather for every row mix — same at cfg-2 / cfg-4 encoder, but on the single-pass
         // path 784 six-record rows cost 19.5 instead of 14.5 us; gather_rows here: 20.2 instead of 11.3 us per workgroup.)
-        gather_split<VT, GT, true, true>(go_base, gv_base, cnt, start, rec, reinterpret_cast<float4 *>(list), npx, row_stride, total, first);
+        gather_split<VT, GT, true>(go_base, gv_base, cnt, start, RecSoa{rw, rq, qbase, row_stride}, reinterpret_cast<float4 *>(list), npx,
+                                   row_stride, total, first);
         MSDA_STAMP(5);
     };
 
     // All points at once; if this workgroup's rows receive more taps than the record array holds, a chunk sized
     // from the count just taken (7/8 full if the points spread evenly), halved while it still does not fit.
-    // A chunk of kWideChunk points always fits (4 taps per point), so the loop ends.
+    // A chunk of wide_chunk points always fits (4 taps per point), so the loop ends.
     int a = 0, step = min(NP, kWideMaxStep);
     bool first = true;
     while (a < NP) {
         const int a1 = min(NP, a + step);
         __syncthreads();                                     // the previous attempt / gather still reads the LDS arrays
         const int t = count_points(a, a1);
-        if (t > kWideRecCap || *kept_p > kWideListCap) {     // uniform: LDS values read after a barrier
-            const long long even = (long long)(a1 - a) * (kWideRecCap - kWideRecCap / 8) / max(t, 1);
-            step = max(kWideChunk, (int)min(even, (long long)(a1 - a) / 2));
+        if (t > rec_cap || *kept_p > list_cap) {             // uniform: LDS values read after a barrier
+            const long long even = (long long)(a1 - a) * (rec_cap - rec_cap / 8) / max(t, 1);
+            step = max(wide_chunk, (int)min(even, (long long)(a1 - a) / 2));
             continue;
         }
         scatter_and_gather(a, t, first);
