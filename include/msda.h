@@ -144,7 +144,7 @@ int msda_backward_passes(int Lq, int P);
  * out-of-range access on this path: such a level contributes nothing and pixels no level covers get zeros.
  * The flag concerns the D = 32 kernel family (the models' shape); the generic family (any D, fp64) keeps its
  * global float atomics for grad_value and ignores it.
- * It costs 1.4-2x the default backward (profiles/r02_notes.md).  Replaces the same reference functions as
+ * It costs 1.5-2x the default backward (profiles/r02_notes.md).  Replaces the same reference functions as
  * msda_backward_*. */
 #define MSDA_FLAG_DETERMINISTIC 1u
 unsigned long long msda_backward_workspace_bytes(int N, int S, int M, int D, int L, int Lq, int P, unsigned flags);

@@ -644,8 +644,10 @@ static ValuePlan plan_value(int N, int S, int M, int L, int Lq, int P, int targe
     pl.acc = !multipass ? kAccNone : (sizeof(VT) == 4 ? (wide ? kAccWide : kAccRmw) : kAccTile);
     if (pl.acc == kAccWide) {
         // enough ranges per level that the taps a workgroup keeps (4*NP/W on average) fit its record array with
-        // 15 % to spare, and at least as many workgroups as the chunked plan would launch
-        static const int wide_wgs = env_int("MSDA_WIDE_WGS", 2);     // x target_wgs
+        // 15 % to spare, and at least one workgroup per CU.  No more than that: every range re-scans its level
+        // (cfg-2 encoder: 67 us with 6 ranges = 384 workgroups, 73 with 8 = 512, 84 with 12; role A's workgroups take
+        // the free slots from the start)
+        static const int wide_wgs = env_int("MSDA_WIDE_WGS", 1);     // x target_wgs
         const int w_max = max(1, S / 16);
         pl.W = max(1, min(max(ceil_div(S, kSingleMaxRows), ceil_div(wide_wgs * target_wgs, pairs_levels)), w_max));
         for (;; ++pl.W) {                                            // the record capacity depends on the rows per range
