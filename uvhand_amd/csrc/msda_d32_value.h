@@ -12,6 +12,10 @@
 //   value_block_to_range  workgroup id -> (pair, level, pixel range)
 #pragma once
 
+#ifndef MSDA_GATHER_NR1
+#define MSDA_GATHER_NR1 4        // gather_rows, fixed-capacity path: rows in flight when one lane group serves a row (A/B: 2)
+#endif
+
 namespace msda {
 
 // ------------------------------------------------------------------------------------------
@@ -80,13 +84,12 @@ __device__ __forceinline__ float4 shfl_xor4(const float4 &v, int m)
 }
 __device__ __forceinline__ void add4(float4 &a, const float4 &b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
 
-// Step 4.  SLOTS lane-groups of 8 lanes share one row's segment; 8/SLOTS rows per wavefront trip and
-// TWO trips' rows in flight (A and B).  A lane group takes CH records of each row at a time: the
-// record reads, then 2*CH independent 128-B row loads, then the FMAs — one memory round trip per
-// CH*SLOTS records of two rows.  (A balanced "linear" variant — the sorted records cut evenly over
-// the lane groups, partial row runs combined in a fix-up phase — was measured and is not faster:
-// its per-record run bookkeeping costs what the load imbalance costs here; profiles/r01_notes.md.)
-template <int SLOTS, int ACC, typename VT, typename GT>
+// Step 4, rows in lockstep.  SLOTS lane-groups of 8 lanes share one row's segment; 8/SLOTS rows per wavefront trip
+// and NR trips' rows in flight.  A lane group takes CH records of each of its NR rows at a time: the record reads,
+// then NR*CH = 8 independent 128-B row loads, then the FMAs — one memory round trip per CH*SLOTS records of NR rows.
+// (Used by the fixed-capacity sort, the LDS-tile passes and the single-pass path's coarse levels; gather_balanced /
+// gather_split below walk contiguous segments instead.)
+template <int SLOTS, int ACC, typename VT, typename GT, int NR1 = 2>
 __device__ __forceinline__ void gather_rows(const VT *__restrict__ go_base, GT *__restrict__ gv_base,
                                             const int *cnt, const int *start, const SRec *rec, float *tile,
                                             int npx, int row_stride, bool first_pass, int cap_shift = -1,
@@ -95,77 +98,88 @@ __device__ __forceinline__ void gather_rows(const VT *__restrict__ go_base, GT *
     // cap_shift >= 0: fixed-capacity segments (row d at d << cap_shift, at most 1 << cap_shift records there,
     // the rest of a fuller row in ovf[0, novf)); cap_shift < 0: segments from the prefix sum (start[])
     constexpr int DPW = 8 / SLOTS;
-    constexpr int CH = 4;
+    // rows in flight per lane group x records of each per trip: 8 loads either way.  NR1 (rows in flight when ONE lane
+    // group serves a row) is 4 on the fixed-capacity path: such rows hold a couple of records (cfg-2 decoder's 48x48
+    // level: 2), and four rows x 2 keeps the loads real — cfg-2 decoder backward 13.5 -> 13.2 us in kbench.  Elsewhere 2:
+    // the wider variant costs the other instantiations 7 VGPRs and cfg-4 decoder 2 us (tools/exp_nr.sh).
+    constexpr int NR = SLOTS == 1 ? NR1 : 2;
+    constexpr int CH = 8 / NR;
     constexpr int RSTEP = kSWaves * DPW;                     // rows per workgroup trip
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int dsub = lane / (SLOTS * 8), slot = (lane >> 3) % SLOTS, j = lane & 7;
-    for (int dA = wave * DPW + dsub; dA < npx; dA += 2 * RSTEP) {
-        const int dB = dA + RSTEP;
-        const bool hasB = dB < npx;
-        const int fullA = cnt[dA], fullB = hasB ? cnt[dB] : 0;
-        const int nA = cap_shift >= 0 ? min(fullA, 1 << cap_shift) : fullA;
-        const int nB = cap_shift >= 0 ? min(fullB, 1 << cap_shift) : fullB;
-        const SRec *rA = rec + (cap_shift >= 0 ? dA << cap_shift : start[dA]);
-        const SRec *rB = rec + (!hasB ? 0 : cap_shift >= 0 ? dB << cap_shift : start[dB]);
-        float4 accA = make_float4(0.f, 0.f, 0.f, 0.f), accB = accA;
-        const int nmax = max(nA, nB);
+    for (int d0 = wave * DPW + dsub; d0 < npx; d0 += NR * RSTEP) {
+        int full[NR], n[NR]; const SRec *rp[NR]; float4 acc[NR];
+        int nmax = 0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int d = d0 + r * RSTEP;
+            const bool has = d < npx;
+            full[r] = has ? cnt[d] : 0;
+            n[r] = cap_shift >= 0 ? min(full[r], 1 << cap_shift) : full[r];
+            rp[r] = rec + (!has ? 0 : cap_shift >= 0 ? d << cap_shift : start[d]);
+            acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+            nmax = max(nmax, n[r]);
+        }
         for (int i0 = slot; i0 < nmax; i0 += CH * SLOTS) {
-            SRec ra[CH], rb[CH]; float4 ga[CH], gb[CH];
+            SRec e[NR][CH]; float4 g[NR][CH];
 #pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                ra[u].w = 0.f; ra[u].q = -1; rb[u] = ra[u];
-                if (i0 + u * SLOTS < nA) ra[u] = rA[i0 + u * SLOTS];
-                if (i0 + u * SLOTS < nB) rb[u] = rB[i0 + u * SLOTS];
-            }
+            for (int r = 0; r < NR; ++r)
 #pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                const float4 ta = Row<VT>::load(go_base + (long long)max(ra[u].q, 0) * row_stride);
-                const float4 tb = Row<VT>::load(go_base + (long long)max(rb[u].q, 0) * row_stride);
-                const bool oa = ra[u].q >= 0, ob = rb[u].q >= 0;
-                ga[u] = make_float4(oa ? ta.x : 0.f, oa ? ta.y : 0.f, oa ? ta.z : 0.f, oa ? ta.w : 0.f);
-                gb[u] = make_float4(ob ? tb.x : 0.f, ob ? tb.y : 0.f, ob ? tb.z : 0.f, ob ? tb.w : 0.f);
-            }
+                for (int u = 0; u < CH; ++u) {
+                    e[r][u].w = 0.f; e[r][u].q = -1;
+                    if (i0 + u * SLOTS < n[r]) e[r][u] = rp[r][i0 + u * SLOTS];
+                }
 #pragma unroll
-            for (int u = 0; u < CH; ++u) { fma4(accA, ra[u].w, ga[u]); fma4(accB, rb[u].w, gb[u]); }
+            for (int r = 0; r < NR; ++r)
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    const float4 t = Row<VT>::load(go_base + (long long)max(e[r][u].q, 0) * row_stride);
+                    const bool ok = e[r][u].q >= 0;
+                    g[r][u] = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
+                }
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+#pragma unroll
+                for (int u = 0; u < CH; ++u) fma4(acc[r], e[r][u].w, g[r][u]);
         }
-        if (novf > 0 && (fullA > nA || fullB > nB)) {                  // rare: this lane group's row overflowed
-            for (int i = slot; i < novf; i += SLOTS) {
-                const SOvf e = ovf[i];
-                if (e.row == dA) fma4(accA, e.w, Row<VT>::load(go_base + (long long)e.q * row_stride));
-                else if (hasB && e.row == dB) fma4(accB, e.w, Row<VT>::load(go_base + (long long)e.q * row_stride));
+        if (novf > 0) {                                                 // rare: one of this lane group's rows overflowed
+            bool any = false;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) any = any || full[r] > n[r];
+            if (any) {
+                for (int i = slot; i < novf; i += SLOTS) {
+                    const SOvf o = ovf[i];
+#pragma unroll
+                    for (int r = 0; r < NR; ++r)
+                        if (o.row == d0 + r * RSTEP && d0 + r * RSTEP < npx)
+                            fma4(acc[r], o.w, Row<VT>::load(go_base + (long long)o.q * row_stride));
+                }
             }
         }
-        if (SLOTS >= 2) { add4(accA, shfl_xor4(accA, 8)); add4(accB, shfl_xor4(accB, 8)); }
-        if (SLOTS >= 4) { add4(accA, shfl_xor4(accA, 16)); add4(accB, shfl_xor4(accB, 16)); }
-        if (SLOTS >= 8) { add4(accA, shfl_xor4(accA, 32)); add4(accB, shfl_xor4(accB, 32)); }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            if (SLOTS >= 2) add4(acc[r], shfl_xor4(acc[r], 8));
+            if (SLOTS >= 4) add4(acc[r], shfl_xor4(acc[r], 16));
+            if (SLOTS >= 8) add4(acc[r], shfl_xor4(acc[r], 32));
+        }
         if (slot == 0) {
-            if (ACC == kAccTile) {
-                float4 *tA = reinterpret_cast<float4 *>(tile) + dA * 8 + j;
-                if (first_pass) *tA = accA; else { float4 o = *tA; add4(o, accA); *tA = o; }
-                if (hasB) {
-                    float4 *tB = reinterpret_cast<float4 *>(tile) + dB * 8 + j;
-                    if (first_pass) *tB = accB; else { float4 o = *tB; add4(o, accB); *tB = o; }
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int d = d0 + r * RSTEP;
+                if (d >= npx) continue;
+                if (ACC == kAccTile) {
+                    float4 *t = reinterpret_cast<float4 *>(tile) + d * 8 + j;
+                    if (first_pass) *t = acc[r]; else { float4 o = *t; add4(o, acc[r]); *t = o; }
+                } else {
+                    GT *pr = gv_base + (long long)d * row_stride;
+                    if (ACC == kAccRmw && !first_pass) add4(acc[r], Row<GT>::load(pr));
+                    Row<GT>::store(pr, acc[r]);
                 }
-            } else {
-                GT *pA = gv_base + (long long)dA * row_stride, *pB = gv_base + (long long)dB * row_stride;
-                if (ACC == kAccRmw && !first_pass) {
-                    add4(accA, Row<GT>::load(pA));
-                    if (hasB) add4(accB, Row<GT>::load(pB));
-                }
-                Row<GT>::store(pA, accA);
-                if (hasB) Row<GT>::store(pB, accB);
             }
         }
     }
 }
 
-// Step 4, balanced (every prefix-sum path): the SORTED record array is cut into 64 stretches of equal weight, one per
-// lane group, at row boundaries (a row's records stay with one lane group: rows are stored once, no combining).  A lane group
-// walks its stretch eight records at a time — every load is a real record, where gather_rows pads a row's last
-// trip (21-record rows on 8 slots x 4: a third of the loads and FMAs) — and stores a row whenever the running
-// index passes its end.  endv[r] = end of row r's segment (segments are contiguous: row r starts at endv[r - 1]).
-// For rows of comparable length; a row with thousands of records would leave most
-// lane groups idle, so the caller keeps gather_rows for those.
 // How a gather reads record i: {weight, element offset of its grad_out row}.  RecAos: the 8-byte {weight, query}
 // records of the chunked / single-pass paths.  RecSoa (kAccWide): a float weight array and a 16-bit array of queries
 // relative to the chunk's first query — 6 bytes per record, so a third more records fit the same LDS and batch-heavy
@@ -442,7 +456,7 @@ __device__ __forceinline__ void bwd_value_body(
             if (novf <= kOvfCap) {
                 MSDA_STAMP(2); MSDA_STAMP(3); MSDA_STAMP(4);
                 const int mean2f = (2 * *total_p) / npx;
-                if (mean2f <= 8)       gather_rows<1, ACC, VT, GT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first, cap_shift, ovf, novf);
+                if (mean2f <= 8)       gather_rows<1, ACC, VT, GT, MSDA_GATHER_NR1>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first, cap_shift, ovf, novf);
                 else if (mean2f <= 16) gather_rows<2, ACC, VT, GT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first, cap_shift, ovf, novf);
                 else if (mean2f <= 32) gather_rows<4, ACC, VT, GT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first, cap_shift, ovf, novf);
                 else                   gather_rows<8, ACC, VT, GT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first, cap_shift, ovf, novf);
