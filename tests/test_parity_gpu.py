@@ -275,11 +275,13 @@ PILED = {"cfg2_decoder": (2, [(48, 48), (24, 24), (12, 12), (6, 6)], 8, 32, 300,
          "long_encoder": (1, [(40, 40), (20, 20), (10, 10), (5, 5)], 8, 32, 2125, 4),
          # Lq*P = 68 000 > 65 536: more than one attempt (16-bit chunk-relative list) and far more taps per workgroup than
          # its record array holds at any spread (9 ranges where 43 would be needed): the count-sized chunks
-         "beyond_16bit": (1, [(12, 12)], 2, 32, 17000, 4)}
+         "beyond_16bit": (1, [(12, 12)], 2, 32, 17000, 4),
+         # P and L*P not powers of two on the kept-taps path (the scan's incremental (q, p) arithmetic, general division)
+         "odd_points": (1, [(20, 20), (10, 10), (5, 5)], 4, 32, 700, 3)}
 
 
 @pytest.mark.parametrize("geometry", list(PILED))
-@pytest.mark.parametrize("spread", [0.0, 0.02, 0.2, 0.6])
+@pytest.mark.parametrize("spread", [0.0, 0.02, 0.2, 0.6, 1.4])
 def test_taps_piled_on_few_pixels(native, oracle, spread, geometry):
     """grad_value's counting sort with every sampling point inside a small patch (collisions: thousands of
     taps on one pixel, most rows of the map empty); compared with the C oracle."""
