@@ -4,7 +4,7 @@ set -u
 cd $GRAFT_REPO_ROOT
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -DMSDA_STAMPS -DMSDA_TUNING ${EXTRA:-} -Iinclude -Iuvhand_amd/csrc tools/micro/kbench.cpp -o /tmp/kbench_x 2>&1 | grep error
 for w in ${WORKLOADS:-c2e c4e}; do
-  kw=8; [ $w = c4e ] && kw=2
+  kw=6; [ $w = c4e ] && kw=2     # ranges per level the plan picks (plan_value)
   for wide in 1 0; do
     echo "== $w wide=$wide fused"; MSDA_BWD_WIDE=$wide /tmp/kbench_x $w 50 2>&1 | grep -E "bwd:"
     echo "== $w wide=$wide split"
