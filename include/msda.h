@@ -40,8 +40,8 @@
  * them on the host side, ms_deform_attn_cuda.cu:54,121-123).
  *
  * Ownership: the library allocates nothing and frees nothing, reads no environment
- * variable, and keeps no global mutable state except a thread-local error string
- * and the test hook msda_force_path().  It never synchronises the
+ * variable, and keeps no process-wide mutable state: the error string and the test
+ * hook msda_force_path() are per thread.  It never synchronises the
  * device: all work (including the zero-fill of grad_value where a kernel needs
  * it) is enqueued on `stream` (a hipStream_t; NULL = the default stream).
  * Re-entrant: forward and backward may be called concurrently from different
@@ -279,12 +279,15 @@ unsigned long long msda_unflatten_workspace_bytes(int L, const int *heights, con
 
 const char *msda_last_error(void);
 
-/* Library/ABI version (major*100 + minor) and the kernel family a geometry maps to. */
+/* Library/ABI version (major*100 + minor) and the kernel family a geometry maps to.  MSDA_ABI_VERSION is what a binding
+ * compiled against THIS header expects msda_version() to return at run time (uvhand_amd/_ext.py compares the two);
+ * it changes whenever a declaration in this file does. */
+#define MSDA_ABI_VERSION 110
 int msda_version(void);
 int msda_path_for(int elem_bytes, int M, int D, int L, int P);
 
-/* Testing/benchmark knob: force the kernel family (-1 = automatic, default).
- * Process-wide; not meant for production callers. */
+/* Test hook: force the kernel family for the CALLING THREAD's subsequent calls (-1 = automatic, default; MSDA_PATH_GENERIC).
+ * Thread-local, so no caller can change the kernels under another thread's launch; not meant for production callers. */
 void msda_force_path(int path);
 
 #ifdef __cplusplus

@@ -158,6 +158,30 @@ def test_inconsistent_shapes_are_memory_safe(native):
     assert torch.count_nonzero(gv2[:, 40:]) == 0
 
 
+@pytest.mark.parametrize("deterministic", [False, True])
+@pytest.mark.parametrize("Lq", [40, 700])                                     # single pass / kept-taps pass of the default kernels
+def test_rows_no_level_covers_are_zero_wherever_they_lie(native, deterministic, Lq):
+    """Gaps BEFORE and BETWEEN the levels (level_start[0] > 0, a middle level that does not fit) — not only a trailing one —
+    get zeros from both role-B generations; grad_value comes from torch.empty, so anything unwritten would show."""
+    z = make_case(5, 1, [(6, 6), (3, 3), (2, 2)], 8, 32, Lq, 4)
+    S = z["value"].shape[1]                                                    # 49
+    # [3, 39, 48]: 3 uncovered rows in front, the last level (4 pixels at 48) runs past S -> dropped, row 48 uncovered;
+    # [0, 47, 45]: the MIDDLE level (9 pixels at 47) does not fit -> rows 36..44 uncovered, the last level sits at 45..48
+    for lsi in ([3, 39, 48], [0, S - 2, 45]):
+        bad = dict(z)
+        bad["level_start"] = np.asarray(lsi, dtype=np.int64)
+        for _ in range(2):                                                     # the allocator hands back dirty blocks
+            torch.full((2, S, 8, 32), float("nan"), device="cuda")
+        gv, gl, ga = _backward(native, bad, deterministic=deterministic)
+        assert torch.isfinite(gv).all() and torch.isfinite(gl).all() and torch.isfinite(ga).all()
+        covered = torch.zeros(S, dtype=torch.bool)
+        for (h, w), st in zip([(6, 6), (3, 3), (2, 2)], lsi):
+            if st + h * w <= S:
+                covered[st:st + h * w] = True
+        assert torch.count_nonzero(gv[:, ~covered.cuda()]) == 0
+        assert gv[:, covered.cuda()].abs().sum() > 0
+
+
 @pytest.mark.parametrize("M,Lq,shapes", [(8, 37, [(12, 12), (6, 6), (3, 3), (2, 2)]),          # one launch (roles fused)
                                          (8, 700, [(16, 16), (8, 8), (4, 4), (2, 2)]),          # Lq*P > 2048: role A as its own launch
                                          (16, 600, [(10, 10), (5, 5)]),                           # 16 heads: whole queries per workgroup

@@ -78,6 +78,20 @@ def test_mixed_dtypes_fall_back_to_the_python_node(ext):
     assert "MSDeformAttnFunction" in out.grad_fn.name() and out.dtype == torch.float32
 
 
+def test_all_half_inputs_are_computed_in_float32(ext):
+    """The amp branch of the dino copy of the module (models/dino/ops/modules/ms_deform_attn.py:124-131) up-casts half
+    tensors before the call; here the Function does it itself: float32 inside, gradients back in the inputs' dtypes."""
+    from uvhand_amd.functions import MSDeformAttnFunction
+    z, value, shapes, lsi, loc, attn, go = _inputs("cfg1")
+    v, l, a = (t.half().requires_grad_(True) for t in (value, loc, attn))
+    out = MSDeformAttnFunction.apply(v, shapes, lsi, l, a, 64)
+    assert out.dtype == torch.float32
+    out.backward(go)
+    assert v.grad.dtype == l.grad.dtype == a.grad.dtype == torch.float16
+    ref = MSDeformAttnFunction.apply(v.detach().float(), shapes, lsi, l.detach().float(), a.detach().float(), 64)
+    assert torch.equal(out.detach(), ref)
+
+
 def test_bf16_cpp_node_equals_python_node(ext):
     from torch.autograd import Function
     from uvhand_amd.functions import MSDeformAttnBF16Function

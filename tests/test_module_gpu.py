@@ -89,6 +89,22 @@ def test_module_runs_under_autocast_like_reference():
     assert rel_err(out.float().detach().cpu().numpy(), ref.detach().cpu().numpy()) < 2e-2
 
 
+def test_half_module_follows_the_dino_amp_branch():
+    """module.half() with half inputs: the op runs in float32 and its output returns to half before output_proj
+    (models/dino/ops/modules/ms_deform_attn.py:124-131)."""
+    mod = _module()
+    z = load_golden("module_2d")
+    query, refp, src, shapes, lsi = [torch.from_numpy(z[k]).cuda() for k in ("query", "refp", "src", "shapes", "level_start")]
+    ref = mod(query, refp, src, shapes, lsi)
+    import copy
+    hmod = copy.deepcopy(mod).half()
+    out = hmod(query.half(), refp.half(), src.half(), shapes, lsi)
+    assert out.dtype == torch.float16 and torch.isfinite(out).all()
+    assert rel_err(out.float().detach().cpu().numpy(), ref.detach().cpu().numpy()) < 3e-2
+    out.float().sum().backward()
+    assert all(p.grad is not None and p.grad.dtype == torch.float16 for p in hmod.parameters())
+
+
 @pytest.mark.parametrize("autocast", [False, True])
 def test_module_bf16_storage_takes_the_fused_path_and_tracks_fp32(autocast, monkeypatch):
     """bf16_storage keeps the fast module path (fused prologue on bf16 rows + merged projection, msda_*_prologue_bf16*):

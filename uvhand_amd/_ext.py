@@ -12,10 +12,11 @@ _mod = None
 _tried = False
 
 
-def get():
-    """The extension module, or None if it is not built / cannot be loaded (ABI mismatch with the installed torch)."""
+def get(retry=False):
+    """The extension module, or None if it is not built / cannot be loaded (ABI mismatch with the installed torch, or
+    compiled against another include/msda.h than the loaded libmsda_hip.so).  retry=True looks again (after a rebuild)."""
     global _mod, _tried
-    if _tried:
+    if _tried and not (retry and _mod is None):
         return _mod
     _tried = True
     if os.path.exists(_PATH) and os.path.exists(_native.LIB_PATH):
@@ -24,6 +25,7 @@ def get():
             spec = importlib.util.spec_from_file_location("_msda_torch", _PATH)
             mod = importlib.util.module_from_spec(spec)
             spec.loader.exec_module(mod)
+            # compile-time MSDA_ABI_VERSION of the extension vs the run-time version of the library it just linked to
             if mod.abi_version() == _native.load().msda_version():
                 _mod = mod
         except (ImportError, OSError):

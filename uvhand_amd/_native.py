@@ -133,6 +133,17 @@ def _compute_dtypes(value, sampling_loc, attn_weight):
     return suf
 
 
+# Test hook (tests/test_parity_gpu.py): msda_force_path() is THREAD-LOCAL in the library, so that no caller can flip the
+# kernel family under another thread's launch.  The setting made here is replayed on whichever thread performs a native
+# call (autograd runs backward on its own device thread); a process that never calls force_path() pays nothing.
+_forced_path = None
+
+
+def _sync_forced_path(lib):
+    if _forced_path is not None:
+        lib.msda_force_path(_forced_path)
+
+
 def _raise(lib, rc, what):
     msg = lib.msda_last_error()
     raise RuntimeError("%s failed (code %d): %s" % (what, rc, msg.decode() if msg else "?"))
@@ -196,6 +207,7 @@ class _DeviceGuard:
 def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
     """Replaces MSDA.ms_deform_attn_forward (vision.cpp:14). Returns out[N, Lq, M*D]."""
     lib = _lib or load()
+    _sync_forced_path(lib)
     _check_inputs((("value", value), ("spatial_shapes", spatial_shapes),
                    ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
                    ("attn_weight", attn_weight)))
@@ -233,6 +245,7 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     comes back in float32 (msda_backward_bf16_gv32, include/msda.h; the only bf16 backward outside D = 32).  deterministic (None = deterministic_requested()):
     bitwise reproducible grad_value (MSDA_FLAG_DETERMINISTIC; D = 32 kernel family, fp32 / bf16 rows)."""
     lib = _lib or load()
+    _sync_forced_path(lib)
     _check_inputs((("value", value), ("spatial_shapes", spatial_shapes),
                    ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
                    ("attn_weight", attn_weight), ("grad_output", grad_output)))
@@ -333,6 +346,7 @@ def prologue_supported(value, reference_points, sampling_offsets, attn_logits):
     N, S, M, D = value.shape
     Lq, L, P = sampling_offsets.shape[1], sampling_offsets.shape[3], sampling_offsets.shape[4]
     lib = _lib or load()
+    _sync_forced_path(lib)
     return bool(lib.msda_prologue_supported(N, S, M, D, L, Lq, P))
 
 
@@ -361,6 +375,7 @@ _LL = ctypes.c_longlong
 def prologue_geometry_supported(N, S, M, D, L, Lq, P):
     """msda_prologue_supported (include/msda.h) for fp32 tensors of these sizes."""
     lib = _lib or load()
+    _sync_forced_path(lib)
     return bool(lib.msda_prologue_supported(N, S, M, D, L, Lq, P))
 
 
@@ -380,6 +395,7 @@ def ms_deform_attn_forward_prologue(value, spatial_shapes, level_start_index, re
     what the reference's Python would have computed and are what the backward consumes.  `sampling_offsets`
     [N,Lq,M,L,P,2] and `attn_logits` [N,Lq,M,L*P] may be column blocks of one wider projection output."""
     lib = _lib or load()
+    _sync_forced_path(lib)
     _check_inputs((("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
                    ("reference_points", reference_points)))
     for name, t in (("sampling_offsets", sampling_offsets), ("attn_logits", attn_logits)):
@@ -422,6 +438,7 @@ def ms_deform_attn_backward_prologue(value, spatial_shapes, level_start_index, s
     merged=True: the two raw gradients are the column blocks [0, 2*M*L*P) and [2*M*L*P, 3*M*L*P) of ONE
     [N, Lq, 3*M*L*P] tensor — the gradient of a merged offsets+logits projection — returned as a fifth value."""
     lib = _lib or load()
+    _sync_forced_path(lib)
     _check_inputs((("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
                    ("sampling_loc", sampling_loc), ("attn_weight", attn_weight), ("grad_output", grad_output)))
     # same checks as the plain backward (the kernels reinterpret device memory: a wrong dtype is silent garbage)
@@ -578,9 +595,13 @@ PATH_GENERIC, PATH_D32 = 0, 1          # MSDA_PATH_* (include/msda.h)
 
 
 def path_for(elem_bytes, M, D, L, P):
+    _sync_forced_path(load())
     return int(load().msda_path_for(ctypes.c_int(elem_bytes), ctypes.c_int(M), ctypes.c_int(D),
                                     ctypes.c_int(L), ctypes.c_int(P)))
 
 
 def force_path(path):
-    load().msda_force_path(ctypes.c_int(int(path)))
+    """Test hook: -1 = automatic selection, PATH_GENERIC = the generic kernels for every call made through this module."""
+    global _forced_path
+    _forced_path = int(path)
+    load().msda_force_path(ctypes.c_int(_forced_path))

@@ -1,6 +1,5 @@
 // C ABI of libmsda_hip.so (declared in include/msda.h): argument validation, kernel-family
 // selection, error reporting.  No torch types, no allocation, no device synchronisation.
-#include <atomic>
 #include <cstdio>
 #include <cstring>
 
@@ -9,7 +8,7 @@
 namespace msda {
 
 static thread_local char g_err[512] = "";
-static std::atomic<int> g_force_path{-1};
+static thread_local int g_force_path = -1;          // msda_force_path(): test hook, this thread's calls only
 
 int set_error(int code, const char *msg)
 {
@@ -78,7 +77,7 @@ static int refuse_unaligned(const char *who)
 
 static bool use_d32(int N, int S, int M, int D, int L, int Lq, int P)
 {
-    const int f = g_force_path.load(std::memory_order_relaxed);
+    const int f = g_force_path;
     if (f == MSDA_PATH_GENERIC) return false;
     return d32_supported(N, S, M, D, L, Lq, P);
 }
@@ -264,7 +263,7 @@ unsigned long long msda_backward_workspace_bytes(int N, int S, int M, int D, int
 {
     if (N <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Lq <= 0 || P <= 0) return 0;
     if (!(flags & MSDA_FLAG_DETERMINISTIC)) return 0;                   // only the deterministic path chunks queries
-    if (msda::g_force_path.load(std::memory_order_relaxed) == MSDA_PATH_GENERIC) return 0;
+    if (msda::g_force_path == MSDA_PATH_GENERIC) return 0;
     return (unsigned long long)msda::backward_workspace_bytes(N, S, M, D, L, Lq, P);
 }
 
@@ -306,7 +305,7 @@ int msda_backward_ws_bf16_gv32(const uint16_t *grad_out, const uint16_t *value, 
 int msda_prologue_supported(int N, int S, int M, int D, int L, int Lq, int P)
 {
     if (N <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Lq <= 0 || P <= 0) return 0;
-    if (msda::g_force_path.load(std::memory_order_relaxed) == MSDA_PATH_GENERIC) return 0;
+    if (msda::g_force_path == MSDA_PATH_GENERIC) return 0;
     return msda::prologue_supported(N, S, M, D, L, Lq, P) ? 1 : 0;
 }
 
@@ -596,7 +595,7 @@ unsigned long long msda_unflatten_workspace_bytes(int L, const int *heights, con
 
 const char *msda_last_error(void) { return msda::g_err; }
 
-int msda_version(void) { return 101; }
+int msda_version(void) { return MSDA_ABI_VERSION; }
 
 int msda_path_for(int elem_bytes, int M, int D, int L, int P)
 {
@@ -604,6 +603,6 @@ int msda_path_for(int elem_bytes, int M, int D, int L, int P)
     return ((elem_bytes == 4 || elem_bytes == 2) && msda::use_d32(1, 1, M, D, L, 1, P)) ? MSDA_PATH_D32 : MSDA_PATH_GENERIC;
 }
 
-void msda_force_path(int path) { msda::g_force_path.store(path, std::memory_order_relaxed); }
+void msda_force_path(int path) { msda::g_force_path = path; }
 
 }  // extern "C"

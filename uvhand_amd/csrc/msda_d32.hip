@@ -25,6 +25,14 @@
 #include "msda_common.h"
 #include "msda_launch.h"
 
+// This file is compiled three times by the Makefile, one object per storage-type combination, so that the three sets of
+// kernel instantiations build side by side (-DMSDA_D32_PART=0: fp32 rows, 1: bf16 rows with a bf16 grad_value, 2: bf16
+// rows with an fp32 grad_value); without the macro (tools/micro/kbench.cpp's unity build) it holds all of them.
+#ifndef MSDA_D32_PART
+#define MSDA_D32_PART -1
+#endif
+#define MSDA_D32_HAS(part) (MSDA_D32_PART < 0 || MSDA_D32_PART == (part))
+
 namespace msda {
 
 // Diagnostic build only (tools/micro/kbench.cpp, -DMSDA_STAMPS): per-workgroup phase timestamps
@@ -565,15 +573,18 @@ __global__ __launch_bounds__(kCBlock, (128 * 8) / kCBlock >= 4 ? 4 : 2) void bwd
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
+#if MSDA_D32_HAS(0)
 bool d32_supported(int N, int S, int M, int D, int L, int Lq, int P)
 {
     if (D != kD || L > kMaxLevels || L * P > 32) return false;
     const long long items = (long long)N * Lq * M;
-    if ((long long)N * S * M * kD >= (1LL << 31)) return false;        // int32 element offsets
+    if ((long long)N * S * M * kD >= (1LL << 31)) return false;        // int32 element offsets (value / grad_value)
+    if (items * kD >= (1LL << 31)) return false;                       // ... and of out / grad_out rows (q * M*32 in role B's gathers)
     if (items * L * P * 2 >= (1LL << 31) || items >= (1LL << 30)) return false;
     if ((long long)N * M > 65535 || S > (1 << 19)) return false;       // role-B workgroup count and S*W stay 32-bit
     return true;
 }
+#endif
 
 // Every MSDA_* knob named in this file is read in DIAGNOSTIC builds only (-DMSDA_TUNING, msda_launch.h); the shipped
 // library gets the defaults.
@@ -726,12 +737,14 @@ static int cell_cmax(int N, int S, int M, int L, int Lq, int P)
     return (int)(c < 1 ? 1 : c > 8 ? 8 : c);
 }
 
+#if MSDA_D32_HAS(0)
 size_t backward_workspace_bytes(int N, int S, int M, int D, int L, int Lq, int P)
 {
     if (!d32_supported(N, S, M, D, L, Lq, P)) return 0;
     const int c = cell_cmax(N, S, M, L, Lq, P);
     return c > 1 ? (size_t)N * M * c * S * kD * sizeof(float) : 0;
 }
+#endif
 
 struct CellLaunch { CellPlan pl; long long nB; };
 static CellLaunch plan_cells(int N, int S, int M, int L, int Lq, int P, void *workspace, size_t ws_bytes)
@@ -887,7 +900,11 @@ static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *
                 if (fp.fixed)                { if (fp.split == 4) MSDA_LAUNCH_F(4, kAccNone, true); else if (fp.split == 2) MSDA_LAUNCH_F(2, kAccNone, true); else MSDA_LAUNCH_F(1, kAccNone, true); }
                 else if (pl.acc == kAccNone) { if (fp.split == 4) MSDA_LAUNCH_F(4, kAccNone, false); else if (fp.split == 2) MSDA_LAUNCH_F(2, kAccNone, false); else MSDA_LAUNCH_F(1, kAccNone, false); }
                 else if (pl.acc == kAccWide) { if (fp.split == 4) MSDA_LAUNCH_F(4, kAccWide, false); else if (fp.split == 2) MSDA_LAUNCH_F(2, kAccWide, false); else MSDA_LAUNCH_F(1, kAccWide, false); }
+#ifdef MSDA_TUNING                                                       // kAccRmw is only ever planned with MSDA_BWD_WIDE=0
                 else                         { if (fp.split == 4) MSDA_LAUNCH_F(4, kAccRmw, false); else if (fp.split == 2) MSDA_LAUNCH_F(2, kAccRmw, false); else MSDA_LAUNCH_F(1, kAccRmw, false); }
+#else
+                else return set_error(MSDA_ERR_LAUNCH, "msda backward (d32): unplanned accumulation mode");
+#endif
 #undef MSDA_LAUNCH_F
                 return check_launch("msda backward (d32, fused)");
             }
@@ -902,8 +919,12 @@ static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *
         if (pl.acc == kAccNone) MSDA_LAUNCH_B(kAccNone, kSinglePPT);
         else if (pl.acc == kAccTile) MSDA_LAUNCH_B(kAccTile, kMultiPPT);
         else if (pl.acc == kAccWide) MSDA_LAUNCH_B(kAccWide, kSinglePPT);
+#ifdef MSDA_TUNING
         else if (pl.ppt == kMultiPPT) MSDA_LAUNCH_B(kAccRmw, kMultiPPT);
         else MSDA_LAUNCH_B(kAccRmw, kSinglePPT);
+#else
+        else return set_error(MSDA_ERR_LAUNCH, "msda backward (d32): unplanned accumulation mode");
+#endif
 #undef MSDA_LAUNCH_B
         if (int rc = check_launch("msda backward (d32, grad_value sort+gather)")) return rc;
     }
@@ -927,6 +948,7 @@ static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *
 }
 
 // ---- fused prologue (fp32 only): see PrologueIn / PrologueOut ----
+#if MSDA_D32_HAS(0)
 bool prologue_supported(int N, int S, int M, int D, int L, int Lq, int P)
 {
     if (!d32_supported(N, S, M, D, L, Lq, P)) return false;
@@ -937,6 +959,7 @@ bool prologue_supported(int N, int S, int M, int D, int L, int Lq, int P)
     static const bool plain_modes = tuning_str("MSDA_BWD_MODE") != nullptr;
     return !plain_modes;                                                        // A/B knobs select the unfused kernels
 }
+#endif
 
 template <typename VT>
 static int launch_fwd_prologue_t(const VT *value, const int64_t *shapes, const int64_t *level_start, const float *ref,
@@ -994,11 +1017,16 @@ static int launch_bwd_prologue_t(const VT *grad_out, const VT *value, const int6
     if (fp.fixed)                { if (fp.split == 4) MSDA_LAUNCH_BP(4, kAccNone, true); else if (fp.split == 2) MSDA_LAUNCH_BP(2, kAccNone, true); else MSDA_LAUNCH_BP(1, kAccNone, true); }
     else if (pl.acc == kAccNone) { if (fp.split == 4) MSDA_LAUNCH_BP(4, kAccNone, false); else if (fp.split == 2) MSDA_LAUNCH_BP(2, kAccNone, false); else MSDA_LAUNCH_BP(1, kAccNone, false); }
     else if (pl.acc == kAccWide) { if (fp.split == 4) MSDA_LAUNCH_BP(4, kAccWide, false); else if (fp.split == 2) MSDA_LAUNCH_BP(2, kAccWide, false); else MSDA_LAUNCH_BP(1, kAccWide, false); }
+#ifdef MSDA_TUNING
     else                         { if (fp.split == 4) MSDA_LAUNCH_BP(4, kAccRmw, false); else if (fp.split == 2) MSDA_LAUNCH_BP(2, kAccRmw, false); else MSDA_LAUNCH_BP(1, kAccRmw, false); }
+#else
+    else return set_error(MSDA_ERR_LAUNCH, "msda backward (d32, fused prologue): unplanned accumulation mode");
+#endif
 #undef MSDA_LAUNCH_BP
     return check_launch("msda backward (d32, fused prologue)");
 }
 
+#if MSDA_D32_HAS(0)
 int launch_fwd_prologue(const float *value, const int64_t *shapes, const int64_t *level_start, const float *ref,
                         const float *offsets, const float *logits, int N, int S, int M, int L, int Lq, int P,
                         long long ld_offsets, long long ld_logits, float *out, float *loc_out, float *attn_out,
@@ -1007,6 +1035,8 @@ int launch_fwd_prologue(const float *value, const int64_t *shapes, const int64_t
     return launch_fwd_prologue_t<float>(value, shapes, level_start, ref, offsets, logits, N, S, M, L, Lq, P, ld_offsets, ld_logits,
                                         out, loc_out, attn_out, stream);
 }
+#endif
+#if MSDA_D32_HAS(1)
 int launch_fwd_prologue_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *level_start, const float *ref,
                              const float *offsets, const float *logits, int N, int S, int M, int L, int Lq, int P,
                              long long ld_offsets, long long ld_logits, uint16_t *out, float *loc_out, float *attn_out,
@@ -1015,6 +1045,8 @@ int launch_fwd_prologue_bf16(const uint16_t *value, const int64_t *shapes, const
     return launch_fwd_prologue_t<bf16_t>(value, shapes, level_start, ref, offsets, logits, N, S, M, L, Lq, P, ld_offsets, ld_logits,
                                          out, loc_out, attn_out, stream);
 }
+#endif
+#if MSDA_D32_HAS(0)
 int launch_bwd_prologue(const float *grad_out, const float *value, const int64_t *shapes, const int64_t *level_start,
                         const float *loc, const float *attn, int N, int S, int M, int L, int Lq, int P, float *grad_value,
                         long long ld_grad_offsets, long long ld_grad_logits, float *grad_offsets, float *grad_logits,
@@ -1024,6 +1056,8 @@ int launch_bwd_prologue(const float *grad_out, const float *value, const int64_t
                                         ld_grad_offsets, ld_grad_logits, grad_offsets, grad_logits, grad_ref, stream, workspace,
                                         ws_bytes, deterministic);
 }
+#endif
+#if MSDA_D32_HAS(2)
 int launch_bwd_prologue_bf16(const uint16_t *grad_out, const uint16_t *value, const int64_t *shapes, const int64_t *level_start,
                              const float *loc, const float *attn, int N, int S, int M, int L, int Lq, int P, float *grad_value,
                              long long ld_grad_offsets, long long ld_grad_logits, float *grad_offsets, float *grad_logits,
@@ -1033,12 +1067,16 @@ int launch_bwd_prologue_bf16(const uint16_t *grad_out, const uint16_t *value, co
                                          ld_grad_offsets, ld_grad_logits, grad_offsets, grad_logits, grad_ref, stream, workspace,
                                          ws_bytes, deterministic);
 }
+#endif
 
+#if MSDA_D32_HAS(0)
 int launch_fwd_d32(const float *value, const int64_t *shapes, const int64_t *level_start, const float *loc,
                    const float *attn, int N, int S, int M, int L, int Lq, int P, float *out, hipStream_t stream)
 {
     return launch_fwd_d32_t<float>(value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, out, stream);
 }
+#endif
+#if MSDA_D32_HAS(0)
 int launch_bwd_d32(const float *grad_out, const float *value, const int64_t *shapes, const int64_t *level_start,
                    const float *loc, const float *attn, int N, int S, int M, int L, int Lq, int P,
                    float *grad_value, float *grad_loc, float *grad_attn, hipStream_t stream, void *workspace, size_t ws_bytes,
@@ -1047,12 +1085,16 @@ int launch_bwd_d32(const float *grad_out, const float *value, const int64_t *sha
     return launch_bwd_d32_t<float>(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, grad_value,
                                    grad_loc, grad_attn, stream, workspace, ws_bytes, deterministic);
 }
+#endif
+#if MSDA_D32_HAS(1)
 int launch_fwd_d32_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *level_start, const float *loc,
                         const float *attn, int N, int S, int M, int L, int Lq, int P, uint16_t *out,
                         hipStream_t stream)
 {
     return launch_fwd_d32_t<bf16_t>(value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, out, stream);
 }
+#endif
+#if MSDA_D32_HAS(1)
 int launch_bwd_d32_bf16(const uint16_t *grad_out, const uint16_t *value, const int64_t *shapes,
                         const int64_t *level_start, const float *loc, const float *attn, int N, int S, int M, int L,
                         int Lq, int P, uint16_t *grad_value, float *grad_loc, float *grad_attn, hipStream_t stream,
@@ -1061,6 +1103,8 @@ int launch_bwd_d32_bf16(const uint16_t *grad_out, const uint16_t *value, const i
     return launch_bwd_d32_t<bf16_t>(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, grad_value,
                                     grad_loc, grad_attn, stream, workspace, ws_bytes, deterministic);
 }
+#endif
+#if MSDA_D32_HAS(2)
 int launch_bwd_d32_bf16_gv32(const uint16_t *grad_out, const uint16_t *value, const int64_t *shapes,
                              const int64_t *level_start, const float *loc, const float *attn, int N, int S, int M, int L,
                              int Lq, int P, float *grad_value, float *grad_loc, float *grad_attn, hipStream_t stream,
@@ -1069,7 +1113,10 @@ int launch_bwd_d32_bf16_gv32(const uint16_t *grad_out, const uint16_t *value, co
     return launch_bwd_d32_t<bf16_t, float>(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, grad_value,
                                            grad_loc, grad_attn, stream, workspace, ws_bytes, deterministic);
 }
+#endif
 
+#if MSDA_D32_HAS(0)
 int backward_passes(int Lq, int P) { return (Lq * P + kSingleMaxPoints - 1) / kSingleMaxPoints; }
+#endif
 
 }  // namespace msda

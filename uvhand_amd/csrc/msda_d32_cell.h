@@ -386,14 +386,13 @@ __device__ __forceinline__ void bwd_cell_body(
 {
     const int NP = Lq * P;
     float *slab_pair = pl.slabs ? pl.slabs + (long long)pr * pl.slab_rows * kD : nullptr;
-    int cursor = 0, first = 0, cover_end = 0;
+    int cursor = 0, first = 0;
     // Items are numbered level by level, tiles then chunks (numbering the coarse levels — the longest items of a pair —
     // first was measured: cfg-4 encoder role B 264 -> 410 us; profiles/r02_notes.md).
     for (int l = 0; l < L; ++l) {                                                  // uniform (scalar) walk over the levels
         LevelTiles lt;
         level_tiles(shapes, level_start, l, S, NP, Lq, pl, cursor, lt);
         const int items = lt.ntile * lt.C;
-        if (lt.ntile > 0) cover_end = max(cover_end, lt.lstart + lt.HW);
         // items of this level owned by this slot: global item numbers first .. first+items-1, mine = slot mod G
         int it = slot - first % pl.slots;
         if (it < 0) it += pl.slots;
@@ -402,13 +401,8 @@ __device__ __forceinline__ void bwd_cell_body(
                               slab_pair, smem);
         first += items;
     }
-    if (slot == 0 && cover_end < S) {
-        // rows past the last level (inconsistent shapes only): defined, zero
-        const int b = pr / M, m = pr - b * M;
-        for (int i = threadIdx.x; i < (S - cover_end) * 8; i += kCBlock)
-            Row<GT>::store(grad_value + ((long long)(b * S + cover_end + (i >> 3)) * M + m) * kD + (i & 7) * 4,
-                           make_float4(0.f, 0.f, 0.f, 0.f));
-    }
+    // rows no level covers (inconsistent shapes only): defined, zero
+    if (slot == 0) zero_uncovered_rows<GT, kCBlock>(shapes, level_start, S, M, L, grad_value, pr / M, pr % M);
 }
 
 // Adds up the C partial slabs of every pixel of the levels that were cut into query chunks, in chunk order.

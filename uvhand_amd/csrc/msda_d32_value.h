@@ -77,6 +77,30 @@ constexpr int kMultiRows = 256;             // 32 KB LDS tile
 constexpr int kMultiPPT = 6;                // 3072 points per pass, 96 KB of records
 
 
+// Rows of [0, S) that no fitting level covers get zeros (include/msda.h) — only shapes inconsistent with S have any: with
+// level_start_index the running sum of H*W, as the reference's callers build it (models/arctic_transformer.py:176-177),
+// the walk below finds no gap and stores nothing.  Called by ONE workgroup per (batch, head) pair.  Levels that overlap
+// each other are not supported (each level's owner STORES its rows, the last store wins); gaps before, between and after
+// the levels — including the rows of a level that was dropped because it does not fit — are handled here.
+template <typename GT, int THREADS>
+__device__ __forceinline__ void zero_uncovered_rows(const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
+                                                    int S, int M, int L, GT *__restrict__ grad_value, int b, int m)
+{
+    long long cur = 0;                                       // rows below `cur` are dealt with (uniform, scalar unit)
+    while (cur < S) {
+        long long ns = S, ne = S;                            // the covered interval [ns, ne) that ends after `cur` and starts first
+        for (int k = 0; k < L; ++k) {
+            if (!level_fits(shapes[2 * k], shapes[2 * k + 1], level_start[k], S)) continue;
+            const long long s0 = level_start[k], e0 = s0 + shapes[2 * k] * shapes[2 * k + 1];
+            if (e0 > cur && s0 < ns) { ns = s0; ne = e0; }
+        }
+        for (long long i = (long long)threadIdx.x; i < (ns - cur) * 8; i += THREADS)
+            Row<GT>::store(grad_value + (((long long)b * S + cur + (i >> 3)) * M + m) * kD + (i & 7) * 4,
+                           make_float4(0.f, 0.f, 0.f, 0.f));
+        cur = ne > cur ? ne : S;
+    }
+}
+
 __device__ __forceinline__ float4 shfl_xor4(const float4 &v, int m)
 {
     return make_float4(__shfl_xor(v.x, m, kWave), __shfl_xor(v.y, m, kWave), __shfl_xor(v.z, m, kWave),
@@ -190,6 +214,8 @@ struct RecAos {
 };
 struct RecSoa {
     const float *w; const uint16_t *q; int qbase, stride;
+    // 32-bit product on purpose (a 64-bit multiply per record would cost the gather an instruction pair per row load):
+    // (qbase + q) < Lq and stride = M*32, and d32_supported() admits only N*Lq*M*32 < 2^31.
     __device__ __forceinline__ void get(int i, float &wt, long long &off) const { wt = w[i]; off = (long long)((qbase + (int)q[i]) * stride); }
 };
 
@@ -365,17 +391,7 @@ __device__ __forceinline__ void bwd_value_body(
     const int px0 = (int)((unsigned)(ti * HW) / (unsigned)W), px1 = (int)((unsigned)((ti + 1) * HW) / (unsigned)W);
     const int npx = px1 - px0;
     const int b = pr / M, m = pr - b * M;
-    if (l == 0 && ti == 0) {
-        // pixels past the last level that fits (inconsistent shapes only) get zeros; with level_start the running
-        // sum of H*W, as the reference's callers build it (models/arctic_transformer.py:176-177), there are none
-        long long cover = 0;
-        for (int k = 0; k < L; ++k)
-            if (level_fits(shapes[2 * k], shapes[2 * k + 1], level_start[k], S))
-                cover = max(cover, (long long)level_start[k] + shapes[2 * k] * shapes[2 * k + 1]);
-        for (int i = threadIdx.x; i < (S - (int)cover) * 8; i += kSBlock)
-            Row<GT>::store(grad_value + ((long long)(b * S + (int)cover + (i >> 3)) * M + m) * kD + (i & 7) * 4,
-                           make_float4(0.f, 0.f, 0.f, 0.f));
-    }
+    if (l == 0 && ti == 0) zero_uncovered_rows<GT, kSBlock>(shapes, level_start, S, M, L, grad_value, b, m);
     // empty range, or a level that does not fit in S (then nothing of it is touched).  A level that fits has
     // npx <= tp_cap by construction of the ranges (plan_value: tp_cap = ceil(S / W) >= ceil(H*W / W_l)).
     if (npx <= 0 || npx > tp_cap || !level_fits(shapes[2 * l], shapes[2 * l + 1], level_start[l], S)) return;
@@ -598,15 +614,7 @@ __device__ __forceinline__ void bwd_value_wide_body(
     const int px0 = (int)((unsigned)(ti * HW) / (unsigned)W), px1 = (int)((unsigned)((ti + 1) * HW) / (unsigned)W);
     const int npx = px1 - px0;
     const int b = pr / M, m = pr - b * M;
-    if (l == 0 && ti == 0) {                                 // pixels past the last level that fits: see bwd_value_body
-        long long cover = 0;
-        for (int k = 0; k < L; ++k)
-            if (level_fits(shapes[2 * k], shapes[2 * k + 1], level_start[k], S))
-                cover = max(cover, (long long)level_start[k] + shapes[2 * k] * shapes[2 * k + 1]);
-        for (int i = threadIdx.x; i < (S - (int)cover) * 8; i += kSBlock)
-            Row<GT>::store(grad_value + ((long long)(b * S + (int)cover + (i >> 3)) * M + m) * kD + (i & 7) * 4,
-                           make_float4(0.f, 0.f, 0.f, 0.f));
-    }
+    if (l == 0 && ti == 0) zero_uncovered_rows<GT, kSBlock>(shapes, level_start, S, M, L, grad_value, b, m);
     if (npx <= 0 || npx > tp_cap || !level_fits(shapes[2 * l], shapes[2 * l + 1], level_start[l], S)) return;
     const int NP = Lq * P;
     const long long item_base = (long long)b * Lq * M + m;

@@ -14,9 +14,26 @@ OUT = os.path.join(PKG, "_msda_torch.so")
 SRC = os.path.join(HERE, "msda_torch.cpp")
 
 
-def build(verbose=False):
+STAMP = os.path.join(ROOT, "build", "torch_ext", "built_with.txt")
+
+
+def _stamp():
+    """What the extension was built against besides its sources: the torch build (its headers and ABI) and the C-ABI
+    library next to it.  A torch upgrade or a rebuilt libmsda_hip.so makes the stamp differ -> rebuild."""
+    import torch
+    lib = os.path.join(PKG, "libmsda_hip.so")
+    return "torch %s\nlibmsda_hip.so %d\n" % (torch.__version__, int(os.path.getmtime(lib)) if os.path.exists(lib) else 0)
+
+
+def build(verbose=False, force=False):
     deps = [SRC, os.path.join(ROOT, "include", "msda.h"), os.path.abspath(__file__)]
-    if os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
+    try:
+        with open(STAMP) as f:
+            same_env = f.read() == _stamp()
+    except OSError:
+        same_env = False
+    if (not force and same_env and os.path.exists(OUT)
+            and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps)):
         return OUT
     import torch
     from torch.utils.cpp_extension import include_paths, library_paths
@@ -37,8 +54,11 @@ def build(verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    os.makedirs(os.path.dirname(STAMP), exist_ok=True)
+    with open(STAMP, "w") as f:
+        f.write(_stamp())
     return OUT
 
 
 if __name__ == "__main__":
-    print(build(verbose="-v" in sys.argv))
+    print(build(verbose="-v" in sys.argv, force="--force" in sys.argv))

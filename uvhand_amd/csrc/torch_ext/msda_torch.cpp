@@ -240,5 +240,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("ms_deform_attn_backward", &backward, "replaces MSDA.ms_deform_attn_backward (vision.cpp:15)");
     m.def("apply", &apply, "MSDeformAttnFunction.apply as a C++ autograd node");
     m.def("apply_bf16", &apply_bf16, "MSDeformAttnBF16Function.apply as a C++ autograd node");
-    m.def("abi_version", [] { return msda_version(); });
+    // the header this file was COMPILED against (not the loaded library's msda_version(): _ext.py compares the two)
+    m.def("abi_version", [] { return (int)MSDA_ABI_VERSION; });
 }

@@ -22,15 +22,16 @@ from ..functions.linear_func import bracket_linear
 from .ms_deform_attn import MSDeformAttn
 
 
+_ACTIVATIONS = {"relu": F.relu, "gelu": F.gelu, "glu": F.glu}
+
+
 def _get_activation_fn(activation):
-    """models/arctic_transformer.py:463-471."""
-    if activation == "relu":
-        return F.relu
-    if activation == "gelu":
-        return F.gelu
-    if activation == "glu":
-        return F.glu
-    raise RuntimeError(F"activation should be relu/gelu, not {activation}.")
+    """Name -> functional of the FFN's non-linearity; the same three names and the same exception type as the
+    reference's helper (models/arctic_transformer.py:463-471) accept."""
+    try:
+        return _ACTIVATIONS[activation]
+    except KeyError:
+        raise RuntimeError("unknown activation %r (one of: %s)" % (activation, ", ".join(sorted(_ACTIVATIONS)))) from None
 
 
 class DeformableTransformerEncoderLayer(nn.Module):

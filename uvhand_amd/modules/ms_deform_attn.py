@@ -206,6 +206,12 @@ class MSDeformAttn(nn.Module):
                 "Last dim of reference_points must be 2 or 4, but get {} instead.".format(ref_dim))
 
         fn = MSDeformAttnBF16Function if self.bf16_storage else MSDeformAttnFunction
+        if value.dtype == torch.float16 and not self.bf16_storage:
+            # all-half inputs (amp): float32 inside the op, half outside — the dino copy of the module,
+            # models/dino/ops/modules/ms_deform_attn.py:124-131
+            output = fn.apply(value.float(), input_spatial_shapes, input_level_start_index, sampling_locations.float(),
+                              attention_weights, self.im2col_step).to(torch.float16)
+            return bracket_linear(output, self.output_proj)
         output = fn.apply(value, input_spatial_shapes, input_level_start_index, sampling_locations,
                           attention_weights, self.im2col_step)
         return bracket_linear(output.to(self.output_proj.weight.dtype) if self.bf16_storage else output,
