@@ -37,6 +37,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+METRIC = "MSDeformAttn fwd+bwd samples/sec @ Swin-L 4-scale, 300 queries, 1/2/4/8 MI355X"      # BASELINE.json "metric"
 
 WORKLOADS = {
     # name: (N per GPU, [(H, W)...], M, D, Lq, P)
@@ -167,17 +168,35 @@ def time_cpu_baseline(workload, budget_s=8.0):
                       % (best["calls"], workload, N, best["threads"])}
 
 
+def kernel_sources_sha16():
+    """Fingerprint of the kernel sources (every .hip / .h under uvhand_amd/csrc, names and contents): PMC traffic figures
+    are only valid for the kernels they were profiled on."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "uvhand_amd", "csrc")
+    for name in sorted(os.listdir(src)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode() + b"\0")
+            with open(os.path.join(src, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(workload, which):
-    """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
-    collected in separate runs by tools/profile_gpu.sh, corrected as MI355X_MICROARCH.md prescribes:
-    KiB units, FETCH_SIZE doubled on gfx950).  The summary is committed under profiles/; None if the
-    workload has not been profiled."""
+    """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in
+    separate runs by tools/profile_gpu.sh, corrected as MI355X_MICROARCH.md prescribes: KiB units, FETCH_SIZE doubled
+    on gfx950; tools/pmc_traffic.py turns the summaries into profiles/pmc_traffic.json and stamps it with the fingerprint
+    of the kernel sources it profiled).  Returns (bytes or None, the fingerprint the figure belongs to): None when the
+    workload has not been profiled OR the kernels have changed since — a stale constant is not a measurement."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f)[workload][which]["hbm_bytes_per_launch"]
+            table = json.load(f)
+        at = table.get("sources_sha16")
+        val = table[workload][which]["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
-        return None
+        return None, None
+    return (val if at == kernel_sources_sha16() else None), at
 
 
 def event_time_ms(fn, iters, stream):
@@ -191,6 +210,119 @@ def event_time_ms(fn, iters, stream):
     return start.elapsed_time(stop) / iters
 
 
+def graph_of(fn, stream, per=10):
+    """fn() captured `per` times into one HIP graph (None if capture fails); the caller is inside `with torch.cuda.stream(stream)`."""
+    fn(); stream.synchronize()
+    try:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            for _ in range(per):
+                fn()
+        return g
+    except Exception as exc:
+        print("bench: HIP graph capture failed (%s)" % exc, file=sys.stderr)
+        return None
+
+
+def timed_us(call, per, stream, budget_s=0.6):
+    """Device time per inner call: HIP events on `stream` around enough back-to-back `call()`s (each = `per` inner calls)
+    to fill ~budget_s, after a short warm-up."""
+    for _ in range(3):
+        call()
+    one = event_time_ms(call, 2, stream)
+    n = max(3, min(2000, int(budget_s * 1e3 / max(one, 1e-3))))
+    return 1e3 * event_time_ms(call, n, stream) / per
+
+
+def measure_op(workload, dtype, device, stream, seed, locations="uniform", budget_s=0.6):
+    """One extra row of the performance table (not `value`): the same step as the headline — Function.apply forward +
+    backward, 10 steps per HIP graph — on another workload / storage type, plus the two kernels on their own."""
+    from uvhand_amd import _native
+    from uvhand_amd.functions import MSDeformAttnBF16Function, MSDeformAttnFunction
+    bf16 = dtype == "bf16"
+    _, d, dims = make_inputs(workload, seed, device, locations)
+    N, S, M, D, L, Lq, P = dims
+    value = (d["value"].to(torch.bfloat16) if bf16 else d["value"]).requires_grad_(True)
+    loc, attn = d["loc"].requires_grad_(True), d["attn"].requires_grad_(True)
+    go = d["go"].to(torch.bfloat16) if bf16 else d["go"]
+    apply = MSDeformAttnBF16Function.apply if bf16 else MSDeformAttnFunction.apply
+
+    def step():
+        value.grad = loc.grad = attn.grad = None
+        apply(value, d["shapes"], d["lsi"], loc, attn, 64).backward(go)
+
+    vd, ld, ad = value.detach(), loc.detach(), attn.detach()
+    gv32 = bf16 and _native.backward_passes(Lq, P) > 1
+    fwd = lambda: _native.ms_deform_attn_forward(vd, d["shapes"], d["lsi"], ld, ad, 64)
+    bwd = lambda: _native.ms_deform_attn_backward(vd, d["shapes"], d["lsi"], ld, ad, go, 64, fp32_grad_value=gv32)
+    row = {"workload": workload, "dtype": dtype, "locations": locations, "N": N, "Lq": Lq, "S": S}
+    with torch.cuda.stream(stream):
+        for name, fn in (("step", step), ("fwd", fwd), ("bwd", bwd)):
+            g = graph_of(fn, stream)
+            row[name + "_us"] = timed_us(g.replay if g is not None else fn, 10 if g is not None else 1, stream, budget_s)
+            del g
+        stream.synchronize()
+    fwd_b, bwd_b = algorithmic_bytes(N, S, M, D, L, Lq, P, e=2 if bf16 else 4)
+    row.update({"ms_per_step": row["step_us"] * 1e-3, "samples_per_s": N / (row["step_us"] * 1e-6),
+                "fwd_algorithmic_bytes": fwd_b, "bwd_algorithmic_bytes": bwd_b,
+                "fwd_frac": fwd_b / (row["fwd_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                "bwd_frac": bwd_b / (row["bwd_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                "launch": "hipGraph replay, 10 steps per graph; HIP events"})
+    tr, at = pmc_traffic(workload + ("_bf16" if bf16 else ""), "bwd")
+    row["bwd_traffic"] = tr
+    return row
+
+
+def measure_module(workload, device, stream, amp=False, budget_s=0.6):
+    """MSDeformAttn MODULE forward + backward (the op, its four nn.Linear projections, softmax / location arithmetic and
+    the weight gradients): one step per HIP graph (GPU-bound time) and the eager wall time a drop-in user sees."""
+    from uvhand_amd.modules import MSDeformAttn
+    N, shapes, M, D, Lq, P = WORKLOADS[workload]
+    gen = torch.Generator(device="cpu").manual_seed(0)
+    torch.manual_seed(0)
+    mod = MSDeformAttn(M * D, len(shapes), M, P).to(device)
+    with torch.no_grad():
+        for p in mod.parameters():
+            p.add_(torch.randn(p.shape, generator=gen).to(device) * 0.02)
+    mod.bf16_storage = bool(amp)
+    sh = torch.tensor(shapes, dtype=torch.long, device=device)
+    lsi = torch.cat((sh.new_zeros(1), sh.prod(1).cumsum(0)[:-1]))
+    S = int(sh.prod(1).sum())
+    q = torch.randn(N, Lq, M * D, generator=gen).to(device).requires_grad_(True)
+    src = torch.randn(N, S, M * D, generator=gen).to(device).requires_grad_(True)
+    ref = torch.rand(N, Lq, len(shapes), 2, generator=gen).to(device).requires_grad_(True)
+    go = torch.randn(N, Lq, M * D, generator=gen).to(device)
+
+    def step():
+        mod.zero_grad(set_to_none=True)
+        q.grad = src.grad = ref.grad = None
+        if amp:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = mod(q, ref, src, sh, lsi)
+            out.backward(go.to(out.dtype))
+        else:
+            mod(q, ref, src, sh, lsi).backward(go)
+
+    row = {"workload": workload, "amp": "bf16" if amp else None}
+    with torch.cuda.stream(stream):
+        for _ in range(3):
+            step()
+        g = graph_of(step, stream, per=1)
+        if g is not None:
+            row["graph_us"] = timed_us(g.replay, 1, stream, budget_s)
+        # eager: wall clock around back-to-back calls (host-bound at decoder sizes)
+        for _ in range(5):
+            step()
+        stream.synchronize()
+        n = 30
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        stream.synchronize()
+        row["eager_wall_us"] = 1e6 * (time.perf_counter() - t0) / n
+    return row
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -202,6 +334,8 @@ def main():
                     help="steps captured per HIP graph (the timed loop replays it steps/graph-steps times; "
                          "reduced to a divisor of --steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-table", action="store_true",
+                    help="skip the `workloads` / `modules` arrays (the other shapes of DESIGN.md's performance table, ~2 s each)")
     ap.add_argument("--repeats", type=int, default=50,
                     help="repetitions of the timed --steps block (each bracketed by barrier + synchronize); the median is reported")
     ap.add_argument("--kernel-iters", type=int, default=200)
@@ -353,8 +487,9 @@ def main():
     if rank == 0:
         fwd_b, bwd_b = algorithmic_bytes(N, S, M, D, L, Lq, P, e=esize)
         ach = bwd_b / (kt["bwd"] * 1e-3) / 1e9
+        traffic, traffic_at = pmc_traffic(args.workload + ("_bf16" if bf16 else ""), "bwd")
         result = {
-            "metric": "MSDeformAttn fwd+bwd samples/sec @ Swin-L 4-scale, 300 queries",
+            "metric": METRIC,
             "value": total_samples / elapsed,
             "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -378,8 +513,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "backward: msda::bwd_fused_d32_kernel (grad_value sort+gather "
                                                     "workgroups and grad_loc/grad_attn workgroups in one launch)",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(args.workload + ("_bf16" if bf16 else ""), "bwd"), "algorithmic_bytes": bwd_b,
-                         "ms": kt["bwd"]},
+                         "traffic": traffic, "traffic_profiled_at": traffic_at, "sources_sha16": kernel_sources_sha16(),
+                         "algorithmic_bytes": bwd_b, "ms": kt["bwd"]},
             "kernels": {"fwd": {"ms": kt["fwd"], "algorithmic_bytes": fwd_b,
                                 "GBps": fwd_b / (kt["fwd"] * 1e-3) / 1e9},
                         "bwd": {"ms": kt["bwd"], "algorithmic_bytes": bwd_b, "GBps": ach}},
@@ -387,6 +522,25 @@ def main():
         result.update(side)
         if world == 1:
             result["roofline"]["copy_GBps_measured"] = copy_bandwidth_gbs(device)
+        if world == 1 and not args.no_table:
+            # the rest of DESIGN.md's performance table, measured in the same run (none of it is `value`)
+            seed = harness.rank_seed(1000, rank)
+            table = [(w, "f32") for w in WORKLOADS if (w, "f32") != (args.workload, args.dtype)]
+            table += [("cfg2_decoder", "bf16")] if (args.workload, args.dtype) != ("cfg2_decoder", "bf16") else []
+            result["workloads"] = []
+            for w, dt in table:
+                try:
+                    result["workloads"].append(measure_op(w, dt, device, stream, seed))
+                except Exception as exc:                  # a row that cannot be measured says so; the headline stands
+                    result["workloads"].append({"workload": w, "dtype": dt, "error": "%s: %s" % (type(exc).__name__, exc)})
+                torch.cuda.empty_cache()
+            result["modules"] = []
+            for w, amp in (("cfg2_decoder", False), ("cfg4_encoder", False), ("cfg2_decoder", True), ("cfg4_encoder", True)):
+                try:
+                    result["modules"].append(measure_module(w, device, stream, amp))
+                except Exception as exc:
+                    result["modules"].append({"workload": w, "amp": amp, "error": "%s: %s" % (type(exc).__name__, exc)})
+                torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = time_cpu_baseline(args.workload)
             result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]

@@ -11,10 +11,10 @@ DT=${3:-f32}                      # f32 | bf16
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_${WL}_${DT}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/bench.py --workload $WL --dtype $DT --steps 300 --warmup 30 --repeats 5 --no-cpu-baseline > $OUT/bench_trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/bench.py --workload $WL --dtype $DT --steps 300 --warmup 30 --repeats 5 --no-cpu-baseline --no-table > $OUT/bench_trace.log 2>&1
 cp $OUT/trace/*/*_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 $GRAFT_REPO_ROOT/bench.py --workload $WL --dtype $DT --steps 50 --warmup 5 --repeats 1 --no-cpu-baseline --no-graph > $OUT/bench_pmc_$C.log 2>&1
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 $GRAFT_REPO_ROOT/bench.py --workload $WL --dtype $DT --steps 50 --warmup 5 --repeats 1 --no-cpu-baseline --no-table --no-graph > $OUT/bench_pmc_$C.log 2>&1
   cp $OUT/pmc_$C/*/*_counter_collection.csv $OUT/pmc_$C.csv 2>/dev/null
 done
 python3 - "$OUT" "$WL" <<'PY'

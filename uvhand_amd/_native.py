@@ -134,14 +134,27 @@ def _compute_dtypes(value, sampling_loc, attn_weight):
 
 
 # Test hook (tests/test_parity_gpu.py): msda_force_path() is THREAD-LOCAL in the library, so that no caller can flip the
-# kernel family under another thread's launch.  The setting made here is replayed on whichever thread performs a native
-# call (autograd runs backward on its own device thread); a process that never calls force_path() pays nothing.
-_forced_path = None
+# kernel family under another thread's launch.  A setting made through force_path() below is applied around each native
+# call on whichever thread performs it (autograd runs backward on its own device thread) and withdrawn right after, so no
+# thread keeps a stale override; a process that never forces a path pays one comparison per call.
+_forced_path = -1
 
 
-def _sync_forced_path(lib):
-    if _forced_path is not None:
-        lib.msda_force_path(_forced_path)
+class _ForcedPathScope:
+    __slots__ = ("lib", "active")
+
+    def __init__(self, lib):
+        self.lib, self.active = lib, _forced_path != -1
+
+    def __enter__(self):
+        if self.active:
+            self.lib.msda_force_path(_forced_path)
+        return self
+
+    def __exit__(self, *exc):
+        if self.active:
+            self.lib.msda_force_path(-1)
+        return False
 
 
 def _raise(lib, rc, what):
@@ -207,13 +220,12 @@ class _DeviceGuard:
 def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
     """Replaces MSDA.ms_deform_attn_forward (vision.cpp:14). Returns out[N, Lq, M*D]."""
     lib = _lib or load()
-    _sync_forced_path(lib)
     _check_inputs((("value", value), ("spatial_shapes", spatial_shapes),
                    ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
                    ("attn_weight", attn_weight)))
     N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step)
     suf = _compute_dtypes(value, sampling_loc, attn_weight)
-    with _DeviceGuard(value.device):
+    with _DeviceGuard(value.device), _ForcedPathScope(lib):
         out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
         rc = _entry(lib, "msda_forward_" + suf, _FWD_ARGTYPES)(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
@@ -245,7 +257,6 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     comes back in float32 (msda_backward_bf16_gv32, include/msda.h; the only bf16 backward outside D = 32).  deterministic (None = deterministic_requested()):
     bitwise reproducible grad_value (MSDA_FLAG_DETERMINISTIC; D = 32 kernel family, fp32 / bf16 rows)."""
     lib = _lib or load()
-    _sync_forced_path(lib)
     _check_inputs((("value", value), ("spatial_shapes", spatial_shapes),
                    ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
                    ("attn_weight", attn_weight), ("grad_output", grad_output)))
@@ -256,7 +267,7 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
                            % (value.dtype, N, Lq, M * D))
     if fp32_grad_value and suf != "bf16":
         raise RuntimeError("fp32_grad_value applies to bfloat16 rows only")
-    with _DeviceGuard(value.device):
+    with _DeviceGuard(value.device), _ForcedPathScope(lib):
         grad_value = torch.empty_like(value, dtype=torch.float32) if fp32_grad_value else torch.empty_like(value)
         grad_loc = torch.empty_like(sampling_loc)
         grad_attn = torch.empty_like(attn_weight)
@@ -346,8 +357,8 @@ def prologue_supported(value, reference_points, sampling_offsets, attn_logits):
     N, S, M, D = value.shape
     Lq, L, P = sampling_offsets.shape[1], sampling_offsets.shape[3], sampling_offsets.shape[4]
     lib = _lib or load()
-    _sync_forced_path(lib)
-    return bool(lib.msda_prologue_supported(N, S, M, D, L, Lq, P))
+    with _ForcedPathScope(lib):
+        return bool(lib.msda_prologue_supported(N, S, M, D, L, Lq, P))
 
 
 def _row_stride(t, name):
@@ -375,8 +386,8 @@ _LL = ctypes.c_longlong
 def prologue_geometry_supported(N, S, M, D, L, Lq, P):
     """msda_prologue_supported (include/msda.h) for fp32 tensors of these sizes."""
     lib = _lib or load()
-    _sync_forced_path(lib)
-    return bool(lib.msda_prologue_supported(N, S, M, D, L, Lq, P))
+    with _ForcedPathScope(lib):
+        return bool(lib.msda_prologue_supported(N, S, M, D, L, Lq, P))
 
 
 def _check_prologue_dtypes(spatial_shapes, level_start_index, **floats):
@@ -395,7 +406,6 @@ def ms_deform_attn_forward_prologue(value, spatial_shapes, level_start_index, re
     what the reference's Python would have computed and are what the backward consumes.  `sampling_offsets`
     [N,Lq,M,L,P,2] and `attn_logits` [N,Lq,M,L*P] may be column blocks of one wider projection output."""
     lib = _lib or load()
-    _sync_forced_path(lib)
     _check_inputs((("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
                    ("reference_points", reference_points)))
     for name, t in (("sampling_offsets", sampling_offsets), ("attn_logits", attn_logits)):
@@ -418,7 +428,7 @@ def ms_deform_attn_forward_prologue(value, spatial_shapes, level_start_index, re
     step = min(N, int(im2col_step))
     if N > 0 and (step <= 0 or N % step != 0):
         raise RuntimeError("batch(%d) must divide im2col_step(%d)" % (N, step))
-    with _DeviceGuard(value.device):
+    with _DeviceGuard(value.device), _ForcedPathScope(lib):
         out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
         loc = torch.empty((N, Lq, M, L, P, 2), dtype=torch.float32, device=value.device)
         attn = torch.empty((N, Lq, M, L, P), dtype=torch.float32, device=value.device)
@@ -438,7 +448,6 @@ def ms_deform_attn_backward_prologue(value, spatial_shapes, level_start_index, s
     merged=True: the two raw gradients are the column blocks [0, 2*M*L*P) and [2*M*L*P, 3*M*L*P) of ONE
     [N, Lq, 3*M*L*P] tensor — the gradient of a merged offsets+logits projection — returned as a fifth value."""
     lib = _lib or load()
-    _sync_forced_path(lib)
     _check_inputs((("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
                    ("sampling_loc", sampling_loc), ("attn_weight", attn_weight), ("grad_output", grad_output)))
     # same checks as the plain backward (the kernels reinterpret device memory: a wrong dtype is silent garbage)
@@ -451,7 +460,7 @@ def ms_deform_attn_backward_prologue(value, spatial_shapes, level_start_index, s
     if grad_output.numel() != N * Lq * M * D:
         raise RuntimeError("ms_deform_attn_backward_prologue: grad_output must be float32[%d,%d,%d]" % (N, Lq, M * D))
     mlp = M * L * P
-    with _DeviceGuard(value.device):
+    with _DeviceGuard(value.device), _ForcedPathScope(lib):
         gv = torch.empty_like(value, dtype=torch.float32)          # fp32 also for bf16 rows (msda_backward_prologue_bf16_gv32)
         if merged:
             both = torch.empty((N, Lq, 3 * mlp), dtype=torch.float32, device=value.device)
@@ -595,13 +604,13 @@ PATH_GENERIC, PATH_D32 = 0, 1          # MSDA_PATH_* (include/msda.h)
 
 
 def path_for(elem_bytes, M, D, L, P):
-    _sync_forced_path(load())
-    return int(load().msda_path_for(ctypes.c_int(elem_bytes), ctypes.c_int(M), ctypes.c_int(D),
-                                    ctypes.c_int(L), ctypes.c_int(P)))
+    with _ForcedPathScope(load()):
+        return int(load().msda_path_for(ctypes.c_int(elem_bytes), ctypes.c_int(M), ctypes.c_int(D),
+                                        ctypes.c_int(L), ctypes.c_int(P)))
 
 
 def force_path(path):
     """Test hook: -1 = automatic selection, PATH_GENERIC = the generic kernels for every call made through this module."""
     global _forced_path
+    load()
     _forced_path = int(path)
-    load().msda_force_path(ctypes.c_int(_forced_path))

@@ -86,6 +86,14 @@ template <typename GT, int THREADS>
 __device__ __forceinline__ void zero_uncovered_rows(const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
                                                     int S, int M, int L, GT *__restrict__ grad_value, int b, int m)
 {
+    // the usual case first, ONE batch of independent scalar loads: every level fits and starts where the previous one ends
+    long long run = 0;
+    bool tiled = true;
+    for (int k = 0; k < L; ++k) {
+        tiled = tiled && level_start[k] == run && level_fits(shapes[2 * k], shapes[2 * k + 1], level_start[k], S);
+        run += shapes[2 * k] * shapes[2 * k + 1];
+    }
+    if (tiled && run == S) return;
     long long cur = 0;                                       // rows below `cur` are dealt with (uniform, scalar unit)
     while (cur < S) {
         long long ns = S, ne = S;                            // the covered interval [ns, ne) that ends after `cur` and starts first

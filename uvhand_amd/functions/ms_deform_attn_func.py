@@ -39,7 +39,7 @@ class MSDeformAttnFunction(Function):
         if (ext is not None and torch.is_tensor(value) and value.is_cuda and value.dtype in _EXT_DTYPES
                 and torch.is_tensor(sampling_locations) and sampling_locations.dtype == value.dtype
                 and torch.is_tensor(attention_weights) and attention_weights.dtype == value.dtype
-                and not torch.is_autocast_enabled() and MSDA._forced_path is None):
+                and not torch.is_autocast_enabled() and MSDA._forced_path == -1):
             return ext.apply(value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights,
                              int(im2col_step), MSDA.deterministic_requested())
         return super().apply(value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights,
@@ -49,10 +49,9 @@ class MSDeformAttnFunction(Function):
     def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations,
                 attention_weights, im2col_step):
         ctx.im2col_step = im2col_step
-        cdt = _compute_dtype(sampling_locations)
+        cdt, loc, attn = _compute_dtype(sampling_locations, attention_weights)
         output = MSDA.ms_deform_attn_forward(
-            value.to(cdt), value_spatial_shapes, value_level_start_index,
-            sampling_locations.to(cdt), attention_weights.to(cdt), ctx.im2col_step)
+            value.to(cdt), value_spatial_shapes, value_level_start_index, loc, attn, ctx.im2col_step)
         ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index,
                               sampling_locations, attention_weights)
         return output
@@ -62,23 +61,26 @@ class MSDeformAttnFunction(Function):
     def backward(ctx, grad_output):
         value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights = \
             ctx.saved_tensors
-        cdt = _compute_dtype(sampling_locations)
+        cdt, loc, attn = _compute_dtype(sampling_locations, attention_weights)
         # the reference asserts contiguity of grad_output (ms_deform_attn_cuda.cu:98) and would
         # raise on e.g. an expanded gradient; making it contiguous is the superset behaviour.
         grad_value, grad_sampling_loc, grad_attn_weight = MSDA.ms_deform_attn_backward(
-            value.to(cdt), value_spatial_shapes, value_level_start_index,
-            sampling_locations.to(cdt), attention_weights.to(cdt), grad_output.to(cdt).contiguous(), ctx.im2col_step)
-        if cdt != sampling_locations.dtype or cdt != attention_weights.dtype:       # half inputs: gradients in their dtypes
+            value.to(cdt), value_spatial_shapes, value_level_start_index, loc, attn,
+            grad_output.to(cdt).contiguous(), ctx.im2col_step)
+        if loc is not sampling_locations:                                           # half inputs: gradients in their dtypes
             grad_sampling_loc = grad_sampling_loc.to(sampling_locations.dtype)
             grad_attn_weight = grad_attn_weight.to(attention_weights.dtype)
         return grad_value, None, None, grad_sampling_loc, grad_attn_weight, None
 
 
-def _compute_dtype(sampling_locations):
-    """float32 / float64 locations select the kernel instantiation (the reference: AT_DISPATCH_FLOATING_TYPES,
-    ms_deform_attn_cuda.cu:64); half-precision locations and weights (the amp branch of the dino copy of the module,
-    models/dino/ops/modules/ms_deform_attn.py:124-131, up-casts them before the call) are computed in float32."""
-    return sampling_locations.dtype if sampling_locations.dtype in _EXT_DTYPES else torch.float32
+def _compute_dtype(sampling_locations, attention_weights):
+    """(compute dtype, locations, weights as handed to the kernels).  float32 / float64 locations select the kernel
+    instantiation (the reference: AT_DISPATCH_FLOATING_TYPES, ms_deform_attn_cuda.cu:64) and are passed on untouched — a
+    weights tensor of another dtype then raises as in the reference.  Half-precision locations (the amp branch of the dino
+    copy of the module, models/dino/ops/modules/ms_deform_attn.py:124-131, up-casts before the call) are computed in float32."""
+    if sampling_locations.dtype in _EXT_DTYPES:
+        return sampling_locations.dtype, sampling_locations, attention_weights
+    return torch.float32, sampling_locations.float(), attention_weights.float()
 
 
 class MSDeformAttnBF16Function(Function):
@@ -100,7 +102,7 @@ class MSDeformAttnBF16Function(Function):
                 and value.dtype in (torch.float32, torch.bfloat16) and torch.is_tensor(sampling_locations)
                 and sampling_locations.is_floating_point() and torch.is_tensor(attention_weights)
                 and attention_weights.is_floating_point() and not torch.is_autocast_enabled()
-                and MSDA._forced_path is None):
+                and MSDA._forced_path == -1):
             return ext.apply_bf16(value, value_spatial_shapes, value_level_start_index, sampling_locations,
                                   attention_weights, int(im2col_step), MSDA.deterministic_requested())
         return super().apply(value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights,
