@@ -147,6 +147,10 @@ int msda_backward_passes(int Lq, int P);
  * It costs 1.5-2x the default backward (profiles/r02_notes.md).  Replaces the same reference functions as
  * msda_backward_*. */
 #define MSDA_FLAG_DETERMINISTIC 1u
+/* msda_backward_workspace_bytes only: the size is asked for a msda_backward_prologue_* call (on large problems its
+ * grad_sampling_loc / grad_attn_weight workgroups see one head each and leave the reference-point gradient per head in
+ * the scratch; without scratch the call runs the kernels that need none). */
+#define MSDA_FLAG_PROLOGUE 2u
 unsigned long long msda_backward_workspace_bytes(int N, int S, int M, int D, int L, int Lq, int P, unsigned flags);
 int msda_backward_ws_f32(const float *grad_out, const float *value, const int64_t *spatial_shapes,
                          const int64_t *level_start, const float *sampling_loc, const float *attn_weight,

@@ -167,6 +167,7 @@ _FWD_ARGTYPES = [_VP] * 5 + [_CI] * 7 + [_VP, _VP]
 _BWD_ARGTYPES = [_VP] * 6 + [_CI] * 7 + [_VP] * 4
 _BWD_WS_ARGTYPES = [_VP] * 6 + [_CI] * 7 + [_VP] * 4 + [ctypes.c_ulonglong, ctypes.c_uint, _VP]
 FLAG_DETERMINISTIC = 1                                # MSDA_FLAG_DETERMINISTIC (include/msda.h)
+FLAG_PROLOGUE = 2                                     # MSDA_FLAG_PROLOGUE
 
 
 def deterministic_requested():
@@ -235,11 +236,11 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     return out
 
 
-def _backward_workspace(lib, N, S, M, D, L, Lq, P, device):
-    """Scratch for the deterministic grad_value path (msda_backward_workspace_bytes, include/msda.h): a stream-ordered
+def _backward_workspace(lib, N, S, M, D, L, Lq, P, device, flags=FLAG_DETERMINISTIC):
+    """Scratch a backward call with these flags can use (msda_backward_workspace_bytes, include/msda.h): a stream-ordered
     torch buffer, or (None, 0) when the call needs none.  The caller keeps it alive until the launch is queued;
     the caching allocator only hands the block out again to work queued later on the same stream."""
-    nbytes = int(lib.msda_backward_workspace_bytes(N, S, M, D, L, Lq, P, FLAG_DETERMINISTIC))
+    nbytes = int(lib.msda_backward_workspace_bytes(N, S, M, D, L, Lq, P, flags))
     if nbytes == 0:
         return None, 0
     return torch.empty((nbytes,), dtype=torch.uint8, device=device), nbytes
@@ -473,7 +474,8 @@ def ms_deform_attn_backward_prologue(value, spatial_shapes, level_start_index, s
             ld_off = ld_log = 0
         gref = torch.empty((N, Lq, L, 2), dtype=torch.float32, device=value.device)
         det = deterministic_requested() if deterministic is None else bool(deterministic)
-        ws, nbytes = _backward_workspace(lib, N, S, M, D, L, Lq, P, value.device) if det else (None, 0)
+        ws, nbytes = _backward_workspace(lib, N, S, M, D, L, Lq, P, value.device,
+                                         FLAG_PROLOGUE | (FLAG_DETERMINISTIC if det else 0))
         rc = _entry(lib, "msda_backward_prologue_bf16_gv32" if bf16 else "msda_backward_prologue_ws_f32",
                     [_VP] * 6 + [_CI] * 7 + [_LL] * 2 + [_VP] * 5 + [ctypes.c_ulonglong, ctypes.c_uint, _VP])(
             grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),

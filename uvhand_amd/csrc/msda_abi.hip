@@ -262,9 +262,8 @@ int msda_backward_passes(int Lq, int P) { return (Lq > 0 && P > 0) ? msda::backw
 unsigned long long msda_backward_workspace_bytes(int N, int S, int M, int D, int L, int Lq, int P, unsigned flags)
 {
     if (N <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Lq <= 0 || P <= 0) return 0;
-    if (!(flags & MSDA_FLAG_DETERMINISTIC)) return 0;                   // only the deterministic path chunks queries
     if (msda::g_force_path == MSDA_PATH_GENERIC) return 0;
-    return (unsigned long long)msda::backward_workspace_bytes(N, S, M, D, L, Lq, P);
+    return (unsigned long long)msda::backward_workspace_bytes(N, S, M, D, L, Lq, P, flags);
 }
 
 int msda_backward_ws_f32(const float *grad_out, const float *value, const int64_t *spatial_shapes,

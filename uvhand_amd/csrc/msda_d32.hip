@@ -132,6 +132,18 @@ __device__ __forceinline__ float dot4(const float4 &a, const float4 &b)
     return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)));
 }
 
+// The three per-tap-set sums of role A from the four <grad_out, tap row> dot products of a lane's channels
+// (ms_deform_im2col_cuda.cuh:116-158: grad_attn, and the pixel-space location gradients before the W / H scaling).
+// Explicit fmaf chains: every role-A kernel (this file and msda_d32_lds.h) gets the same contraction, bit for bit.
+__device__ __forceinline__ void tap_sums(float lh, float lw, float a, float d1, float d2, float d3, float d4, float &s_a,
+                                         float &s_x, float &s_y)
+{
+    const float hh = 1.f - lh, hw = 1.f - lw;
+    s_a = fmaf(lh * lw, d4, fmaf(lh * hw, d3, fmaf(hh * lw, d2, (hh * hw) * d1)));
+    s_x = a * fmaf(lh, d4 - d3, hh * (d2 - d1));
+    s_y = a * fmaf(lw, d4 - d2, hw * (d3 - d1));
+}
+
 // Sum over the 8 lanes that share an item (lanes 8k..8k+7), on the VALU's DPP path — no LDS
 // crossbar round trips: quad_perm [1,0,3,2], quad_perm [2,3,0,1], then row_half_mirror (lane j of
 // each 8-lane half-row reads lane 7-j, which by then holds the other quad's sum).
@@ -402,9 +414,8 @@ __device__ __forceinline__ void bwd_query_body(
                         atomicAdd(d, c * g4.x); atomicAdd(d + 1, c * g4.y); atomicAdd(d + 2, c * g4.z); atomicAdd(d + 3, c * g4.w); }
             }
             const float d1 = dot4(g4, v[u][0]), d2 = dot4(g4, v[u][1]), d3 = dot4(g4, v[u][2]), d4 = dot4(g4, v[u][3]);
-            float s_a = k1 * d1 + k2 * d2 + k3 * d3 + k4 * d4;
-            float s_x = a * (hh * (d2 - d1) + lh * (d4 - d3));
-            float s_y = a * (hw * (d3 - d1) + lw * (d4 - d2));
+            float s_a, s_x, s_y;
+            tap_sums(lh, lw, a, d1, d2, d3, d4, s_a, s_x, s_y);
             s_a = octlane_sum(s_a); s_x = octlane_sum(s_x); s_y = octlane_sum(s_y);
             if (j == 0 && p < LP) res[il * LP + p] = make_float4(s_x, s_y, s_a, 0.f);
         }
@@ -467,6 +478,7 @@ __global__ __launch_bounds__(kBlock) void bwd_query_d32_kernel(
 }
 
 }  // namespace msda
+#include "msda_d32_lds.h"        // large problems: forward and role A with the coarse levels served from LDS
 #include "msda_d32_value.h"      // role B, per-tap records: gathers, bwd_value_body, bwd_value_wide_body, value_block_to_range
 namespace msda {
 
@@ -514,6 +526,31 @@ __global__ __launch_bounds__(kSBlock, 4) void bwd_fused_d32_kernel(
         bwd_query_body<SPLIT, false, kSBlock, VT, FUSED>(grad_out, value, shapes, level_start, loc, attn, S, M, L, Lq, P,
                                                      items, p_shift, lp_shift, m_shift, static_cast<VT *>(nullptr), grad_loc, grad_attn,
                                                      xcd ? xcd_block(bid - nB, (int)gridDim.x - nB) : bid - nB, smem, pro);
+    }
+}
+
+// The same single launch for LARGE problems: role B as above, role A on the LDS-stage body of msda_d32_lds.h (chunks of
+// one (batch, head) pair's queries, coarse levels served from LDS).  Both roles are 512-thread workgroups, two per CU.
+template <int ACC, typename VT, bool FUSED, typename GT, int NS>
+__global__ __launch_bounds__(kSBlock, 4) void bwd_fused_lds_d32_kernel(
+    const VT *__restrict__ grad_out, const VT *__restrict__ value, const int64_t *__restrict__ shapes,
+    const int64_t *__restrict__ level_start, const float *__restrict__ loc, const float *__restrict__ attn, int S, int M, int L,
+    int Lq, int P, int p_shift, int lp_shift, int tp_cap, int W, int nB, int chunks, int qw, int stage_rows,
+    GT *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attn, const PrologueOut pro, int xcd)
+{
+    static_assert(kSBlock == kLBlock, "both roles run in 512-thread workgroups");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int bid = (int)blockIdx.x;
+    if (bid < nB) {
+        if (xcd) bid = xcd_block(bid, nB);
+        int pr, l, ti, Wl;
+        value_block_to_range(bid, W, L, shapes, pr, l, ti, Wl, ACC != kAccWide);
+        bwd_value_body<ACC, kSinglePPT, VT, GT, false>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, tp_cap,
+                                                       grad_value, ti, Wl, l, pr, smem);
+    } else {
+        bwd_query_lds_body<VT, FUSED, NS>(grad_out, value, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, lp_shift, chunks,
+                                          qw, stage_rows, grad_loc, grad_attn, pro,
+                                          xcd ? xcd_block(bid - nB, (int)gridDim.x - nB) : bid - nB, smem);
     }
 }
 
@@ -618,11 +655,77 @@ static int pick_split(int items, int LP)
     return 1;
 }
 
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static int allow_lds(const void *fn, size_t bytes);
+
+// Large problems take the LDS-stage kernels of msda_d32_lds.h: `chunks` workgroups per (batch, head) pair, each staging the
+// pair's coarse levels once and serving `qw` queries in sub-batches of 64.  At least ~1024 workgroups (two resident per
+// CU, 512 threads each) unless that would leave fewer than one sub-batch per workgroup; MSDA_LDS=0/1 overrides (tuning).
+struct LdsPlan { bool use; int chunks, qw, stage_rows; size_t lds; };
+template <typename VT>
+static LdsPlan plan_lds(int N, int S, int M, int L, int Lq, int P)
+{
+    static const int mode = env_int("MSDA_LDS", -1);
+    static const int target = env_int("MSDA_LDS_WGS", 512);              // two 512-thread workgroups per CU: ONE round
+    LdsPlan pl;
+    const long long pairs = (long long)N * M, items = pairs * Lq;
+    pl.stage_rows = min(S, kLStageBytes / (int)(kD * sizeof(VT)));
+    // chunks per pair: the whole launch resident at once when possible (every workgroup stages its pair's levels once and
+    // all of them finish together), but at least one octet per wavefront; qw a multiple of 8 queries
+    const int octets = ceil_div(Lq, 8);
+    const int want_chunks = (int)max(1LL, min((long long)ceil_div(octets, kLWaves), (target + pairs - 1) / pairs));
+    pl.qw = 8 * ceil_div(octets, want_chunks);
+    pl.chunks = ceil_div(Lq, pl.qw);
+    pl.lds = lds_variant_bytes<VT>(pl.stage_rows, L * P);
+    const bool large = items >= 32768 && Lq >= kLItems;                       // below that the launch is latency-bound
+    // (a batch element's slice of `value` is addressed through a buffer descriptor with 32-bit byte offsets)
+    // L*P <= 16: two point slots per lane and octet (with more, role A's look-ahead registers spill)
+    pl.use = (mode < 0 ? large : mode != 0) && pairs * pl.chunks <= 0x7fffffffLL && Lq > 0 && L * P <= 16 &&
+             (long long)S * M * kD * (long long)sizeof(VT) < (1LL << 31);
+    return pl;
+}
+
+template <typename VT, bool FUSED>
+static int launch_fwd_lds(const LdsPlan &lp, const VT *value, const int64_t *shapes, const int64_t *level_start, const float *loc,
+                          const float *attn, int N, int S, int M, int L, int Lq, int P, VT *out, const PrologueIn &pro,
+                          hipStream_t stream)
+{
+    const dim3 grid((unsigned)(N * M * lp.chunks));
+#define MSDA_LAUNCH_FL(NS_)                                                                            \
+    do { if (int rc = allow_lds(reinterpret_cast<const void *>(fwd_d32_lds_kernel<VT, FUSED, NS_>), lp.lds)) return rc;            \
+         hipLaunchKernelGGL((fwd_d32_lds_kernel<VT, FUSED, NS_>), grid, dim3(kLBlock), lp.lds, stream, value, shapes, level_start, \
+                            loc, attn, S, M, L, Lq, P, pow2_shift(P), pow2_shift(L * P), lp.chunks, lp.qw, lp.stage_rows, out,   \
+                            pro, xcd_remap()); } while (0)
+    if (8 * L * P <= kWave) MSDA_LAUNCH_FL(1); else MSDA_LAUNCH_FL(2);             // plan_lds: L*P <= 16
+#undef MSDA_LAUNCH_FL
+    return check_launch("msda forward (d32, LDS stage)");
+}
+
+template <typename VT, bool FUSED>
+static int launch_query_lds(const LdsPlan &lp, const VT *grad_out, const VT *value, const int64_t *shapes,
+                            const int64_t *level_start, const float *loc, const float *attn, int N, int S, int M, int L, int Lq,
+                            int P, float *grad_loc, float *grad_attn, const PrologueOut &pro, hipStream_t stream)
+{
+    const dim3 grid((unsigned)(N * M * lp.chunks));
+#define MSDA_LAUNCH_QL(NS_)                                                                            \
+    do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_query_d32_lds_kernel<VT, FUSED, NS_>), lp.lds)) return rc;      \
+         hipLaunchKernelGGL((bwd_query_d32_lds_kernel<VT, FUSED, NS_>), grid, dim3(kLBlock), lp.lds, stream, grad_out, value,      \
+                            shapes, level_start, loc, attn, S, M, L, Lq, P, pow2_shift(P), pow2_shift(L * P), lp.chunks, lp.qw,  \
+                            lp.stage_rows, grad_loc, grad_attn, pro, xcd_remap()); } while (0)
+    if (8 * L * P <= kWave) MSDA_LAUNCH_QL(1); else MSDA_LAUNCH_QL(2);             // plan_lds: L*P <= 16
+#undef MSDA_LAUNCH_QL
+    return check_launch("msda backward (d32, query-major, LDS stage)");
+}
+
 template <typename VT>
 static int launch_fwd_d32_t(const VT *value, const int64_t *shapes, const int64_t *level_start,
                             const float *loc, const float *attn, int N, int S, int M, int L, int Lq, int P,
                             VT *out, hipStream_t stream)
 {
+    const LdsPlan lp = plan_lds<VT>(N, S, M, L, Lq, P);
+    if (lp.use)
+        return launch_fwd_lds<VT, false>(lp, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, out,
+                                         PrologueIn{nullptr, nullptr, nullptr, 0, 0}, stream);
     const int items = N * Lq * M, LP = L * P;
     const int item_stride = LP * kRecBytes + kItemPad;
     const int split = pick_split(items, LP);
@@ -638,8 +741,6 @@ static int launch_fwd_d32_t(const VT *value, const int64_t *shapes, const int64_
 #undef MSDA_LAUNCH_FWD
     return check_launch("msda forward (d32)");
 }
-
-static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // Role-B plan (host side; only S, the batch and Lq*P are known here — the level geometry lives on
 // the device): W ranges per level, PPT points per thread per pass, accumulation mode.
@@ -738,11 +839,19 @@ static int cell_cmax(int N, int S, int M, int L, int Lq, int P)
 }
 
 #if MSDA_D32_HAS(0)
-size_t backward_workspace_bytes(int N, int S, int M, int D, int L, int Lq, int P)
+size_t backward_workspace_bytes(int N, int S, int M, int D, int L, int Lq, int P, unsigned flags)
 {
     if (!d32_supported(N, S, M, D, L, Lq, P)) return 0;
-    const int c = cell_cmax(N, S, M, L, Lq, P);
-    return c > 1 ? (size_t)N * M * c * S * kD * sizeof(float) : 0;
+    if (flags & MSDA_FLAG_DETERMINISTIC) {                                    // fp32 slabs of the query chunks (msda_d32_cell.h)
+        const int c = cell_cmax(N, S, M, L, Lq, P);
+        return c > 1 ? (size_t)N * M * c * S * kD * sizeof(float) : 0;
+    }
+    if (flags & MSDA_FLAG_PROLOGUE) {
+        // large problems: role A sees one head per workgroup and leaves the reference-point gradient per head
+        // ([N, Lq, M, L, 2]) for ref_heads_reduce_kernel (the stage plan does not depend on the row type's size here)
+        return plan_lds<float>(N, S, M, L, Lq, P).use ? (size_t)N * Lq * M * L * sizeof(float2) : 0;
+    }
+    return 0;
 }
 #endif
 
@@ -873,6 +982,9 @@ static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *
     const int split = pick_split(items, LP);
     const int ps = pow2_shift(P), lps = pow2_shift(LP), ms = pow2_shift(M);
     const int xcd = xcd_remap();
+    // large problems: role A as its own launch with the coarse levels in LDS (msda_d32_lds.h), role B as its own launch
+    LdsPlan lds_a = plan_lds<VT>(N, S, M, L, Lq, P);
+    if (bwd_mode == 2) lds_a.use = false;
 
 #ifdef MSDA_TUNING
     if (bwd_mode == 2) {
@@ -883,8 +995,25 @@ static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *
     {
         const ValuePlan pl = plan_value<GT>(N, S, M, L, Lq, P, target_wgs);
         const long long nB = (long long)pl.W * N * M * L;
+        // ---- large problems: one launch, role A on the LDS-stage body ----
+        if (bwd_mode == 0 && lds_a.use && pl.ppt == kSinglePPT && (pl.acc == kAccNone || pl.acc == kAccWide) &&
+            nB + (long long)N * M * lds_a.chunks <= 0x7fffffffLL) {
+            const dim3 fgrid((unsigned)(nB + (long long)N * M * lds_a.chunks));
+            const size_t flds = pl.lds > lds_a.lds ? pl.lds : lds_a.lds;
+#define MSDA_LAUNCH_FLD(AC, NS_)                                                                       \
+            do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_fused_lds_d32_kernel<AC, VT, false, GT, NS_>), flds)) return rc; \
+            hipLaunchKernelGGL((bwd_fused_lds_d32_kernel<AC, VT, false, GT, NS_>), fgrid, dim3(kSBlock), flds, stream, grad_out,  \
+                               value, shapes, level_start, loc, attn, S, M, L, Lq, P, ps, lps, pl.tp_cap, pl.W, (int)nB,          \
+                               lds_a.chunks, lds_a.qw, lds_a.stage_rows, grad_value, grad_loc, grad_attn,                        \
+                               PrologueOut{nullptr, 0, 0}, xcd); } while (0)
+            const bool one_slot = 8 * LP <= kWave;
+            if (pl.acc == kAccNone) { if (one_slot) MSDA_LAUNCH_FLD(kAccNone, 1); else MSDA_LAUNCH_FLD(kAccNone, 2); }
+            else                    { if (one_slot) MSDA_LAUNCH_FLD(kAccWide, 1); else MSDA_LAUNCH_FLD(kAccWide, 2); }
+#undef MSDA_LAUNCH_FLD
+            return check_launch("msda backward (d32, fused, LDS stage)");
+        }
         // ---- whole backward in one launch when role A's workgroups can share the CUs (LDS) ----
-        if (bwd_mode == 0 && pl.ppt == kSinglePPT && pl.acc != kAccTile) {
+        if (bwd_mode == 0 && pl.ppt == kSinglePPT && pl.acc != kAccTile && !lds_a.use) {
             const FusedPlan fp = plan_fused(items, LP, split, nB, pl.acc);
             const int ipw_f = 64 / fp.split;                            // 512-thread role-A workgroups
             const size_t lds_a = (size_t)ipw_f * item_stride + (size_t)ipw_f * LP * 16;
@@ -928,6 +1057,9 @@ static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *
 #undef MSDA_LAUNCH_B
         if (int rc = check_launch("msda backward (d32, grad_value sort+gather)")) return rc;
     }
+    if (lds_a.use)
+        return launch_query_lds<VT, false>(lds_a, grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, grad_loc,
+                                           grad_attn, PrologueOut{nullptr, 0, 0}, stream);
     {
         const int ipw = 32 / split;
         const size_t lds = (size_t)ipw * item_stride + (size_t)ipw * LP * 16;
@@ -974,6 +1106,8 @@ static int launch_fwd_prologue_t(const VT *value, const int64_t *shapes, const i
     const size_t lds = (size_t)ipw * item_stride + (split > 1 ? 4096 : 0);
     const dim3 grid((items + ipw - 1) / ipw), block(kBlock);
     const PrologueIn pro{ref, loc_out, attn_out, (int)((ld_offsets - 2LL * M * LP) / 2), (int)(ld_logits - (long long)M * LP)};
+    const LdsPlan lp = plan_lds<VT>(N, S, M, L, Lq, P);
+    if (lp.use) return launch_fwd_lds<VT, true>(lp, value, shapes, level_start, offsets, logits, N, S, M, L, Lq, P, out, pro, stream);
     const int xcd = xcd_remap();
 #define MSDA_LAUNCH_FP(SP)                                                                             \
     hipLaunchKernelGGL((fwd_d32_kernel<SP, VT, true>), grid, block, lds, stream, value, shapes, level_start, offsets, \
@@ -1006,9 +1140,32 @@ static int launch_bwd_prologue_t(const VT *grad_out, const VT *value, const int6
     const long long nA = (items + ipw_f - 1) / ipw_f;
     if (pl.ppt != kSinglePPT || pl.acc == kAccTile || nB + nA > 0x7fffffffLL)
         return set_error(MSDA_ERR_ARGUMENT, "msda backward (fused prologue): geometry not supported");
+    const PrologueOut pro{grad_ref, (int)((ld_grad_offsets - 2LL * M * LP) / 2), (int)(ld_grad_logits - (long long)M * LP)};
+    // ---- large problems: role A on the LDS-stage body; it leaves grad_ref per head in the caller's scratch ----
+    const LdsPlan lq = plan_lds<VT>(N, S, M, L, Lq, P);
+    const size_t heads_bytes = (size_t)N * Lq * M * L * sizeof(float2);
+    if (lq.use && workspace != nullptr && ws_bytes >= heads_bytes && ((uintptr_t)workspace & 7) == 0 &&
+        (pl.acc == kAccNone || pl.acc == kAccWide) && nB + (long long)N * M * lq.chunks <= 0x7fffffffLL) {
+        const PrologueOut pro_h{static_cast<float *>(workspace), pro.off_pad, pro.log_pad};
+        const dim3 lgrid((unsigned)(nB + (long long)N * M * lq.chunks));
+        const size_t llds = pl.lds > lq.lds ? pl.lds : lq.lds;
+#define MSDA_LAUNCH_BPL(AC, NS_)                                                                       \
+        do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_fused_lds_d32_kernel<AC, VT, true, float, NS_>), llds)) return rc; \
+        hipLaunchKernelGGL((bwd_fused_lds_d32_kernel<AC, VT, true, float, NS_>), lgrid, dim3(kSBlock), llds, stream, grad_out,   \
+                           value, shapes, level_start, loc, attn, S, M, L, Lq, P, ps, lps, pl.tp_cap, pl.W, (int)nB, lq.chunks,   \
+                           lq.qw, lq.stage_rows, grad_value, grad_offsets, grad_logits, pro_h, xcd_remap()); } while (0)
+        const bool one_slot = 8 * LP <= kWave;
+        if (pl.acc == kAccNone) { if (one_slot) MSDA_LAUNCH_BPL(kAccNone, 1); else MSDA_LAUNCH_BPL(kAccNone, 2); }
+        else                    { if (one_slot) MSDA_LAUNCH_BPL(kAccWide, 1); else MSDA_LAUNCH_BPL(kAccWide, 2); }
+#undef MSDA_LAUNCH_BPL
+        if (int rc = check_launch("msda backward (d32, fused prologue, LDS stage)")) return rc;
+        const long long cells = (long long)N * Lq * L;
+        hipLaunchKernelGGL(ref_heads_reduce_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, stream,
+                           reinterpret_cast<const float2 *>(workspace), N * Lq, M, L, reinterpret_cast<float2 *>(grad_ref));
+        return check_launch("msda backward (d32, reference-point gradient over heads)");
+    }
     const dim3 fgrid((unsigned)(nB + nA));
     const size_t flds = pl.lds > lds_a ? pl.lds : lds_a;
-    const PrologueOut pro{grad_ref, (int)((ld_grad_offsets - 2LL * M * LP) / 2), (int)(ld_grad_logits - (long long)M * LP)};
 #define MSDA_LAUNCH_BP(SP, AC, FX)                                                                     \
     do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_fused_d32_kernel<SP, AC, VT, true, float, FX>), flds)) return rc; \
     hipLaunchKernelGGL((bwd_fused_d32_kernel<SP, AC, VT, true, float, FX>), fgrid, dim3(kSBlock), flds, stream, grad_out, \

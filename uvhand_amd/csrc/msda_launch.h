@@ -47,7 +47,7 @@ int launch_bwd_d32(const float *grad_out, const float *value, const int64_t *sha
                    int M, int L, int Lq, int P, float *grad_value, float *grad_loc, float *grad_attn,
                    hipStream_t stream, void *workspace = nullptr, size_t ws_bytes = 0, bool deterministic = false);
 // scratch the D = 32 backward can use to cut long levels into query chunks (0 = none needed); see msda.h
-size_t backward_workspace_bytes(int N, int S, int M, int D, int L, int Lq, int P);
+size_t backward_workspace_bytes(int N, int S, int M, int D, int L, int Lq, int P, unsigned flags);
 
 // bf16 storage (uint16_t bits) of value / out / grad_out / grad_value; loc, attn and their gradients fp32.
 int launch_fwd_d32_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *level_start,

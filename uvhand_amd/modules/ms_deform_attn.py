@@ -210,7 +210,7 @@ class MSDeformAttn(nn.Module):
             # all-half inputs (amp): float32 inside the op, half outside — the dino copy of the module,
             # models/dino/ops/modules/ms_deform_attn.py:124-131
             output = fn.apply(value.float(), input_spatial_shapes, input_level_start_index, sampling_locations.float(),
-                              attention_weights, self.im2col_step).to(torch.float16)
+                              attention_weights.float(), self.im2col_step).to(torch.float16)
             return bracket_linear(output, self.output_proj)
         output = fn.apply(value, input_spatial_shapes, input_level_start_index, sampling_locations,
                           attention_weights, self.im2col_step)
