@@ -49,6 +49,11 @@ int main(int argc, char **argv)
     // KB_DET=1: the deterministic (cell-sorted) backward with its query-chunk workspace
     const bool det = getenv("KB_DET") && atoi(getenv("KB_DET")) != 0;
     void *ws = nullptr; unsigned long long ws_bytes = 0;
+    if (!det) {                                      // default path: scratch for the level-major point table, if the shape uses one
+        ws_bytes = msda_backward_workspace_bytes(N, S, M, D, L, Lq, P, 0);
+        if (ws_bytes) CK(hipMalloc(&ws, ws_bytes));
+        printf("default backward, workspace %.1f MB\n", ws_bytes / 1e6);
+    }
     if (det) {
         ws_bytes = msda_backward_workspace_bytes(N, S, M, D, L, Lq, P, MSDA_FLAG_DETERMINISTIC);
         if (ws_bytes) CK(hipMalloc(&ws, ws_bytes));
@@ -60,7 +65,7 @@ int main(int argc, char **argv)
     }
     auto bwd = [&] { return det ? msda_backward_ws_f32(go, v, ds, dl, loc, at, N, S, M, D, L, Lq, P, gv, gl, ga, ws, ws_bytes,
                                                        MSDA_FLAG_DETERMINISTIC, st)
-                                : msda_backward_f32(go, v, ds, dl, loc, at, N, S, M, D, L, Lq, P, gv, gl, ga, st); };
+                                : msda_backward_ws_f32(go, v, ds, dl, loc, at, N, S, M, D, L, Lq, P, gv, gl, ga, ws, ws_bytes, 0, st); };
     for (int which = 0; which < 2; ++which) {
         for (int i = 0; i < 5; ++i) if ((which ? bwd() : fwd()) != 0) { printf("launch failed: %s\n", msda_last_error()); return 1; }
         CK(hipStreamSynchronize(st));

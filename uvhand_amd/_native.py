@@ -273,15 +273,18 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
         grad_loc = torch.empty_like(sampling_loc)
         grad_attn = torch.empty_like(attn_weight)
         det = deterministic_requested() if deterministic is None else bool(deterministic)
-        if det and suf != "f64":
-            ws, nbytes = _backward_workspace(lib, N, S, M, D, L, Lq, P, value.device)
+        if suf != "f64":
+            # always through the entry with scratch: large encoder-regime calls use it for the level-major point table
+            # (msda_backward_workspace_bytes says how much; 0 for most shapes), the deterministic kernels for their slabs
+            flags = FLAG_DETERMINISTIC if det else 0
+            ws, nbytes = _backward_workspace(lib, N, S, M, D, L, Lq, P, value.device, flags)
             rc = _entry(lib, "msda_backward_ws_" + suf + ("_gv32" if fp32_grad_value else ""), _BWD_WS_ARGTYPES)(
                 grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
                 sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P,
                 grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(),
-                ws.data_ptr() if ws is not None else None, nbytes, FLAG_DETERMINISTIC, _raw_stream(value.device))
+                ws.data_ptr() if ws is not None else None, nbytes, flags, _raw_stream(value.device))
         else:
-            rc = _entry(lib, "msda_backward_" + suf + ("_gv32" if fp32_grad_value else ""), _BWD_ARGTYPES)(
+            rc = _entry(lib, "msda_backward_" + suf, _BWD_ARGTYPES)(
                 grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
                 sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P,
                 grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(), _raw_stream(value.device))

@@ -93,7 +93,8 @@ std::vector<at::Tensor> backward(const at::Tensor &value, const at::Tensor &shap
     if (value.scalar_type() == at::kFloat) {
         const unsigned flags = deterministic ? MSDA_FLAG_DETERMINISTIC : 0u;
         at::Tensor ws;
-        unsigned long long nbytes = flags ? msda_backward_workspace_bytes(d.N, d.S, d.M, d.D, d.L, d.Lq, d.P, flags) : 0;
+        // (also without flags: large encoder-regime calls use scratch for the level-major point table)
+        unsigned long long nbytes = msda_backward_workspace_bytes(d.N, d.S, d.M, d.D, d.L, d.Lq, d.P, flags);
         if (nbytes) ws = at::empty({(int64_t)nbytes}, value.options().dtype(at::kByte));
         rc = msda_backward_ws_f32(grad_out.data_ptr<float>(), value.data_ptr<float>(), shapes.data_ptr<int64_t>(),
                                   lsi.data_ptr<int64_t>(), loc.data_ptr<float>(), attn.data_ptr<float>(), d.N, d.S, d.M, d.D, d.L,
@@ -205,7 +206,7 @@ public:
         auto gv = at::empty_like(v16, v16.options().dtype(gv32 ? at::kFloat : at::kBFloat16));
         auto gl = at::empty_like(l32), ga = at::empty_like(a32);
         at::Tensor ws;
-        const unsigned long long nbytes = flags ? msda_backward_workspace_bytes(d.N, d.S, d.M, d.D, d.L, d.Lq, d.P, flags) : 0;
+        const unsigned long long nbytes = msda_backward_workspace_bytes(d.N, d.S, d.M, d.D, d.L, d.Lq, d.P, flags);
         if (nbytes) ws = at::empty({(int64_t)nbytes}, v16.options().dtype(at::kByte));
         auto stream = (msda_stream_t)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(v16.device().index()).stream();
         int rc;
