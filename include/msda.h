@@ -142,8 +142,8 @@ int msda_backward_passes(int Lq, int P);
  * always accepted (same result per tile, less parallelism).  The library still allocates nothing.
  * Shapes that are inconsistent with S (a level whose pixels do not lie in [0, S)) never cause an
  * out-of-range access on this path: such a level contributes nothing and pixels no level covers get zeros.
- * The flag concerns the D = 32 kernel family (the models' shape); the generic family (any D, fp64) keeps its
- * global float atomics for grad_value and ignores it.
+ * Outside the D = 32 family (any D, fp64, element-aligned views) the flag selects a destination-major kernel that
+ * adds a pixel's contributions in (query, point) order — no atomics, no scratch, rows x Lq*P point tests of work.
  * It costs 1.5-2x the default backward (profiles/r02_notes.md).  Replaces the same reference functions as
  * msda_backward_*. */
 #define MSDA_FLAG_DETERMINISTIC 1u
@@ -156,6 +156,11 @@ int msda_backward_ws_f32(const float *grad_out, const float *value, const int64_
                          const int64_t *level_start, const float *sampling_loc, const float *attn_weight,
                          int N, int S, int M, int D, int L, int Lq, int P,
                          float *grad_value, float *grad_sampling_loc, float *grad_attn_weight,
+                         void *workspace, unsigned long long workspace_bytes, unsigned flags, msda_stream_t stream);
+int msda_backward_ws_f64(const double *grad_out, const double *value, const int64_t *spatial_shapes,
+                         const int64_t *level_start, const double *sampling_loc, const double *attn_weight,
+                         int N, int S, int M, int D, int L, int Lq, int P,
+                         double *grad_value, double *grad_sampling_loc, double *grad_attn_weight,
                          void *workspace, unsigned long long workspace_bytes, unsigned flags, msda_stream_t stream);
 int msda_backward_ws_bf16(const uint16_t *grad_out, const uint16_t *value, const int64_t *spatial_shapes,
                           const int64_t *level_start, const float *sampling_loc, const float *attn_weight,
@@ -286,7 +291,7 @@ const char *msda_last_error(void);
 /* Library/ABI version (major*100 + minor) and the kernel family a geometry maps to.  MSDA_ABI_VERSION is what a binding
  * compiled against THIS header expects msda_version() to return at run time (uvhand_amd/_ext.py compares the two);
  * it changes whenever a declaration in this file does. */
-#define MSDA_ABI_VERSION 110
+#define MSDA_ABI_VERSION 111
 int msda_version(void);
 int msda_path_for(int elem_bytes, int M, int D, int L, int P);
 

@@ -232,3 +232,25 @@ def test_deterministic_full_size_shapes(native, name):
     assert rel_err(det[0].cpu().numpy(), base[0].cpu().numpy()) < 2e-5
     assert torch.equal(det[1], base[1]) and torch.equal(det[2], base[2])          # role A is the same arithmetic
     assert all(torch.equal(a, b) for a, b in zip(det, det2))
+
+
+@pytest.mark.parametrize("name,dtype", [("testpy_D30", torch.float32), ("wide_D64", torch.float32), ("testpy_D30", torch.float64),
+                                        ("cfg1_like", torch.float32)])
+def test_deterministic_flag_reaches_the_generic_family(native, oracle, name, dtype):
+    """Outside the D = 32 family (any D, fp64, a forced path) MSDA_FLAG_DETERMINISTIC selects the destination-major kernel of
+    msda_generic.hip: grad_value equals the oracle's, identically on every run; grad_loc / grad_attn are the default kernel's."""
+    cases = {"testpy_D30": (3, [(6, 4), (3, 2)], 2, 30, 7, 2), "wide_D64": (2, [(9, 7), (4, 5), (2, 2)], 3, 64, 50, 4),
+             "cfg1_like": (1, [(16, 16), (8, 8)], 8, 32, 60, 4)}
+    z = make_case(11, *cases[name])
+    force = name == "cfg1_like"                              # a D = 32 geometry pushed onto the generic kernels
+    if force:
+        native.force_path(native.PATH_GENERIC)
+    try:
+        runs = [_backward(native, z, deterministic=True, dtype=dtype) for _ in range(3)]
+        base = _backward(native, z, deterministic=False, dtype=dtype)
+    finally:
+        native.force_path(-1)
+    for r in runs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(runs[0], r))
+    assert torch.equal(runs[0][1], base[1]) and torch.equal(runs[0][2], base[2])
+    _check(z, runs[0], oracle)                           # (the oracle runs in the inputs' precision: float32)

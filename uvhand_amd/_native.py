@@ -23,7 +23,8 @@ _lib = None
 _SYMBOLS = (
     "msda_forward_f32", "msda_backward_f32", "msda_forward_f64", "msda_backward_f64",
     "msda_forward_bf16", "msda_backward_bf16", "msda_backward_bf16_gv32", "msda_backward_passes",
-    "msda_backward_workspace_bytes", "msda_backward_ws_f32", "msda_backward_ws_bf16", "msda_backward_ws_bf16_gv32",
+    "msda_backward_workspace_bytes", "msda_backward_ws_f32", "msda_backward_ws_f64", "msda_backward_ws_bf16",
+    "msda_backward_ws_bf16_gv32",
     "msda_backward_prologue_ws_f32", "msda_forward_prologue_bf16", "msda_backward_prologue_bf16_gv32",
     "msda_add_layernorm_workspace_bytes", "msda_add_layernorm_forward_f32", "msda_add_layernorm_backward_f32",
     "msda_flatten_levels_f32", "msda_unflatten_levels_f32", "msda_unflatten_workspace_bytes",
@@ -256,7 +257,7 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     """Replaces MSDA.ms_deform_attn_backward (vision.cpp:15).
     Returns (grad_value, grad_sampling_loc, grad_attn_weight).  fp32_grad_value (bf16 rows only): grad_value
     comes back in float32 (msda_backward_bf16_gv32, include/msda.h; the only bf16 backward outside D = 32).  deterministic (None = deterministic_requested()):
-    bitwise reproducible grad_value (MSDA_FLAG_DETERMINISTIC; D = 32 kernel family, fp32 / bf16 rows)."""
+    bitwise reproducible grad_value (MSDA_FLAG_DETERMINISTIC; every kernel family and dtype)."""
     lib = _lib or load()
     _check_inputs((("value", value), ("spatial_shapes", spatial_shapes),
                    ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
@@ -273,21 +274,15 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
         grad_loc = torch.empty_like(sampling_loc)
         grad_attn = torch.empty_like(attn_weight)
         det = deterministic_requested() if deterministic is None else bool(deterministic)
-        if suf != "f64":
-            # always through the entry with scratch: large encoder-regime calls use it for the level-major point table
-            # (msda_backward_workspace_bytes says how much; 0 for most shapes), the deterministic kernels for their slabs
-            flags = FLAG_DETERMINISTIC if det else 0
-            ws, nbytes = _backward_workspace(lib, N, S, M, D, L, Lq, P, value.device, flags)
-            rc = _entry(lib, "msda_backward_ws_" + suf + ("_gv32" if fp32_grad_value else ""), _BWD_WS_ARGTYPES)(
-                grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
-                sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P,
-                grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(),
-                ws.data_ptr() if ws is not None else None, nbytes, flags, _raw_stream(value.device))
-        else:
-            rc = _entry(lib, "msda_backward_" + suf, _BWD_ARGTYPES)(
-                grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
-                sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P,
-                grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(), _raw_stream(value.device))
+        # always through the entry with flags and scratch (msda_backward_workspace_bytes says how much a call can use: 0 for
+        # most shapes); the deterministic flag reaches every kernel family and dtype
+        flags = FLAG_DETERMINISTIC if det else 0
+        ws, nbytes = _backward_workspace(lib, N, S, M, D, L, Lq, P, value.device, flags)
+        rc = _entry(lib, "msda_backward_ws_" + suf + ("_gv32" if fp32_grad_value else ""), _BWD_WS_ARGTYPES)(
+            grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+            sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P,
+            grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(),
+            ws.data_ptr() if ws is not None else None, nbytes, flags, _raw_stream(value.device))
     if rc != 0:
         _raise(lib, rc, "ms_deform_attn_backward")
     return grad_value, grad_loc, grad_attn

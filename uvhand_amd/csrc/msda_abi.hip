@@ -130,7 +130,7 @@ static int backward_impl(const T *grad_out, const T *value, const int64_t *shape
                                   (flags & MSDA_FLAG_DETERMINISTIC) != 0);
     }
     return launch_bwd_generic<T>(grad_out, value, shapes, level_start, loc, attn, N, S, M, D, L, Lq, P,
-                                 grad_value, grad_loc, grad_attn, stream);
+                                 grad_value, grad_loc, grad_attn, stream, (flags & MSDA_FLAG_DETERMINISTIC) != 0);
 }
 
 }  // namespace msda
@@ -171,7 +171,7 @@ static int backward_bf16_impl(const uint16_t *grad_out, const uint16_t *value, c
         if (!d32)                                                   // element-wise accesses: any D, any element offset
             return msda::launch_bwd_generic<float>(grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, N,
                                                    S, M, D, L, Lq, P, grad_value, grad_sampling_loc, grad_attn_weight,
-                                                   (hipStream_t)stream);
+                                                   (hipStream_t)stream, (flags & MSDA_FLAG_DETERMINISTIC) != 0);
         return msda::launch_bwd_d32_bf16_gv32(grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S,
                                               M, L, Lq, P, grad_value, grad_sampling_loc, grad_attn_weight,
                                               (hipStream_t)stream, workspace, ws_bytes, (flags & MSDA_FLAG_DETERMINISTIC) != 0);
@@ -275,6 +275,17 @@ int msda_backward_ws_f32(const float *grad_out, const float *value, const int64_
     return msda::backward_impl<float>(grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M, D,
                                       L, Lq, P, grad_value, grad_sampling_loc, grad_attn_weight, (hipStream_t)stream,
                                       msda::use_d32(N, S, M, D, L, Lq, P), workspace, (size_t)workspace_bytes, flags);
+}
+
+int msda_backward_ws_f64(const double *grad_out, const double *value, const int64_t *spatial_shapes,
+                         const int64_t *level_start, const double *sampling_loc, const double *attn_weight,
+                         int N, int S, int M, int D, int L, int Lq, int P, double *grad_value,
+                         double *grad_sampling_loc, double *grad_attn_weight, void *workspace,
+                         unsigned long long workspace_bytes, unsigned flags, msda_stream_t stream)
+{
+    return msda::backward_impl<double>(grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M, D,
+                                       L, Lq, P, grad_value, grad_sampling_loc, grad_attn_weight, (hipStream_t)stream, false,
+                                       workspace, (size_t)workspace_bytes, flags);
 }
 
 int msda_backward_ws_bf16(const uint16_t *grad_out, const uint16_t *value, const int64_t *spatial_shapes,

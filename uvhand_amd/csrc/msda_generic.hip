@@ -86,7 +86,8 @@ __global__ __launch_bounds__(kGenericBlock) void fwd_generic_kernel(
 // the channels, written once per point (zero for a point outside the map, as the
 // reference's shared-memory variants produce, ms_deform_im2col_cuda.cuh:365-393).
 // grad_value must be zero on entry (the launcher enqueues the memset).
-template <typename T, typename VT>
+// SCATTER = false (deterministic mode): grad_value is left to bwd_generic_value_det_kernel below.
+template <typename T, typename VT, bool SCATTER>
 __global__ __launch_bounds__(kGenericBlock) void bwd_generic_kernel(
     const VT *__restrict__ grad_out, const VT *__restrict__ value,
     const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
@@ -124,10 +125,10 @@ __global__ __launch_bounds__(kGenericBlock) void bwd_generic_kernel(
                 for (int c = lane; c < D; c += kWave) {
                     const T top = ld_elem<T>(go + c), tv = top * a;
                     T v1 = 0, v2 = 0, v3 = 0, v4 = 0;
-                    if (g.ok00) { v1 = ld_elem<T>(value + r0 + c);      atomicAdd(grad_value + r0 + c, k1 * tv); }
-                    if (g.ok01) { v2 = ld_elem<T>(value + r0 + ws + c); atomicAdd(grad_value + r0 + ws + c, k2 * tv); }
-                    if (g.ok10) { v3 = ld_elem<T>(value + r1 + c);      atomicAdd(grad_value + r1 + c, k3 * tv); }
-                    if (g.ok11) { v4 = ld_elem<T>(value + r1 + ws + c); atomicAdd(grad_value + r1 + ws + c, k4 * tv); }
+                    if (g.ok00) { v1 = ld_elem<T>(value + r0 + c);      if (SCATTER) atomicAdd(grad_value + r0 + c, k1 * tv); }
+                    if (g.ok01) { v2 = ld_elem<T>(value + r0 + ws + c); if (SCATTER) atomicAdd(grad_value + r0 + ws + c, k2 * tv); }
+                    if (g.ok10) { v3 = ld_elem<T>(value + r1 + c);      if (SCATTER) atomicAdd(grad_value + r1 + c, k3 * tv); }
+                    if (g.ok11) { v4 = ld_elem<T>(value + r1 + ws + c); if (SCATTER) atomicAdd(grad_value + r1 + ws + c, k4 * tv); }
                     s_attn += top * (k1 * v1 + k2 * v2 + k3 * v3 + k4 * v4);
                     s_x += (hh * (v2 - v1) + g.lh * (v4 - v3)) * tv;    // d/dw of the bilinear form
                     s_y += (hw * (v3 - v1) + g.lw * (v4 - v2)) * tv;    // d/dh
@@ -137,6 +138,79 @@ __global__ __launch_bounds__(kGenericBlock) void bwd_generic_kernel(
                 s_y = wave_sum(s_y) * (T)H;
             }
             if (lane == 0) { gl[2 * k] = s_x; gl[2 * k + 1] = s_y; ga[k] = s_attn; }
+        }
+    }
+}
+
+// Deterministic grad_value for any D (MSDA_FLAG_DETERMINISTIC outside the D = 32 family; the reference has nothing like it:
+// every one of its backward variants ends in atomicAdd, ms_deform_im2col_cuda.cuh:125-152, 845-920).  Destination-major and
+// brute force: one wavefront owns one (batch, pixel, head) row; its lanes test 64 sampling points of the pixel's level at
+// a time against the pixel, and every hit — taken in (query, point) order, so the sum's association is a pure function of
+// the inputs — adds weight * attention * grad_out row into the lanes' channel accumulators.  Work is rows x Lq*P point tests:
+// fine for the shapes that take this family (test sweeps, odd D), and it needs neither a zero-fill nor scratch.
+constexpr int kDetChunk = 4;                              // channels per lane and pass: 256 channels per sweep over the points
+template <typename T, typename VT>
+__global__ __launch_bounds__(kGenericBlock) void bwd_generic_value_det_kernel(
+    const VT *__restrict__ grad_out, const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
+    const T *__restrict__ loc, const T *__restrict__ attn, int S, int M, int D, int L, int Lq, int P, long long rows,
+    T *__restrict__ grad_value)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const long long row = (long long)blockIdx.x * kGenericItemsPerBlock + (threadIdx.x >> 6);
+    if (row >= rows) return;                              // whole wavefront leaves together
+    const int m = (int)(row % M);
+    const int sp = (int)((row / M) % S);
+    const long long b = row / ((long long)M * S);
+    T *gv = grad_value + row * D;
+    int l = -1, H = 0, W = 0, pix = 0;
+    for (int k = 0; k < L && l < 0; ++k) {                // the (first) level that covers this pixel
+        const long long hk = shapes[2 * k], wk = shapes[2 * k + 1], st = level_start[k];
+        if (level_fits(hk, wk, st, S) && sp >= st && sp < st + hk * wk) { l = k; H = (int)hk; W = (int)wk; pix = sp - (int)st; }
+    }
+    if (l < 0) {                                          // a pixel no level covers: zeros (include/msda.h)
+        for (int c = lane; c < D; c += kWave) gv[c] = 0;
+        return;
+    }
+    const int h = pix / W, w = pix - h * W, LP = L * P;
+    const long long NP = (long long)Lq * P;
+    for (int c0 = 0; c0 < D; c0 += kWave * kDetChunk) {
+        T acc[kDetChunk];
+#pragma unroll
+        for (int k = 0; k < kDetChunk; ++k) acc[k] = 0;
+        for (long long base = 0; base < NP; base += kWave) {
+            const long long idx = base + lane;
+            bool hit = false;
+            T wt = 0, a = 0;
+            long long q = 0;
+            if (idx < NP) {
+                q = idx / P;
+                const long long e = ((b * Lq + q) * M + m) * LP + (long long)l * P + (idx - q * P);
+                const PointGeom<T> g = point_geom<T>(loc[2 * e], loc[2 * e + 1], H, W);
+                const int dh = h - g.h0, dw = w - g.w0;   // the pixel is inside the map: a matching tap is a valid one
+                if (g.inside && (dh == 0 || dh == 1) && (dw == 0 || dw == 1)) {
+                    hit = true;
+                    wt = (dh ? g.lh : 1 - g.lh) * (dw ? g.lw : 1 - g.lw);
+                    a = attn[e];
+                }
+            }
+            unsigned long long mask = __ballot(hit);
+            while (mask) {                                // uniform loop: hits in point order
+                const int src = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const long long qs = __shfl(q, src, kWave);
+                const T ws = __shfl(wt, src, kWave), as = __shfl(a, src, kWave);
+                const VT *go = grad_out + ((b * Lq + qs) * M + m) * D;
+#pragma unroll
+                for (int k = 0; k < kDetChunk; ++k) {
+                    const int c = c0 + k * kWave + lane;
+                    if (c < D) acc[k] += ws * (ld_elem<T>(go + c) * as);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kDetChunk; ++k) {
+            const int c = c0 + k * kWave + lane;
+            if (c < D) gv[c] = acc[k];
         }
     }
 }
@@ -158,14 +232,25 @@ template <typename T, typename VT>
 int launch_bwd_generic(const VT *grad_out, const VT *value, const int64_t *shapes,
                        const int64_t *level_start, const T *loc, const T *attn, int N, int S, int M,
                        int D, int L, int Lq, int P, T *grad_value, T *grad_loc, T *grad_attn,
-                       hipStream_t stream)
+                       hipStream_t stream, bool deterministic)
 {
     const long long items = (long long)N * Lq * M;
     const long long blocks = (items + kGenericItemsPerBlock - 1) / kGenericItemsPerBlock;
     if (blocks > 0x7fffffffLL) return set_error(MSDA_ERR_ARGUMENT, "N*Lq*M too large for one launch");
+    if (deterministic) {
+        const long long rows = (long long)N * S * M, rblocks = (rows + kGenericItemsPerBlock - 1) / kGenericItemsPerBlock;
+        if (rblocks > 0x7fffffffLL) return set_error(MSDA_ERR_ARGUMENT, "N*S*M too large for one launch");
+        hipLaunchKernelGGL((bwd_generic_kernel<T, VT, false>), dim3((unsigned)blocks), dim3(kGenericBlock), 0, stream,
+                           grad_out, value, shapes, level_start, loc, attn, S, M, D, L, Lq, P, items,
+                           grad_value, grad_loc, grad_attn);
+        if (int rc = check_launch("msda backward (generic, grad_loc / grad_attn)")) return rc;
+        hipLaunchKernelGGL((bwd_generic_value_det_kernel<T, VT>), dim3((unsigned)rblocks), dim3(kGenericBlock), 0, stream,
+                           grad_out, shapes, level_start, loc, attn, S, M, D, L, Lq, P, rows, grad_value);
+        return check_launch("msda backward (generic, deterministic grad_value)");
+    }
     hipError_t e = hipMemsetAsync(grad_value, 0, sizeof(T) * (size_t)N * S * M * D, stream);
     if (e != hipSuccess) return set_error(MSDA_ERR_LAUNCH, hipGetErrorString(e));
-    hipLaunchKernelGGL((bwd_generic_kernel<T, VT>), dim3((unsigned)blocks), dim3(kGenericBlock), 0, stream,
+    hipLaunchKernelGGL((bwd_generic_kernel<T, VT, true>), dim3((unsigned)blocks), dim3(kGenericBlock), 0, stream,
                        grad_out, value, shapes, level_start, loc, attn, S, M, D, L, Lq, P, items,
                        grad_value, grad_loc, grad_attn);
     return check_launch("msda backward (generic)");
@@ -175,7 +260,7 @@ int launch_bwd_generic(const VT *grad_out, const VT *value, const int64_t *shape
     template int launch_fwd_generic<T, VT>(const VT *, const int64_t *, const int64_t *, const T *, const T *, int, int, int, \
                                            int, int, int, int, VT *, hipStream_t);                                            \
     template int launch_bwd_generic<T, VT>(const VT *, const VT *, const int64_t *, const int64_t *, const T *, const T *,    \
-                                           int, int, int, int, int, int, int, T *, T *, T *, hipStream_t);
+                                           int, int, int, int, int, int, int, T *, T *, T *, hipStream_t, bool);
 MSDA_GENERIC_INST(float, float)
 MSDA_GENERIC_INST(double, double)
 MSDA_GENERIC_INST(float, uint16_t)       // bf16 rows, fp32 grad_value

@@ -35,7 +35,7 @@ template <typename T, typename VT>
 int launch_bwd_generic(const VT *grad_out, const VT *value, const int64_t *shapes,
                        const int64_t *level_start, const T *loc, const T *attn, int N, int S, int M,
                        int D, int L, int Lq, int P, T *grad_value, T *grad_loc, T *grad_attn,
-                       hipStream_t stream);
+                       hipStream_t stream, bool deterministic = false);
 
 // ---- D = 32 fp32 family (msda_d32.hip): the model's shape ------------------------------------
 bool d32_supported(int N, int S, int M, int D, int L, int Lq, int P);

@@ -90,21 +90,21 @@ std::vector<at::Tensor> backward(const at::Tensor &value, const at::Tensor &shap
     auto gv = at::empty_like(value), gl = at::empty_like(loc), ga = at::empty_like(attn);
     auto stream = (msda_stream_t)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(value.device().index()).stream();
     int rc;
-    if (value.scalar_type() == at::kFloat) {
-        const unsigned flags = deterministic ? MSDA_FLAG_DETERMINISTIC : 0u;
-        at::Tensor ws;
-        // (also without flags: large encoder-regime calls use scratch for the level-major point table)
-        unsigned long long nbytes = msda_backward_workspace_bytes(d.N, d.S, d.M, d.D, d.L, d.Lq, d.P, flags);
-        if (nbytes) ws = at::empty({(int64_t)nbytes}, value.options().dtype(at::kByte));
+    const unsigned flags = deterministic ? MSDA_FLAG_DETERMINISTIC : 0u;
+    at::Tensor ws;
+    // (also without flags: the library says how much scratch a call of this geometry can use, mostly none)
+    const unsigned long long nbytes = msda_backward_workspace_bytes(d.N, d.S, d.M, d.D, d.L, d.Lq, d.P, flags);
+    if (nbytes) ws = at::empty({(int64_t)nbytes}, value.options().dtype(at::kByte));
+    if (value.scalar_type() == at::kFloat)
         rc = msda_backward_ws_f32(grad_out.data_ptr<float>(), value.data_ptr<float>(), shapes.data_ptr<int64_t>(),
                                   lsi.data_ptr<int64_t>(), loc.data_ptr<float>(), attn.data_ptr<float>(), d.N, d.S, d.M, d.D, d.L,
                                   d.Lq, d.P, gv.data_ptr<float>(), gl.data_ptr<float>(), ga.data_ptr<float>(),
                                   nbytes ? ws.data_ptr() : nullptr, nbytes, flags, stream);
-    } else {
-        rc = msda_backward_f64(grad_out.data_ptr<double>(), value.data_ptr<double>(), shapes.data_ptr<int64_t>(),
-                               lsi.data_ptr<int64_t>(), loc.data_ptr<double>(), attn.data_ptr<double>(), d.N, d.S, d.M, d.D, d.L,
-                               d.Lq, d.P, gv.data_ptr<double>(), gl.data_ptr<double>(), ga.data_ptr<double>(), stream);
-    }
+    else
+        rc = msda_backward_ws_f64(grad_out.data_ptr<double>(), value.data_ptr<double>(), shapes.data_ptr<int64_t>(),
+                                  lsi.data_ptr<int64_t>(), loc.data_ptr<double>(), attn.data_ptr<double>(), d.N, d.S, d.M, d.D, d.L,
+                                  d.Lq, d.P, gv.data_ptr<double>(), gl.data_ptr<double>(), ga.data_ptr<double>(),
+                                  nbytes ? ws.data_ptr() : nullptr, nbytes, flags, stream);
     raise_if(rc, "ms_deform_attn_backward");
     return {gv, gl, ga};
 }
@@ -127,7 +127,7 @@ public:
     {
         const auto saved = ctx->get_saved_variables();
         const auto g = ::backward(saved[0].to(saved[3].scalar_type()), saved[1], saved[2], saved[3], saved[4], grads[0],
-                                  ctx->saved_data["step"].toInt(), ctx->saved_data["det"].toBool());
+                                  ctx->saved_data["step"].toInt(), (ctx->saved_data["det"].toBool() || at::globalContext().deterministicAlgorithms()));
         return {g[0], at::Tensor(), at::Tensor(), g[1], g[2], at::Tensor(), at::Tensor()};
     }
 };
@@ -201,7 +201,7 @@ public:
         const bool gv32 = value.scalar_type() == at::kFloat || msda_backward_passes(d.Lq, d.P) > 1 ||
                           msda_path_for(2, d.M, d.D, d.L, d.P) != MSDA_PATH_D32 ||
                           (((uintptr_t)go.data_ptr() | (uintptr_t)v16.data_ptr() | (uintptr_t)l32.data_ptr()) & 7) != 0;
-        const unsigned flags = ctx->saved_data["det"].toBool() ? MSDA_FLAG_DETERMINISTIC : 0u;
+        const unsigned flags = (ctx->saved_data["det"].toBool() || at::globalContext().deterministicAlgorithms()) ? MSDA_FLAG_DETERMINISTIC : 0u;
         c10::hip::HIPGuardMasqueradingAsCUDA guard(v16.device());
         auto gv = at::empty_like(v16, v16.options().dtype(gv32 ? at::kFloat : at::kBFloat16));
         auto gl = at::empty_like(l32), ga = at::empty_like(a32);
