@@ -354,10 +354,18 @@ def main():
     import torch.distributed as dist
     # one rank per GPU; MSDA_BENCH_BACKEND=gloo lets several ranks rehearse the N>1 path on one card
     backend = os.environ.get("MSDA_BENCH_BACKEND", "nccl")
-    dev_index = local_rank % max(1, torch.cuda.device_count())
+    n_dev = torch.cuda.device_count()
+    if backend == "nccl" and world > 1 and local_rank >= n_dev:
+        sys.exit("bench.py: LOCAL_RANK %d but only %d visible GPU(s): RCCL needs one rank per device "
+                 "(MSDA_BENCH_BACKEND=gloo rehearses several ranks on one card)" % (local_rank, n_dev))
+    dev_index = local_rank % max(1, n_dev)
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     harness.init_process_group(backend, device)
+    identities = harness.check_one_rank_per_device(backend if world > 1 else "none", device)   # raises under nccl
+    runtime = harness.collective_runtime()
+    if rank == 0:
+        print("bench: %s" % json.dumps(runtime), file=sys.stderr, flush=True)
 
     from uvhand_amd import _native
     from uvhand_amd.functions import MSDeformAttnBF16Function, MSDeformAttnFunction
@@ -478,11 +486,12 @@ def main():
     elapsed = block_max[len(block_max) // 2]
     ranks_seen = harness.gather_objects({"rank": rank, "local_rank": local_rank, "device": "cuda:%d" % dev_index,
                                          "device_name": torch.cuda.get_device_name(dev_index), "pid": os.getpid(),
+                                         "pci_bus_id": identities[rank]["pci_bus_id"], "uuid": identities[rank]["uuid"],
                                          "seed": harness.rank_seed(1000, rank), "samples": N * args.steps,
                                          "median_block_s": sorted(blocks)[len(blocks) // 2]})
-    print("bench: rank %d/%d backend=%s device=cuda:%d (%s) pid=%d" % (rank, world, backend if world > 1 else "none",
-                                                                    dev_index, torch.cuda.get_device_name(dev_index), os.getpid()),
-          file=sys.stderr, flush=True)
+    print("bench: rank %d/%d backend=%s device=cuda:%d (%s, pci %s) pid=%d" % (
+        rank, world, backend if world > 1 else "none", dev_index, torch.cuda.get_device_name(dev_index),
+        identities[rank]["pci_bus_id"], os.getpid()), file=sys.stderr, flush=True)
 
     if rank == 0:
         fwd_b, bwd_b = algorithmic_bytes(N, S, M, D, L, Lq, P, e=esize)
@@ -509,7 +518,7 @@ def main():
                                                                                   1e3 * block_max[0] / args.steps,
                                                                                   1e3 * block_max[-1] / args.steps),
                        "backend": backend if world > 1 else None},
-            "ranks": ranks_seen,
+            "ranks": ranks_seen, "runtime": runtime,
             "roofline": {"bound": "hbm", "kernel": "backward: msda::bwd_fused_d32_kernel (grad_value sort+gather "
                                                     "workgroups and grad_loc/grad_attn workgroups in one launch)",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,

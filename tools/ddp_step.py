@@ -58,7 +58,7 @@ class SyntheticDeformableStack(nn.Module):
         n = int(ballast_mb * 1e6 / 4)
         self.ballast = nn.Parameter(torch.zeros(n)) if n else None
 
-    def forward(self, src, pos, enc_ref, shapes, lsi):
+    def forward(self, src, pos, enc_ref, shapes, lsi, host_matcher=False, n_losses=0):
         for layer in self.enc:
             src = layer(src, pos, enc_ref, shapes, lsi)
         n = src.shape[0]
@@ -67,10 +67,31 @@ class SyntheticDeformableStack(nn.Module):
         ref = self.ref_head(qpos).sigmoid()[:, :, None, :].expand(-1, -1, shapes.shape[0], -1)
         for layer in self.dec:
             tgt = layer(tgt, qpos, ref, src, shapes, lsi)
-        out = self.out_head(tgt)
-        loss = out.float().pow(2).mean()
+        out = self.out_head(tgt)                            # [n, queries, 64]
+        if host_matcher:
+            # f4: the reference's Hungarian matcher on the critical path (models/matcher.py:120-123): the cost matrix goes
+            # to the host (a device->host sync in the middle of the step), scipy assigns 3 targets (two hands, object) per
+            # frame, and the loss is taken on the matched queries only
+            from scipy.optimize import linear_sum_assignment
+            tgt_key = torch.linspace(-1, 1, 3 * 64, device=out.device).view(3, 64)
+            cost = torch.cdist(out.float().flatten(0, 1), tgt_key, p=1).view(n, out.shape[1], 3).cpu()
+            idx = [linear_sum_assignment(c) for c in cost]
+            rows = torch.as_tensor([i for i, _ in idx], dtype=torch.int64, device=out.device)           # [n, 3]
+            cols = torch.as_tensor([j for _, j in idx], dtype=torch.int64, device=out.device)
+            matched = out.float()[torch.arange(n, device=out.device)[:, None], rows]                     # [n, 3, 64]
+            per = (matched - tgt_key[cols]).pow(2)
+            loss = per.mean() + 1e-3 * out.float().pow(2).mean()
+        else:
+            per = out.float().pow(2)
+            loss = per.mean()
         if self.ballast is not None:
             loss = loss + 0.0 * self.ballast.sum()          # gives the ballast a (zero) gradient to reduce
+        if n_losses:
+            # the loss dictionary the reference reduces for logging every step (engine.py:617 -> util/misc.py:186-192):
+            # ~120 scalar tensors (every loss term x every decoder layer's auxiliary output)
+            flat = per.detach().reshape(-1)
+            chunk = max(1, flat.numel() // n_losses)
+            return loss, {"loss_%03d" % i: flat[i * chunk:(i + 1) * chunk].mean() for i in range(n_losses)}
         return loss
 
 
@@ -89,6 +110,11 @@ def main():
                     help="f4 A/B: the reference's per-step barrier() + all_reduce(num_err) skip vote (engine.py:564-572)")
     ap.add_argument("--find-unused", action="store_true",
                     help="f4 A/B: DistributedDataParallel(find_unused_parameters=True) as in main.py:97")
+    ap.add_argument("--reduce-dict", action="store_true",
+                    help="f4 A/B: per-step reduce_dict of ~120 stacked loss scalars + .item() for logging "
+                         "(engine.py:617-625, util/misc.py:186-192)")
+    ap.add_argument("--host-matcher", action="store_true",
+                    help="f4 A/B: Hungarian matching on the host inside the step (models/matcher.py:120-123: C.cpu() + scipy)")
     ap.add_argument("--plain-layers", action="store_true",
                     help="A/B: stock add + LayerNorm and stock FFN weight gradients inside the layers")
     ap.add_argument("--amp", default="", choices=["", "bf16"],
@@ -97,10 +123,18 @@ def main():
 
     rank, local_rank, world = harness.dist_env()
     backend = os.environ.get("MSDA_BENCH_BACKEND", "nccl")
-    dev_index = local_rank % max(1, torch.cuda.device_count())
+    n_dev = torch.cuda.device_count()
+    if backend == "nccl" and world > 1 and local_rank >= n_dev:
+        sys.exit("ddp_step.py: LOCAL_RANK %d but only %d visible GPU(s): RCCL needs one rank per device" % (local_rank, n_dev))
+    dev_index = local_rank % max(1, n_dev)
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     distributed = harness.init_process_group(backend, device)
+    identities = harness.check_one_rank_per_device(backend if distributed else "none", device)     # raises under nccl
+    runtime = harness.collective_runtime()
+    print("ddp_step: rank %d/%d backend=%s %s pci %s rccl %s visible devices %d" % (
+        rank, world, backend if distributed else "none", identities[rank]["device"], identities[rank]["pci_bus_id"],
+        runtime["rccl"], runtime["visible_devices"]), file=sys.stderr, flush=True)
 
     torch.manual_seed(harness.rank_seed(0, 0))                  # identical initial weights on every rank
     model = SyntheticDeformableStack(args.enc, args.dec, args.queries, args.ballast_mb, dropout=args.dropout,
@@ -134,11 +168,20 @@ def main():
             if int(num_err.item()) > 0:                     # (the host read is part of what the vote costs)
                 return torch.zeros((), device=device)
         opt.zero_grad(set_to_none=True)
+        kw = dict(host_matcher=args.host_matcher, n_losses=120 if args.reduce_dict else 0)
         if args.amp == "bf16":
             with torch.autocast("cuda", dtype=torch.bfloat16):
-                loss = model(src, pos, enc_ref, shapes, lsi)
+                loss = model(src, pos, enc_ref, shapes, lsi, **kw)
         else:
-            loss = model(src, pos, enc_ref, shapes, lsi)
+            loss = model(src, pos, enc_ref, shapes, lsi, **kw)
+        if args.reduce_dict:
+            loss, loss_dict = loss
+            with torch.no_grad():                           # util/misc.py:186-192, then engine.py's .item() for the logger
+                values = torch.stack([loss_dict[k] for k in sorted(loss_dict)], 0)
+                if distributed:
+                    torch.distributed.all_reduce(values)
+                    values /= world
+                step.logged = float(values.sum().item())
         loss.backward()
         torch.nn.utils.clip_grad_norm_(model.parameters(), 0.1)
         opt.step()
@@ -161,6 +204,7 @@ def main():
         digest = [float(flat.double().sum().item()), float(flat.double().abs().sum().item()),
                   int(flat.view(torch.int32).long().sum().item())]
     digests = harness.gather_objects({"rank": rank, "device": "cuda:%d" % dev_index, "pid": os.getpid(),
+                                      "pci_bus_id": identities[rank]["pci_bus_id"],
                                       "loss": float(loss.detach().item()), "params": digest})
     in_sync = all(d["params"] == digests[0]["params"] for d in digests)
     if rank == 0:
@@ -169,7 +213,9 @@ def main():
                           "per_rank": {"window": args.window, "S": S, "queries": args.queries, "enc": args.enc,
                                        "dec": args.dec, "ballast_mb": args.ballast_mb, "amp": args.amp or None,
                                        "dropout": args.dropout, "layers": "plain" if args.plain_layers else "fused",
-                                       "vote": args.vote, "find_unused_parameters": args.find_unused},
+                                       "vote": args.vote, "find_unused_parameters": args.find_unused,
+                                       "reduce_dict": args.reduce_dict, "host_matcher": args.host_matcher},
+                          "runtime": runtime,
                           "backend": backend if distributed else None, "loss_finite": finite,
                           "params_in_sync": in_sync, "ranks": digests}))
     if distributed:

@@ -88,3 +88,52 @@ def gather_objects(obj):
     out = [None] * dist.get_world_size()
     dist.all_gather_object(out, obj)
     return out
+
+
+def device_identity(device):
+    """What tells two ranks' GPUs apart: index, name, PCI bus id and uuid where this torch exposes them."""
+    if device is None or device.type != "cuda":
+        return {"device": str(device), "index": None, "name": None, "pci_bus_id": None, "uuid": None}
+    props = torch.cuda.get_device_properties(device)
+    bus = getattr(props, "pci_bus_id", None)
+    return {"device": str(device), "index": device.index, "name": props.name,
+            "pci_bus_id": None if bus is None else "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), bus,
+                                                                       getattr(props, "pci_device_id", 0)),
+            "uuid": str(getattr(props, "uuid", "")) or None}
+
+
+def duplicate_devices(identities):
+    """Pairs of ranks that sit on the same physical GPU (same uuid / PCI bus id, or — lacking both — same index)."""
+    seen, dup = {}, []
+    for rank, ident in enumerate(identities):
+        key = ident.get("uuid") or ident.get("pci_bus_id") or ident.get("index")
+        if key is None:
+            continue
+        if key in seen:
+            dup.append((seen[key], rank, key))
+        else:
+            seen[key] = rank
+    return dup
+
+
+def collective_runtime():
+    """Version of the collective library behind backend "nccl" on this build (RCCL on ROCm), device count, HIP version."""
+    info = {"torch": torch.__version__, "hip": getattr(torch.version, "hip", None), "visible_devices": torch.cuda.device_count()}
+    try:
+        info["rccl"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception as exc:                                # no GPU build / no collective library
+        info["rccl"] = "unavailable (%s)" % type(exc).__name__
+    return info
+
+
+def check_one_rank_per_device(backend, device):
+    """Every rank's device identity, gathered; under RCCL two ranks on one GPU is a launch error (it deadlocks or silently
+    serialises): raise on EVERY rank so that the job exits non-zero instead of reporting a number.  Under gloo (the CPU /
+    one-card rehearsal) sharing a device is the point, so it is only reported.  Returns the list of identities."""
+    idents = gather_objects(device_identity(device))
+    dup = duplicate_devices(idents)
+    if dup and backend == "nccl":
+        raise RuntimeError("ranks share a GPU under backend nccl (RCCL needs one rank per device): %s — launch with one "
+                           "process per GPU (torch.distributed.run --nproc-per-node <#GPUs>) and LOCAL_RANK < device_count (%d)"
+                           % (", ".join("ranks %d and %d on %s" % d for d in dup), torch.cuda.device_count()))
+    return idents
