@@ -89,6 +89,38 @@ def test_module_runs_under_autocast_like_reference():
     assert rel_err(out.float().detach().cpu().numpy(), ref.detach().cpu().numpy()) < 2e-2
 
 
+@pytest.mark.parametrize("case", ["module_2d", "module_42d"])
+def test_cpp_module_node_equals_python_composition(case):
+    """The fp32 fused path as ONE C++ autograd node (msda_torch.cpp: module_forward, what runs by default when the torch
+    extension is built) against the same path composed in Python (cpp_node = False): the same kernels in the same order —
+    identical forward, identical gradients except where grad_value's summation order enters (value_proj's parameters and
+    the gradient of src: within 1e-5 of max)."""
+    from uvhand_amd import _ext
+    if _ext.get() is None or not hasattr(_ext.get(), "module_forward"):
+        pytest.skip("torch extension not built")
+    z = load_golden(case)
+    res = []
+    for cpp in (True, False):
+        mod = _module()
+        mod.cpp_node = cpp
+        query = torch.from_numpy(z["query"]).cuda().requires_grad_(True)
+        src = torch.from_numpy(z["src"]).cuda().requires_grad_(True)
+        refp = torch.from_numpy(z["refp"]).cuda().requires_grad_(True)
+        out = mod(query, refp, src, torch.from_numpy(z["shapes"]).cuda(), torch.from_numpy(z["level_start"]).cuda(),
+                  torch.from_numpy(z["mask"]).cuda())
+        assert ("MSDAModuleFunction" in out.grad_fn.name()) == cpp
+        out.backward(torch.from_numpy(z["gout"]).cuda())
+        res.append((out.detach(), query.grad, refp.grad, src.grad, {n: p.grad for n, p in mod.named_parameters()}))
+    a, b = res
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert rel_err(a[3].cpu().numpy(), b[3].cpu().numpy()) < 1e-5
+    for n in a[4]:
+        if n.startswith("value_proj"):
+            assert rel_err(a[4][n].cpu().numpy(), b[4][n].cpu().numpy()) < 1e-5, n
+        else:
+            assert torch.equal(a[4][n], b[4][n]), n
+
+
 def test_half_module_follows_the_dino_amp_branch():
     """module.half() with half inputs: the op runs in float32 and its output returns to half before output_proj
     (models/dino/ops/modules/ms_deform_attn.py:124-131)."""

@@ -74,7 +74,7 @@ class SyntheticDeformableStack(nn.Module):
             # frame, and the loss is taken on the matched queries only
             from scipy.optimize import linear_sum_assignment
             tgt_key = torch.linspace(-1, 1, 3 * 64, device=out.device).view(3, 64)
-            cost = torch.cdist(out.float().flatten(0, 1), tgt_key, p=1).view(n, out.shape[1], 3).cpu()
+            cost = torch.cdist(out.detach().float().flatten(0, 1), tgt_key, p=1).view(n, out.shape[1], 3).cpu().numpy()
             idx = [linear_sum_assignment(c) for c in cost]
             rows = torch.as_tensor([i for i, _ in idx], dtype=torch.int64, device=out.device)           # [n, 3]
             cols = torch.as_tensor([j for _, j in idx], dtype=torch.int64, device=out.device)

@@ -178,6 +178,137 @@ __global__ __launch_bounds__(kWgBlock) void linear_wgrad_partial_kernel(
 
 #undef MSDA_LOAD_STAGE
 
+// ---- bf16 operands on the bf16 MFMA (v_mfma_f32_32x32x16_bf16: 16x the rate of the f32-input form the kernel above uses) ----
+// Under autocast dY and X arrive as bf16.  A product of two bf16 values is exact in fp32 and the MFMA accumulates in fp32, so
+// this loses nothing the widening kernel keeps; it only stops spending 15/16 of the matrix cores' time.
+// Both operands have the REDUCTION index as their row ([M, N] and [M, K] row-major) while the MFMA wants, per lane, 8
+// consecutive reduction steps of one output row / column — a transposed read.  The stage is therefore kept in LDS as 4-row x
+// 16-column blocks of 128 B ([m / 4][col / 16][4][16] bf16), which is exactly what one 16-lane group of ds_read_b64_tr_b16
+// consumes: the hardware delivers each lane its column of the block's four rows.  A 32-lane half reads two neighbouring
+// blocks = 256 contiguous bytes: conflict-free.  Rows of blocks are skewed by 16 B so that the global->LDS copy (8 lanes = 8
+// rows of one 16-byte column chunk) does not land on one bank group.
+constexpr int kBfStage = 32;                               // reduction rows per LDS stage
+constexpr int kBfBlkRow = (kWgTile / 16) * 128 + 16;       // bytes per row of blocks: 4 blocks + skew
+constexpr int kBfOperand = (kBfStage / 4) * kBfBlkRow;     // bytes per operand and buffer (4224)
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using i16x4 = __attribute__((ext_vector_type(4))) short;
+using i16x8 = __attribute__((ext_vector_type(8))) short;
+
+__device__ __forceinline__ i16x4 lds_read_tr16(const unsigned char *p)
+{
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3))) *)p);
+}
+
+__global__ __launch_bounds__(kWgBlock) void linear_wgrad_partial_bf16_kernel(
+    const uint16_t *__restrict__ dY, const uint16_t *__restrict__ X, const uint8_t *__restrict__ row_mask, int M, int N, int K,
+    int chunk, int tiles, int splits, long long slab, float *__restrict__ out_w, float *__restrict__ out_b)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char Ab[2][kBfOperand];
+    __shared__ __attribute__((aligned(16))) unsigned char Bb[2][kBfOperand];
+    __shared__ float bred[kWgBlock][8];                                  // bias partials (k0 == 0 tiles only)
+    const int tiles_k = (K + kWgTile - 1) / kWgTile;
+    int tile, split;
+    tile_and_split((int)blockIdx.x, tiles, splits, tile, split);
+    const int n0 = (tile / tiles_k) * kWgTile, k0 = (tile % tiles_k) * kWgTile;
+    const int m_begin = split * chunk, m_end = min(M, m_begin + chunk);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int i0 = (wave >> 1) * 32, j0 = (wave & 1) * 32, h = lane >> 5, c = lane & 31;
+
+    // global -> registers: one 16-byte chunk (8 bf16) of one row per thread and operand; 8 consecutive lanes take 8 rows of
+    // the same column chunk, a wavefront 8 whole 128-byte rows
+    const int lrow = (tid & 7) + 8 * wave, lchunk = (tid >> 3) & 7;       // stage row 0..31, columns 8*lchunk ..
+    const bool a_ok = n0 + 8 * lchunk < N, b_ok = k0 + 8 * lchunk < K;    // N, K are multiples of 8 (host check)
+    const int st_off = (lrow >> 2) * kBfBlkRow + (lchunk >> 1) * 128 + (lrow & 3) * 32 + (lchunk & 1) * 16;
+    uint4 ra, rb;
+    unsigned mk;
+    const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+#define MSDA_LOAD_STAGE_BF(m0_)                                                                                      \
+    do {                                                                                                            \
+        const int m = (m0_) + lrow;                                                                                 \
+        mk = 0;                                                                                                     \
+        if (row_mask != nullptr && m < m_end) mk = row_mask[m];                                                     \
+        ra = zero; rb = zero;                                                                                       \
+        if (a_ok && m < m_end) ra = *reinterpret_cast<const uint4 *>(dY + (long long)m * N + n0 + 8 * lchunk);      \
+        if (b_ok && m < m_end) rb = *reinterpret_cast<const uint4 *>(X + (long long)m * K + k0 + 8 * lchunk);       \
+    } while (0)
+#define MSDA_STORE_STAGE_BF(buf_)                                                                                    \
+    do {                                                                                                            \
+        const uint4 am = mk == 0 ? ra : zero;                                                                       \
+        *reinterpret_cast<uint4 *>(&Ab[buf_][st_off]) = make_uint4(am.x, am.y, am.z, am.w);                         \
+        *reinterpret_cast<uint4 *>(&Bb[buf_][st_off]) = rb;                                                         \
+        if (do_bias) {                                                                                              \
+            bs[0] += __uint_as_float(am.x << 16); bs[1] += __uint_as_float(am.x & 0xffff0000u);                     \
+            bs[2] += __uint_as_float(am.y << 16); bs[3] += __uint_as_float(am.y & 0xffff0000u);                     \
+            bs[4] += __uint_as_float(am.z << 16); bs[5] += __uint_as_float(am.z & 0xffff0000u);                     \
+            bs[6] += __uint_as_float(am.w << 16); bs[7] += __uint_as_float(am.w & 0xffff0000u);                     \
+        }                                                                                                           \
+    } while (0)
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // bias gradient (k0 == 0 tiles): every thread keeps the column sums of ITS 8 columns over the rows it stages
+    float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = out_b != nullptr && k0 == 0;
+
+    // transposed-read addresses of this lane: block row 2h (+1), column block of output row / column (c >> 4), in-block
+    // row (lane & 15) >> 2 and 8-byte piece lane & 3
+    const int rd = (2 * h) * kBfBlkRow + ((lane & 15) >> 2) * 32 + (lane & 3) * 8;
+    const int a_rd = rd + ((i0 + (c & 16)) >> 4) * 128, b_rd = rd + ((j0 + (c & 16)) >> 4) * 128;
+
+    MSDA_LOAD_STAGE_BF(m_begin);
+    MSDA_STORE_STAGE_BF(0);
+    MSDA_LOAD_STAGE_BF(m_begin + kBfStage);                             // rows past m_end load as zeros
+    __syncthreads();
+    int cur = 0;
+    for (int m0 = m_begin; m0 < m_end; m0 += kBfStage) {
+        const unsigned char *A = Ab[cur], *B = Bb[cur];
+        i16x4 a[4], b[4];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[2 * s + t] = lds_read_tr16(A + a_rd + (4 * s + t) * kBfBlkRow);
+                b[2 * s + t] = lds_read_tr16(B + b_rd + (4 * s + t) * kBfBlkRow);
+            }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const i16x8 av = {a[2 * s].x, a[2 * s].y, a[2 * s].z, a[2 * s].w, a[2 * s + 1].x, a[2 * s + 1].y, a[2 * s + 1].z, a[2 * s + 1].w};
+            const i16x8 bv = {b[2 * s].x, b[2 * s].y, b[2 * s].z, b[2 * s].w, b[2 * s + 1].x, b[2 * s + 1].y, b[2 * s + 1].z, b[2 * s + 1].w};
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0);
+        }
+        if (m0 + kBfStage < m_end) {
+            MSDA_STORE_STAGE_BF(cur ^ 1);
+            if (m0 + 2 * kBfStage < m_end) MSDA_LOAD_STAGE_BF(m0 + 2 * kBfStage);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    float *ow = out_w + (long long)split * slab;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = n0 + i0 + (r & 3) + 8 * (r >> 2) + 4 * h, j = k0 + j0 + c;
+        if (i < N && j < K) ow[(long long)i * K + j] = acc[r];
+    }
+    if (do_bias) {                                                      // uniform per workgroup
+        // thread t holds columns 8*lchunk .. +7 over rows == lrow (mod 32): the 32 threads of a column chunk are
+        // tid = (tid & 7) + 8*lchunk + 64*wave; summed in a fixed order
+#pragma unroll
+        for (int k = 0; k < 8; ++k) bred[tid][k] = bs[k];
+        __syncthreads();
+        if (tid < kWgTile && n0 + tid < N) {
+            const int ch = tid >> 3, k = tid & 7;
+            float sum = 0.f;
+            for (int w = 0; w < 4; ++w)
+                for (int r = 0; r < 8; ++r) sum += bred[r + 8 * ch + 64 * w][k];
+            out_b[(long long)split * slab + n0 + tid] = sum;
+        }
+    }
+}
+#undef MSDA_LOAD_STAGE_BF
+#undef MSDA_STORE_STAGE_BF
+
 // Fixed-order sum of the partial slabs (each slab = [N*K weight partials][N bias partials]):
 // out[e] = sum_k part[k][e]; elements below nw go to dW, the rest to db.  A workgroup takes 64 float4 columns;
 // its 4 wavefronts each sum a quarter of the splits (4 independent loads in flight per lane), and the four
@@ -269,6 +400,12 @@ static int launch_linear_wgrad_t(const OT *dY, const OT *X, const uint8_t *row_m
     const int tiles = ((N + kWgTile - 1) / kWgTile) * ((K + kWgTile - 1) / kWgTile);
     const dim3 grid((unsigned)(tiles * splits));
     auto partial = linear_wgrad_partial_kernel<OT>;
+    if constexpr (sizeof(OT) == 2) {
+        // bf16 operands: the bf16-MFMA kernel whenever whole 16-byte chunks of 8 columns can be moved (else the widening one)
+        static const int use_bf16_mfma = tuning_int("MSDA_WGRAD_BF16_MFMA", 1);
+        if (use_bf16_mfma && N % 8 == 0 && K % 8 == 0 && (((uintptr_t)dY | (uintptr_t)X) & 15) == 0)
+            partial = linear_wgrad_partial_bf16_kernel;
+    }
     if (splits == 1) {
         hipLaunchKernelGGL(partial, grid, dim3(kWgBlock), 0, stream, dY, X, row_mask, M, N, K, chunk, tiles, splits, 0LL, dW, db);
         return check_launch("msda linear wgrad");

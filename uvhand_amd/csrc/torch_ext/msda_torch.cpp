@@ -232,6 +232,138 @@ at::Tensor apply_bf16(const at::Tensor &value, const at::Tensor &shapes, const a
     return MSDABF16Function::apply(value, shapes, lsi, loc, attn, im2col_step, deterministic);
 }
 
+// ---- the whole MSDeformAttn module as ONE autograd node (fp32, fused prologue + merged projection) -------------------------
+// What uvhand_amd/modules/ms_deform_attn.py composes from four Python autograd Functions and ctypes calls — value_proj
+// (+ padding-mask rows), the merged sampling_offsets / attention_weights projection, the fused-prologue sampling kernels,
+// output_proj, and in the backward the input-gradient GEMMs plus the MFMA weight-gradient kernel of every projection
+// (models/ops/modules/ms_deform_attn.py:96-139 and its autograd) — queued from C++ with no Python in between: the eager
+// step at decoder sizes is bound by host time, not by the GPU (profiles/r02_notes.md section 7).  Same kernels, same
+// arithmetic, same results as the Python composition (tests/test_module_gpu.py runs both).
+inline at::Tensor wgrad_into(const at::Tensor &dY2, const at::Tensor &X2, const at::Tensor *mask, at::Tensor &gb, bool want_bias,
+                             msda_stream_t stream)
+{
+    const int M = (int)dY2.size(0), N = (int)dY2.size(1), K = (int)X2.size(1);
+    auto gw = at::empty({N, K}, dY2.options());
+    if (want_bias) gb = at::empty({N}, dY2.options());
+    const unsigned long long nbytes = msda_linear_wgrad_workspace_bytes(M, N, K);
+    at::Tensor ws;
+    if (nbytes) ws = at::empty({(int64_t)nbytes}, dY2.options().dtype(at::kByte));
+    raise_if(msda_linear_wgrad_masked_f32(dY2.data_ptr<float>(), X2.data_ptr<float>(),
+                                          mask ? reinterpret_cast<const uint8_t *>(mask->data_ptr<bool>()) : nullptr, M, N, K,
+                                          gw.data_ptr<float>(), want_bias ? gb.data_ptr<float>() : nullptr,
+                                          nbytes ? ws.data_ptr() : nullptr, stream),
+             "msda_linear_wgrad");
+    return gw;
+}
+
+class MSDAModuleFunction : public torch::autograd::Function<MSDAModuleFunction> {
+public:
+    // inputs 0..2 may need gradients (query, centre = reference point per level, input_flatten), 5..12 are the parameters
+    static at::Tensor forward(torch::autograd::AutogradContext *ctx, const at::Tensor &query, const at::Tensor &centre,
+                              const at::Tensor &input_flatten, const c10::optional<at::Tensor> &mask, const at::Tensor &shapes,
+                              const at::Tensor &lsi, const at::Tensor &w_off, const at::Tensor &b_off, const at::Tensor &w_attn,
+                              const at::Tensor &b_attn, const at::Tensor &w_val, const at::Tensor &b_val, const at::Tensor &w_out,
+                              const at::Tensor &b_out, int64_t n_heads, int64_t n_levels, int64_t n_points, int64_t im2col_step,
+                              bool deterministic)
+    {
+        const int N = (int)query.size(0), Lq = (int)query.size(1), C = (int)query.size(2), S = (int)input_flatten.size(1);
+        const int M = (int)n_heads, L = (int)n_levels, P = (int)n_points, D = C / M, mlp = M * L * P;
+        TORCH_CHECK(msda_prologue_supported(N, S, M, D, L, Lq, P), "MSDeformAttn (C++ node): geometry outside the fused prologue");
+        const int64_t step = std::min<int64_t>(N, im2col_step);
+        TORCH_CHECK(N == 0 || (step > 0 && N % step == 0), "batch(", N, ") must divide im2col_step(", step, ")");
+        c10::hip::HIPGuardMasqueradingAsCUDA guard(query.device());
+        auto stream = (msda_stream_t)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(query.device().index()).stream();
+        const at::Tensor q2 = query.contiguous(), x2 = input_flatten.contiguous(), c2 = centre.contiguous();
+        at::Tensor rmask;
+        if (mask.has_value() && mask->defined()) rmask = mask->reshape({-1}).contiguous();
+        // value_proj (+ the padding mask on the masked rows only)
+        at::Tensor value = at::linear(x2, w_val, b_val);                                      // [N, S, C]
+        if (rmask.defined())
+            raise_if(msda_zero_masked_rows_f32(value.data_ptr<float>(), reinterpret_cast<const uint8_t *>(rmask.data_ptr<bool>()),
+                                               (long long)N * S, C, stream), "msda_zero_masked_rows");
+        // sampling_offsets and attention_weights as ONE GEMM (both read the same query); the kernels read its output in place
+        const at::Tensor wm = at::cat({w_off, w_attn}, 0), bm = at::cat({b_off, b_attn}, 0);
+        const at::Tensor projected = at::linear(q2, wm, bm);                                  // [N, Lq, 3*mlp]
+        auto sampled = at::empty({N, Lq, C}, q2.options());
+        auto loc = at::empty({N, Lq, M, L, P, 2}, q2.options()), attn = at::empty({N, Lq, M, L, P}, q2.options());
+        raise_if(msda_forward_prologue_f32(value.data_ptr<float>(), shapes.data_ptr<int64_t>(), lsi.data_ptr<int64_t>(),
+                                           c2.data_ptr<float>(), projected.data_ptr<float>(), projected.data_ptr<float>() + 2 * mlp,
+                                           N, S, M, D, L, Lq, P, 3LL * mlp, 3LL * mlp, sampled.data_ptr<float>(),
+                                           loc.data_ptr<float>(), attn.data_ptr<float>(), stream),
+                 "ms_deform_attn_forward_prologue");
+        ctx->save_for_backward({q2, x2, rmask.defined() ? rmask : at::Tensor(), value, loc, attn, sampled, wm, w_val, w_out, shapes, lsi});
+        ctx->saved_data["dims"] = std::vector<int64_t>{N, S, M, D, L, Lq, P, C};
+        ctx->saved_data["det"] = deterministic;
+        return at::linear(sampled, w_out, b_out);
+    }
+
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext *ctx, torch::autograd::variable_list grads)
+    {
+        const auto sv = ctx->get_saved_variables();
+        const at::Tensor &q2 = sv[0], &x2 = sv[1], &rmask = sv[2], &value = sv[3], &loc = sv[4], &attn = sv[5], &sampled = sv[6],
+                         &wm = sv[7], &w_val = sv[8], &w_out = sv[9], &shapes = sv[10], &lsi = sv[11];
+        const auto dims = ctx->saved_data["dims"].toIntVector();
+        const int N = (int)dims[0], S = (int)dims[1], M = (int)dims[2], D = (int)dims[3], L = (int)dims[4], Lq = (int)dims[5],
+                  P = (int)dims[6], C = (int)dims[7], mlp = M * L * P;
+        c10::hip::HIPGuardMasqueradingAsCUDA guard(q2.device());
+        auto stream = (msda_stream_t)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(q2.device().index()).stream();
+        const at::Tensor go2 = grads[0].contiguous().view({(int64_t)N * Lq, C});
+        const at::Tensor *maskp = rmask.defined() ? &rmask : nullptr;
+        // output_proj
+        at::Tensor gb_out, gb_m, gb_val;
+        const at::Tensor g_sampled = at::matmul(go2, w_out);                                   // [N*Lq, C]
+        const at::Tensor gw_out = wgrad_into(go2, sampled.view({(int64_t)N * Lq, C}), nullptr, gb_out, true, stream);
+        // the sampling kernels: gradients of value, of the raw offsets / logits (one tensor, the projection's layout) and of
+        // the reference points
+        const bool det = ctx->saved_data["det"].toBool() || at::globalContext().deterministicAlgorithms();
+        const unsigned flags = MSDA_FLAG_PROLOGUE | (det ? MSDA_FLAG_DETERMINISTIC : 0u);
+        const unsigned long long nbytes = msda_backward_workspace_bytes(N, S, M, D, L, Lq, P, flags);
+        at::Tensor ws;
+        if (nbytes) ws = at::empty({(int64_t)nbytes}, q2.options().dtype(at::kByte));
+        auto gv = at::empty_like(value), gproj = at::empty({(int64_t)N * Lq, 3LL * mlp}, q2.options());
+        auto gref = at::empty({N, Lq, L, 2}, q2.options());
+        raise_if(msda_backward_prologue_ws_f32(g_sampled.data_ptr<float>(), value.data_ptr<float>(), shapes.data_ptr<int64_t>(),
+                                               lsi.data_ptr<int64_t>(), loc.data_ptr<float>(), attn.data_ptr<float>(), N, S, M, D, L,
+                                               Lq, P, 3LL * mlp, 3LL * mlp, gv.data_ptr<float>(), gproj.data_ptr<float>(),
+                                               gproj.data_ptr<float>() + 2 * mlp, gref.data_ptr<float>(),
+                                               nbytes ? ws.data_ptr() : nullptr, nbytes, det ? MSDA_FLAG_DETERMINISTIC : 0u, stream),
+                 "ms_deform_attn_backward_prologue");
+        // merged projection
+        at::Tensor g_query;
+        if (ctx->needs_input_grad(0)) g_query = at::matmul(gproj, wm).view({N, Lq, C});
+        const at::Tensor gw_m = wgrad_into(gproj, q2.view({(int64_t)N * Lq, C}), nullptr, gb_m, true, stream);
+        // value_proj: masked rows of grad_value count as zero (weight gradient) and get a zero input gradient
+        const at::Tensor gv2 = gv.view({(int64_t)N * S, C});
+        at::Tensor g_input;
+        if (ctx->needs_input_grad(2)) {
+            g_input = at::matmul(gv2, w_val);
+            if (maskp)
+                raise_if(msda_zero_masked_rows_f32(g_input.data_ptr<float>(), reinterpret_cast<const uint8_t *>(rmask.data_ptr<bool>()),
+                                                   (long long)N * S, C, stream), "msda_zero_masked_rows");
+            g_input = g_input.view({N, S, C});
+        }
+        const at::Tensor gw_val = wgrad_into(gv2, x2.view({(int64_t)N * S, C}), maskp, gb_val, true, stream);
+        return {g_query, gref, g_input, at::Tensor(), at::Tensor(), at::Tensor(),
+                gw_m.narrow(0, 0, 2 * mlp), gb_m.narrow(0, 0, 2 * mlp), gw_m.narrow(0, 2 * mlp, mlp), gb_m.narrow(0, 2 * mlp, mlp),
+                gw_val, gb_val, gw_out, gb_out, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+    }
+};
+
+at::Tensor module_forward(const at::Tensor &query, const at::Tensor &centre, const at::Tensor &input_flatten,
+                          const c10::optional<at::Tensor> &mask, const at::Tensor &shapes, const at::Tensor &lsi,
+                          const at::Tensor &w_off, const at::Tensor &b_off, const at::Tensor &w_attn, const at::Tensor &b_attn,
+                          const at::Tensor &w_val, const at::Tensor &b_val, const at::Tensor &w_out, const at::Tensor &b_out,
+                          int64_t n_heads, int64_t n_levels, int64_t n_points, int64_t im2col_step, bool deterministic)
+{
+    for (const at::Tensor *t : {&query, &centre, &input_flatten, &w_off, &b_off, &w_attn, &b_attn, &w_val, &b_val, &w_out, &b_out})
+        TORCH_CHECK(t->is_cuda() && t->scalar_type() == at::kFloat && t->device() == query.device(),
+                    "MSDeformAttn (C++ node): float32 CUDA tensors on one device expected");
+    TORCH_CHECK(shapes.is_cuda() && lsi.is_cuda() && shapes.scalar_type() == at::kLong && lsi.scalar_type() == at::kLong,
+                "expected scalar type Long for spatial_shapes / level_start_index (on the device)");
+    return MSDAModuleFunction::apply(query, centre, input_flatten, mask, shapes, lsi, w_off, b_off, w_attn, b_attn, w_val, b_val,
+                                     w_out, b_out, n_heads, n_levels, n_points, im2col_step, deterministic);
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
@@ -241,6 +373,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("ms_deform_attn_backward", &backward, "replaces MSDA.ms_deform_attn_backward (vision.cpp:15)");
     m.def("apply", &apply, "MSDeformAttnFunction.apply as a C++ autograd node");
     m.def("apply_bf16", &apply_bf16, "MSDeformAttnBF16Function.apply as a C++ autograd node");
+    m.def("module_forward", &module_forward, "MSDeformAttn.forward (fp32, fused prologue + merged projection) as one C++ autograd node");
     // the header this file was COMPILED against (not the loaded library's msda_version(): _ext.py compares the two)
     m.def("abi_version", [] { return (int)MSDA_ABI_VERSION; });
 }

@@ -26,7 +26,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .. import _native
+from .. import _ext, _native
 from ..functions import (MSDeformAttnBF16Function, MSDeformAttnFunction, MSDeformAttnMergedPrologueFunction,
                          MSDeformAttnPrologueFunction)
 from ..functions.linear_func import bracket_linear, bracket_linear_masked, bracket_linear_wb
@@ -89,6 +89,10 @@ class MSDeformAttn(nn.Module):
         # with the fused prologue: sampling_offsets and attention_weights (two layers on the same query) as
         # ONE GEMM whose output the kernels read in place; the parameters stay two nn.Linear modules
         self.merged_projection = True
+        # the fp32 fused path as ONE C++ autograd node (csrc/torch_ext/msda_torch.cpp: module_forward) when the torch
+        # extension is built: the same kernels queued without Python in between (the eager step is host-bound at decoder
+        # sizes); False = the Python composition below
+        self.cpp_node = True
         self.d_model = d_model
         self.n_levels = n_levels
         self.n_heads = n_heads
@@ -119,6 +123,36 @@ class MSDeformAttn(nn.Module):
         nn.init.xavier_uniform_(self.output_proj.weight.data)
         nn.init.constant_(self.output_proj.bias.data, 0.0)
 
+    def _cpp_node(self, query, reference_points, input_flatten, spatial_shapes, level_start_index, padding_mask):
+        """The torch extension, if this call can run as its one-node form of the fp32 fused path (module_forward in
+        csrc/torch_ext/msda_torch.cpp): float32 CUDA tensors outside autocast, 2-d / 42-d reference points, plain nn.Linear
+        projections with biases, a geometry the fused prologue takes.  None -> the Python composition below."""
+        if not (self.cpp_node and self.fused_prologue and self.merged_projection and not self.bf16_storage):
+            return None
+        ext = _ext.get()
+        if ext is None or not hasattr(ext, "module_forward") or _native._forced_path != -1:
+            return None
+        if torch.is_autocast_enabled() or not torch.is_grad_enabled() or reference_points.shape[-1] not in (2, 42):
+            return None
+        tensors = (query, reference_points, input_flatten)
+        layers = (self.sampling_offsets, self.attention_weights, self.value_proj, self.output_proj)
+        if not all(t.is_cuda and t.dtype == torch.float32 for t in tensors):
+            return None
+        if not all(type(m) is nn.Linear and m.bias is not None and m.weight.dtype == torch.float32 and m.weight.is_cuda
+                   for m in layers):
+            return None
+        if not (spatial_shapes.is_cuda and level_start_index.is_cuda and self.d_model % 4 == 0
+                and (self.n_heads * self.n_levels * self.n_points) % 2 == 0):
+            return None
+        if padding_mask is not None and not (padding_mask.dtype == torch.bool and padding_mask.is_cuda
+                                             and padding_mask.shape == input_flatten.shape[:-1]):
+            return None
+        N, Len_q, _ = query.shape
+        if not _native.prologue_geometry_supported(N, input_flatten.shape[1], self.n_heads, self.d_model // self.n_heads,
+                                                   self.n_levels, Len_q, self.n_points):
+            return None
+        return ext
+
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
                 input_padding_mask=None):
         """
@@ -135,6 +169,18 @@ class MSDeformAttn(nn.Module):
         N, Len_q, _ = query.shape
         N, Len_in, _ = input_flatten.shape
         _check_shapes_sum(input_spatial_shapes, Len_in)
+
+        ext = self._cpp_node(query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
+                             input_padding_mask)
+        if ext is not None:
+            centre = reference_points if reference_points.shape[-1] == 2 else torch.stack(
+                [reference_points[..., 0::2].mean(-1), reference_points[..., 1::2].mean(-1)], -1)
+            return ext.module_forward(
+                query, centre, input_flatten, input_padding_mask, input_spatial_shapes, input_level_start_index,
+                self.sampling_offsets.weight, self.sampling_offsets.bias, self.attention_weights.weight,
+                self.attention_weights.bias, self.value_proj.weight, self.value_proj.bias, self.output_proj.weight,
+                self.output_proj.bias, self.n_heads, self.n_levels, self.n_points, self.im2col_step,
+                _native.deterministic_requested())
 
         # the four projections are nn.Linear (same parameters, same forward GEMM as the reference);
         # bracket_linear only swaps the weight-gradient GEMM of their backward (functions/linear_func.py)
