@@ -63,6 +63,9 @@ __device__ __forceinline__ float4 keep4(const float4 &v, bool keep)
 constexpr int kWgTile = 64;        // output tile is kWgTile x kWgTile
 constexpr int kWgStage = 32;       // reduction rows per LDS stage (64 measured: no faster)
 constexpr int kWgBlock = 256;      // 4 wavefronts
+#ifndef MSDA_BF_STAGE
+#define MSDA_BF_STAGE 32            // reduction rows per LDS stage of the bf16-MFMA kernel (64 measured: no faster)
+#endif
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 // Operand storage: float, or bfloat16 bits (uint16_t) widened to fp32 on the way into LDS — the products and the
@@ -187,9 +190,10 @@ __global__ __launch_bounds__(kWgBlock) void linear_wgrad_partial_kernel(
 // consumes: the hardware delivers each lane its column of the block's four rows.  A 32-lane half reads two neighbouring
 // blocks = 256 contiguous bytes: conflict-free.  Rows of blocks are skewed by 16 B so that the global->LDS copy (8 lanes = 8
 // rows of one 16-byte column chunk) does not land on one bank group.
-constexpr int kBfStage = 32;                               // reduction rows per LDS stage
+constexpr int kBfStage = MSDA_BF_STAGE;                    // reduction rows per LDS stage
+constexpr int kBfRows = kBfStage / 32;                     // rows per thread and stage of the global -> LDS copy
 constexpr int kBfBlkRow = (kWgTile / 16) * 128 + 16;       // bytes per row of blocks: 4 blocks + skew
-constexpr int kBfOperand = (kBfStage / 4) * kBfBlkRow;     // bytes per operand and buffer (4224)
+constexpr int kBfOperand = (kBfStage / 4) * kBfBlkRow;     // bytes per operand and buffer
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using i16x4 = __attribute__((ext_vector_type(4))) short;
 using i16x8 = __attribute__((ext_vector_type(8))) short;
@@ -205,7 +209,6 @@ __global__ __launch_bounds__(kWgBlock) void linear_wgrad_partial_bf16_kernel(
 {
     __shared__ __attribute__((aligned(16))) unsigned char Ab[2][kBfOperand];
     __shared__ __attribute__((aligned(16))) unsigned char Bb[2][kBfOperand];
-    __shared__ float bred[kWgBlock][8];                                  // bias partials (k0 == 0 tiles only)
     const int tiles_k = (K + kWgTile - 1) / kWgTile;
     int tile, split;
     tile_and_split((int)blockIdx.x, tiles, splits, tile, split);
@@ -214,33 +217,37 @@ __global__ __launch_bounds__(kWgBlock) void linear_wgrad_partial_bf16_kernel(
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int i0 = (wave >> 1) * 32, j0 = (wave & 1) * 32, h = lane >> 5, c = lane & 31;
 
-    // global -> registers: one 16-byte chunk (8 bf16) of one row per thread and operand; 8 consecutive lanes take 8 rows of
-    // the same column chunk, a wavefront 8 whole 128-byte rows
+    // global -> registers: 16-byte chunks (8 bf16) of kBfRows rows per thread and operand; 8 consecutive lanes take 8 rows
+    // of the same column chunk, a wavefront 8 whole 128-byte rows (rows lrow, lrow + 32, ...)
     const int lrow = (tid & 7) + 8 * wave, lchunk = (tid >> 3) & 7;       // stage row 0..31, columns 8*lchunk ..
     const bool a_ok = n0 + 8 * lchunk < N, b_ok = k0 + 8 * lchunk < K;    // N, K are multiples of 8 (host check)
     const int st_off = (lrow >> 2) * kBfBlkRow + (lchunk >> 1) * 128 + (lrow & 3) * 32 + (lchunk & 1) * 16;
-    uint4 ra, rb;
-    unsigned mk;
+    uint4 ra[kBfRows], rb[kBfRows];
+    unsigned mk[kBfRows];
     const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
 #define MSDA_LOAD_STAGE_BF(m0_)                                                                                      \
     do {                                                                                                            \
-        const int m = (m0_) + lrow;                                                                                 \
-        mk = 0;                                                                                                     \
-        if (row_mask != nullptr && m < m_end) mk = row_mask[m];                                                     \
-        ra = zero; rb = zero;                                                                                       \
-        if (a_ok && m < m_end) ra = *reinterpret_cast<const uint4 *>(dY + (long long)m * N + n0 + 8 * lchunk);      \
-        if (b_ok && m < m_end) rb = *reinterpret_cast<const uint4 *>(X + (long long)m * K + k0 + 8 * lchunk);       \
+        _Pragma("unroll") for (int r = 0; r < kBfRows; ++r) {                                                       \
+            const int m = (m0_) + lrow + 32 * r;                                                                    \
+            mk[r] = 0;                                                                                              \
+            if (row_mask != nullptr && m < m_end) mk[r] = row_mask[m];                                              \
+            ra[r] = zero; rb[r] = zero;                                                                             \
+            if (a_ok && m < m_end) ra[r] = *reinterpret_cast<const uint4 *>(dY + (long long)m * N + n0 + 8 * lchunk); \
+            if (b_ok && m < m_end) rb[r] = *reinterpret_cast<const uint4 *>(X + (long long)m * K + k0 + 8 * lchunk);  \
+        }                                                                                                           \
     } while (0)
 #define MSDA_STORE_STAGE_BF(buf_)                                                                                    \
     do {                                                                                                            \
-        const uint4 am = mk == 0 ? ra : zero;                                                                       \
-        *reinterpret_cast<uint4 *>(&Ab[buf_][st_off]) = make_uint4(am.x, am.y, am.z, am.w);                         \
-        *reinterpret_cast<uint4 *>(&Bb[buf_][st_off]) = rb;                                                         \
-        if (do_bias) {                                                                                              \
-            bs[0] += __uint_as_float(am.x << 16); bs[1] += __uint_as_float(am.x & 0xffff0000u);                     \
-            bs[2] += __uint_as_float(am.y << 16); bs[3] += __uint_as_float(am.y & 0xffff0000u);                     \
-            bs[4] += __uint_as_float(am.z << 16); bs[5] += __uint_as_float(am.z & 0xffff0000u);                     \
-            bs[6] += __uint_as_float(am.w << 16); bs[7] += __uint_as_float(am.w & 0xffff0000u);                     \
+        _Pragma("unroll") for (int r = 0; r < kBfRows; ++r) {                                                       \
+            const uint4 am = mk[r] == 0 ? ra[r] : zero;                                                             \
+            *reinterpret_cast<uint4 *>(&Ab[buf_][st_off + 8 * r * kBfBlkRow]) = make_uint4(am.x, am.y, am.z, am.w); \
+            *reinterpret_cast<uint4 *>(&Bb[buf_][st_off + 8 * r * kBfBlkRow]) = rb[r];                              \
+            if (do_bias) {                                                                                          \
+                bs[0] += __uint_as_float(am.x << 16); bs[1] += __uint_as_float(am.x & 0xffff0000u);                 \
+                bs[2] += __uint_as_float(am.y << 16); bs[3] += __uint_as_float(am.y & 0xffff0000u);                 \
+                bs[4] += __uint_as_float(am.z << 16); bs[5] += __uint_as_float(am.z & 0xffff0000u);                 \
+                bs[6] += __uint_as_float(am.w << 16); bs[7] += __uint_as_float(am.w & 0xffff0000u);                 \
+            }                                                                                                       \
         }                                                                                                           \
     } while (0)
 
@@ -263,16 +270,17 @@ __global__ __launch_bounds__(kWgBlock) void linear_wgrad_partial_bf16_kernel(
     int cur = 0;
     for (int m0 = m_begin; m0 < m_end; m0 += kBfStage) {
         const unsigned char *A = Ab[cur], *B = Bb[cur];
-        i16x4 a[4], b[4];
+        constexpr int KS = kBfStage / 16;                               // MFMAs (k = 16 each) per stage
+        i16x4 a[2 * KS], b[2 * KS];
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < KS; ++s)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 a[2 * s + t] = lds_read_tr16(A + a_rd + (4 * s + t) * kBfBlkRow);
                 b[2 * s + t] = lds_read_tr16(B + b_rd + (4 * s + t) * kBfBlkRow);
             }
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < KS; ++s) {
             const i16x8 av = {a[2 * s].x, a[2 * s].y, a[2 * s].z, a[2 * s].w, a[2 * s + 1].x, a[2 * s + 1].y, a[2 * s + 1].z, a[2 * s + 1].w};
             const i16x8 bv = {b[2 * s].x, b[2 * s].y, b[2 * s].z, b[2 * s].w, b[2 * s + 1].x, b[2 * s + 1].y, b[2 * s + 1].z, b[2 * s + 1].w};
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0);
@@ -292,8 +300,10 @@ __global__ __launch_bounds__(kWgBlock) void linear_wgrad_partial_bf16_kernel(
         if (i < N && j < K) ow[(long long)i * K + j] = acc[r];
     }
     if (do_bias) {                                                      // uniform per workgroup
-        // thread t holds columns 8*lchunk .. +7 over rows == lrow (mod 32): the 32 threads of a column chunk are
-        // tid = (tid & 7) + 8*lchunk + 64*wave; summed in a fixed order
+        // thread t holds columns 8*lchunk .. +7 over its rows: the 32 threads of a column chunk are
+        // tid = (tid & 7) + 8*lchunk + 64*wave; summed in a fixed order through LDS (the stage buffers are free now)
+        float (*bred)[8] = reinterpret_cast<float (*)[8]>(&Ab[0][0]);
+        static_assert(2 * kBfOperand >= kWgBlock * 8 * (int)sizeof(float), "bias partials fit the A buffers");
 #pragma unroll
         for (int k = 0; k < 8; ++k) bred[tid][k] = bs[k];
         __syncthreads();
@@ -396,7 +406,8 @@ static int launch_linear_wgrad_t(const OT *dY, const OT *X, const uint8_t *row_m
 {
     const int splits = wgrad_splits(M, N, K);
     int chunk = (M + splits - 1) / splits;
-    chunk = ((chunk + kWgStage - 1) / kWgStage) * kWgStage;
+    constexpr int stage = sizeof(OT) == 2 ? (kBfStage > kWgStage ? kBfStage : kWgStage) : kWgStage;
+    chunk = ((chunk + stage - 1) / stage) * stage;
     const int tiles = ((N + kWgTile - 1) / kWgTile) * ((K + kWgTile - 1) / kWgTile);
     const dim3 grid((unsigned)(tiles * splits));
     auto partial = linear_wgrad_partial_kernel<OT>;
