@@ -131,21 +131,16 @@ int msda_backward_passes(int Lq, int P);
  * flags & MSDA_FLAG_DETERMINISTIC: grad_value is bitwise reproducible run to run (grad_sampling_loc and
  * grad_attn_weight always are).  The default kernels order the contributions to a pixel by the rank an LDS
  * integer atomic returned, the reference by the arrival of its atomicAdds (ms_deform_im2col_cuda.cuh:125-152);
- * both differ in the last bits between runs.  The deterministic kernels sort whole sampling POINTS by bilinear
- * cell with a stable counting sort, read each grad_out row once per point, and add the four corner sums of a
- * cell into an fp32 tile image in LDS, cells of one colour (row parity, column parity) at a time — no two
- * cells of a colour share a pixel, so no atomics and a fixed summation order (uvhand_amd/csrc/msda_d32_cell.h).
- * With many sampling points per level and few (batch, head) pairs they also cut a level's queries into
- * chunks whose partial images go through `workspace` (fp32 slabs) and a fixed-order reduction:
- * msda_backward_workspace_bytes() says how much scratch such a call can use (0 = none); the caller passes a
- * 16-byte aligned device buffer of that size (stream-ordered, e.g. torch.empty).  workspace = NULL is
- * always accepted (same result per tile, less parallelism).  The library still allocates nothing.
+ * both differ in the last bits between runs.  With the flag the D = 32 kernels run the same sort + gather with one
+ * counter per (pixel row, WAVEFRONT) — eight 16-bit counters packed in four LDS words per row — so that a row's
+ * records end up wavefront-major in sampling-point order, a pure function of the inputs (uvhand_amd/csrc/
+ * msda_d32_value.h, DET); grad_value's role runs as its own launch.  It needs no scratch: `workspace` may be NULL
+ * (msda_backward_workspace_bytes() says what a call can use; with this flag alone that is nothing).
  * Shapes that are inconsistent with S (a level whose pixels do not lie in [0, S)) never cause an
  * out-of-range access on this path: such a level contributes nothing and pixels no level covers get zeros.
  * Outside the D = 32 family (any D, fp64, element-aligned views) the flag selects a destination-major kernel that
  * adds a pixel's contributions in (query, point) order — no atomics, no scratch, rows x Lq*P point tests of work.
- * It costs 1.5-2x the default backward (profiles/r02_notes.md).  Replaces the same reference functions as
- * msda_backward_*. */
+ * Cost on the D = 32 family: profiles/r03_notes.md.  Replaces the same reference functions as msda_backward_*. */
 #define MSDA_FLAG_DETERMINISTIC 1u
 /* msda_backward_workspace_bytes only: the size is asked for a msda_backward_prologue_* call (on large problems its
  * grad_sampling_loc / grad_attn_weight workgroups see one head each and leave the reference-point gradient per head in
@@ -291,7 +286,7 @@ const char *msda_last_error(void);
 /* Library/ABI version (major*100 + minor) and the kernel family a geometry maps to.  MSDA_ABI_VERSION is what a binding
  * compiled against THIS header expects msda_version() to return at run time (uvhand_amd/_ext.py compares the two);
  * it changes whenever a declaration in this file does. */
-#define MSDA_ABI_VERSION 111
+#define MSDA_ABI_VERSION 112
 int msda_version(void);
 int msda_path_for(int elem_bytes, int M, int D, int L, int P);
 

@@ -197,9 +197,12 @@ def test_argument_errors_are_reported_before_anything_is_launched(native):
     # sizes only (no pointers, no launch)
     lib.msda_backward_workspace_bytes.restype = ctypes.c_ulonglong
     lib.msda_backward_workspace_bytes.argtypes = [I] * 7 + [ctypes.c_uint]
-    assert lib.msda_backward_workspace_bytes(2, 3060, 8, 32, 4, 300, 4, 1) == 0           # decoder regime: no query chunks
-    assert lib.msda_backward_workspace_bytes(2, 3060, 8, 32, 4, 3060, 4, 1) > 0           # encoder regime, few pairs
+    assert lib.msda_backward_workspace_bytes(2, 3060, 8, 32, 4, 300, 4, 1) == 0           # deterministic: counters in LDS
+    assert lib.msda_backward_workspace_bytes(2, 3060, 8, 32, 4, 3060, 4, 1) == 0
     assert lib.msda_backward_workspace_bytes(2, 3060, 8, 32, 4, 3060, 4, 0) == 0           # default kernels need none
+    # MSDA_FLAG_PROLOGUE (2): large problems keep per-head reference-point gradients [N, Lq, M, L, 2] in scratch
+    assert lib.msda_backward_workspace_bytes(2, 3060, 8, 32, 4, 3060, 4, 2) == 2 * 3060 * 8 * 4 * 8
+    assert lib.msda_backward_workspace_bytes(2, 3060, 8, 32, 4, 300, 4, 2) == 0            # small problem: the fused launch
     lib.msda_unflatten_workspace_bytes.restype = ctypes.c_ulonglong
     lib.msda_unflatten_workspace_bytes.argtypes = [I, V, V, I, I]
     hs4, ws4 = (I * 4)(28, 14, 7, 4), (I * 4)(28, 14, 7, 4)

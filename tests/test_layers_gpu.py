@@ -75,9 +75,18 @@ def test_layers_use_the_fused_kernels(monkeypatch):
         monkeypatch.setattr(_native, name, wrapped)
     z = load_golden("layer_encoder")
     layer = _load(DeformableTransformerEncoderLayer(64, 128, 0.0, "relu", 4, 2, 4), z)
+    layer.self_attn.cpp_node = False          # count the attention module's kernels through the Python composition
     out = layer(_cuda(z["src"], True), _cuda(z["pos"]), _cuda(z["ref"]), _cuda(z["shapes"]), _cuda(z["level_start"]))
     out.sum().backward()
     assert calls["ln_f"] == 2 and calls["ln_b"] == 2 and calls["wgrad"] >= 4
+    # by default the attention module is ONE C++ node (its three weight gradients are queued from there): the FFN's two remain
+    calls.update(ln_f=0, ln_b=0, wgrad=0)
+    layer.self_attn.cpp_node = True
+    out = layer(_cuda(z["src"], True), _cuda(z["pos"]), _cuda(z["ref"]), _cuda(z["shapes"]), _cuda(z["level_start"]))
+    out.sum().backward()
+    from uvhand_amd import _ext
+    if _ext.get() is not None and hasattr(_ext.get(), "module_forward"):
+        assert calls["ln_f"] == 2 and calls["ln_b"] == 2 and calls["wgrad"] == 2
 
 
 def test_dropout_in_training_keeps_torch_random_stream():

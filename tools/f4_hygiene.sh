@@ -12,11 +12,12 @@ NDEV=$(python3 -c "import torch; print(torch.cuda.device_count())")
 BACKEND=nccl; [ "$NDEV" -lt 2 ] && BACKEND=gloo
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 show() { python3 -c "import json,sys; r=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('%-46s ranks %d backend %-5s %.2f ms/step  %.0f frames/s  in sync %s' % ('$1' or '(none)', r['n_gpus'], r['backend'], r['ms_per_step'], r['frames_per_s'], r['params_in_sync']))"; }
-for FL in "" "--reduce-dict" "--host-matcher" "--reduce-dict --host-matcher"; do
-  python3 tools/ddp_step.py --steps 10 --warmup 3 --window 16 $FL 2>/dev/null | show "$FL"
+python3 tools/ddp_step.py --steps 5 --warmup 3 --window 16 > /dev/null 2>&1      # page the image in: the first run is not a sample
+for FL in "" "--reduce-dict" "--host-matcher" "--reduce-dict --host-matcher" ""; do
+  python3 tools/ddp_step.py --steps 30 --warmup 5 --window 16 $FL 2>/dev/null | show "$FL"
 done
 export MSDA_BENCH_BACKEND=$BACKEND
 for FL in "" "--vote" "--find-unused" "--reduce-dict" "--host-matcher" "--vote --find-unused --reduce-dict --host-matcher"; do
   python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 tools/ddp_step.py \
-      --steps 10 --warmup 3 --window 16 $FL 2>/dev/null | show "$FL"
+      --steps 30 --warmup 5 --window 16 $FL 2>/dev/null | show "$FL"
 done

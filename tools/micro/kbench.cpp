@@ -46,7 +46,7 @@ int main(int argc, char **argv)
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     auto fwd = [&] { return msda_forward_f32(v, ds, dl, loc, at, N, S, M, D, L, Lq, P, out, st); };
-    // KB_DET=1: the deterministic (cell-sorted) backward with its query-chunk workspace
+    // KB_DET=1: the deterministic backward (per-wavefront counters; role B and role A as two launches)
     const bool det = getenv("KB_DET") && atoi(getenv("KB_DET")) != 0;
     void *ws = nullptr; unsigned long long ws_bytes = 0;
     if (!det) {                                      // default path: scratch for the level-major point table, if the shape uses one
@@ -58,10 +58,6 @@ int main(int argc, char **argv)
         ws_bytes = msda_backward_workspace_bytes(N, S, M, D, L, Lq, P, MSDA_FLAG_DETERMINISTIC);
         if (ws_bytes) CK(hipMalloc(&ws, ws_bytes));
         printf("deterministic backward, workspace %.1f MB\n", ws_bytes / 1e6);
-        int occ = -1;
-        hipFuncSetAttribute(reinterpret_cast<const void *>(msda::bwd_cell_d32_kernel<float, float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)msda::kCellLdsBytes);
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, msda::bwd_cell_d32_kernel<float, float>, msda::kCBlock, msda::kCellLdsBytes);
-        printf("bwd_cell_d32_kernel: %d workgroups of %d threads per CU with %zu B of LDS\n", occ, msda::kCBlock, msda::kCellLdsBytes);
     }
     auto bwd = [&] { return det ? msda_backward_ws_f32(go, v, ds, dl, loc, at, N, S, M, D, L, Lq, P, gv, gl, ga, ws, ws_bytes,
                                                        MSDA_FLAG_DETERMINISTIC, st)
@@ -83,33 +79,6 @@ int main(int argc, char **argv)
     unsigned long long *nul = nullptr; CK(hipMemcpyToSymbol(HIP_SYMBOL(msda::msda_stamp_buf), &nul, sizeof(nul)));
     std::vector<unsigned long long> hsb(total);
     CK(hipMemcpy(hsb.data(), sb, total * 8, hipMemcpyDeviceToHost));
-    if (det) {
-        // cell-sorted role B (msda_d32_cell.h): per-workgroup phase totals
-        double sum[6] = {0, 0, 0, 0, 0, 0}, mx = 0; size_t nb = 0; unsigned long long tmin = ~0ull, tmax = 0, kept = 0, batches = 0;
-        for (size_t b = 0; b < 65536; ++b) {
-            const unsigned long long *t = &hsb[b * 8];
-            if (!t[0] || !t[1]) continue;
-            ++nb; tmin = std::min(tmin, t[0]); tmax = std::max(tmax, t[1]);
-            const double life = (double)(t[1] - t[0]) * 0.01;
-            sum[0] += life; mx = std::max(mx, life);
-            for (int k = 2; k < 6; ++k) sum[k - 1] += (double)t[k] * 0.01;
-            batches += t[6]; kept += t[7];
-        }
-        {   // whole-workgroup lifetimes (entry -> exit), region 1
-            double life = 0, lmax = 0; size_t nw = 0; unsigned long long a = ~0ull, z = 0;
-            for (size_t b = 0; b < 65536; ++b) {
-                const unsigned long long *t = &hsb[region + b * 8];
-                if (!t[0] || !t[1]) continue;
-                ++nw; a = std::min(a, t[0]); z = std::max(z, t[1]);
-                const double d = (double)(t[1] - t[0]) * 0.01; life += d; lmax = std::max(lmax, d);
-            }
-            if (nw) printf("cell kernel: %zu workgroups launched, span %.2f us, mean lifetime %.2f us (max %.2f), sum of lifetimes / span = %.1f "
-                           "workgroups in flight\n", nw, (double)(z - a) * 0.01, life / nw, lmax, life / ((double)(z - a) * 0.01));
-        }
-        if (nb) printf("cell role B: %zu workgroups with items, span %.2f us; per workgroup: last item %.2f us (max %.2f), scan %.2f sort %.2f gather %.2f "
-                       "flush %.2f us; batches %.2f, kept points %.1f\n", nb, (double)(tmax - tmin) * 0.01, sum[0] / nb, mx, sum[1] / nb, sum[2] / nb,
-                       sum[3] / nb, sum[4] / nb, (double)batches / nb, (double)kept / nb);
-    }
     struct Reg { const char *name; int nph; const char *ph[5]; };
     const Reg regs[3] = {{"grad_value kernel (role B)", 5, {"loads+zero", "histogram", "prefix sum", "scatter", "gather"}},
                          {"query kernel (role A)", 3, {"prepass", "taps+dots", "write-out", "", ""}},
@@ -118,7 +87,6 @@ int main(int argc, char **argv)
         unsigned long long tmin = ~0ull, tmax = 0, smax = 0; size_t nb = 0;
         double ph[5] = {0, 0, 0, 0, 0}, phmax[5] = {0, 0, 0, 0, 0};
         const int last = regs[rg].nph;
-        if (rg == 0 && det) continue;
         for (size_t b = 0; b < 65536; ++b) {
             const unsigned long long *t = &hsb[rg * region + b * 8];
             if (!t[0] || !t[last]) continue;

@@ -482,7 +482,7 @@ __global__ __launch_bounds__(kBlock) void bwd_query_d32_kernel(
 #include "msda_d32_value.h"      // role B, per-tap records: gathers, bwd_value_body, bwd_value_wide_body, value_block_to_range
 namespace msda {
 
-template <int ACC, int PPT, typename VT, typename GT = VT>
+template <int ACC, int PPT, typename VT, typename GT = VT, bool DET = false>
 __global__ __launch_bounds__(kSBlock) void bwd_value_d32_kernel(
     const VT *__restrict__ grad_out, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ level_start, const float *__restrict__ loc,
@@ -494,8 +494,8 @@ __global__ __launch_bounds__(kSBlock) void bwd_value_d32_kernel(
     const int bid = xcd ? xcd_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
     int pr, l, ti, Wl;
     value_block_to_range(bid, W, L, shapes, pr, l, ti, Wl, ACC != kAccWide);
-    bwd_value_body<ACC, PPT, VT, GT>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, tp_cap,
-                                       grad_value, ti, Wl, l, pr, smem);
+    bwd_value_body<ACC, PPT, VT, GT, false, DET>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, tp_cap,
+                                                 grad_value, ti, Wl, l, pr, smem);
 }
 
 // One launch for the whole backward of a single-pass problem: the first nB workgroups are role B
@@ -551,59 +551,6 @@ __global__ __launch_bounds__(kSBlock, 4) void bwd_fused_lds_d32_kernel(
         bwd_query_lds_body<VT, FUSED, NS>(grad_out, value, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, lp_shift, chunks,
                                           qw, stage_rows, grad_loc, grad_attn, pro,
                                           xcd ? xcd_block(bid - nB, (int)gridDim.x - nB) : bid - nB, smem);
-    }
-}
-
-}  // namespace msda
-#include "msda_d32_cell.h"
-namespace msda {
-
-// Role B alone on the cell-sorted path (large problems: role A then runs as its own 256-thread kernel with its own,
-// smaller LDS and register footprint — inside one launch it would inherit role B's and lose a third of its occupancy).
-template <typename VT, typename GT>
-__global__ __launch_bounds__(kCBlock, MSDA_CELL_MIN_WAVES) void bwd_cell_d32_kernel(
-    const VT *__restrict__ grad_out, const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
-    const float *__restrict__ loc, const float *__restrict__ attn, int S, int M, int L, int Lq, int P, int p_shift,
-    const CellPlan plan, GT *__restrict__ grad_value, int xcd, int nvb)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // pair-major numbering, whole pairs per XCD: the items of a (batch, head) pair run at the same time on one XCD and
-    // share its grad_out rows in that L2 (slot-major — every pair's heaviest item first — was measured: cfg-4 encoder role B
-    // 264 -> 371 us, the pair's rows no longer survive in L2 between its items)
-    // persistent form: the launch has at most as many workgroups as fit on the chip at once (a multiple of 8, so a
-    // workgroup keeps its XCD) and each walks the virtual blocks vb = blockIdx.x, + gridDim.x, ...
-    MSDA_STAMP_AT(1, 0);
-    for (int vb = (int)blockIdx.x; vb < nvb; vb += (int)gridDim.x) {
-        const int bid = xcd ? xcd_block(vb, nvb) : vb;
-        const int pr = bid / plan.slots;
-        bwd_cell_body<VT, GT>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, grad_value, plan, pr,
-                              bid - pr * plan.slots, smem);
-    }
-    MSDA_STAMP_AT(1, 1);
-}
-
-// The whole backward in ONE launch, second generation: the first nB workgroups are role B on the cell-sorted
-// path (msda_d32_cell.h; slot `bid % G` of pair `bid / G`), the rest role A.  The two roles share no data.
-template <int SPLIT, typename VT, bool FUSED, typename GT>
-__global__ __launch_bounds__(kCBlock, (128 * 8) / kCBlock >= 4 ? 4 : 2) void bwd_cell_fused_d32_kernel(
-    const VT *__restrict__ grad_out, const VT *__restrict__ value,
-    const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
-    const float *__restrict__ loc, const float *__restrict__ attn, int S, int M, int L, int Lq,
-    int P, int items, int p_shift, int lp_shift, int m_shift, int nB, const CellPlan plan,
-    GT *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attn,
-    const PrologueOut pro, int xcd)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int bid = (int)blockIdx.x;
-    if (bid < nB) {
-        if (xcd) bid = xcd_block(bid, nB);
-        const int pr = bid / plan.slots;
-        bwd_cell_body<VT, GT>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, grad_value, plan, pr,
-                              bid - pr * plan.slots, smem);
-    } else {
-        bwd_query_body<SPLIT, false, kCBlock, VT, FUSED>(grad_out, value, shapes, level_start, loc, attn, S, M, L, Lq, P,
-                                                     items, p_shift, lp_shift, m_shift, static_cast<VT *>(nullptr), grad_loc, grad_attn,
-                                                     xcd ? xcd_block(bid - nB, (int)gridDim.x - nB) : bid - nB, smem, pro);
     }
 }
 
@@ -747,7 +694,7 @@ static int launch_fwd_d32_t(const VT *value, const int64_t *shapes, const int64_
 struct ValuePlan { int W, tp_cap, ppt, acc; size_t lds; };
 
 template <typename VT>
-static ValuePlan plan_value(int N, int S, int M, int L, int Lq, int P, int target_wgs)
+static ValuePlan plan_value(int N, int S, int M, int L, int Lq, int P, int target_wgs, bool det = false)
 {
     ValuePlan pl;
     const int NP = Lq * P, pairs_levels = N * M * L;
@@ -765,11 +712,11 @@ static ValuePlan plan_value(int N, int S, int M, int L, int Lq, int P, int targe
         for (;; ++pl.W) {                                            // the record capacity depends on the rows per range
             pl.tp_cap = (ceil_div(S, pl.W) + 3) & ~3;
             int rec_cap, list_cap;
-            wide_caps(pl.tp_cap, NP, rec_cap, list_cap);
+            wide_caps(pl.tp_cap, NP, rec_cap, list_cap, det);
             if (pl.W >= w_max || (long long)4 * NP * 115 / 100 <= (long long)rec_cap * pl.W) break;
         }
         pl.ppt = kSinglePPT;
-        pl.lds = (size_t)wide_lds_bytes(pl.tp_cap, NP);
+        pl.lds = (size_t)wide_lds_bytes(pl.tp_cap, NP, det);
         return pl;
     }
     if (pl.acc == kAccTile) {
@@ -788,7 +735,8 @@ static ValuePlan plan_value(int N, int S, int M, int L, int Lq, int P, int targe
     }
     pl.tp_cap = (pl.tp_cap + 3) & ~3;                                 // keeps the LDS arrays 16-B aligned
     const int pass_points = min(NP, pl.ppt * kSBlock);
-    pl.lds = (pl.acc == kAccTile ? (size_t)pl.tp_cap * kD * 4 : 0) + (2 * (size_t)pl.tp_cap + 32) * 4 +
+    // (DET: four counter words per row and the row totals besides the segment starts)
+    pl.lds = (pl.acc == kAccTile ? (size_t)pl.tp_cap * kD * 4 : 0) + ((det ? 6 : 2) * (size_t)pl.tp_cap + 32) * 4 +
              (size_t)4 * pass_points * sizeof(SRec) + (size_t)kOvfCap * sizeof(SOvf);
     return pl;
 }
@@ -822,139 +770,90 @@ static FusedPlan plan_fused(int items, int LP, int split, long long nB, int acc,
     return fp;
 }
 
-// ---- role B on the cell-sorted path (msda_d32_cell.h): host plan --------------------------------------------
-// The host knows S, L and Lq*P but not the level shapes (they live on the device), so it sizes the launch from
-// bounds: `slots` workgroup slots per (batch, head) pair (a slot loops over the pair's items slot, slot + G, ...:
-// the count only affects balance, never the result), and — when Lq*P is large and there are few pairs — up to
-// c_max query chunks per (level, tile), whose partial images go through `slabs` and slab_reduce_kernel.
-constexpr int kCellChunkPoints = 2048;
-static int cell_cmax(int N, int S, int M, int L, int Lq, int P)
-{
-    static const int target = [] { int t = env_int("MSDA_CELL_ITEMS", 1024); return t < 1 ? 1 : t; }();
-    if ((long long)Lq * P <= kCellChunkPoints) return 1;                   // a (level, tile) keeps few points anyway
-    const long long base_items = (long long)N * M * (S / 192 + L);          // ~ (pairs) x (tiles per pair)
-    long long c = (target + base_items - 1) / base_items;
-    // (forcing >= 2 chunks so that one-tile levels are not the launch's tail was measured: cfg-4 encoder role B 264 -> 317 us)
-    return (int)(c < 1 ? 1 : c > 8 ? 8 : c);
-}
+// per-head reference-point gradients of the fused-prologue backward on large problems, padded to 16 bytes
+static size_t prologue_heads_bytes(int N, int M, int L, int Lq) { return ((size_t)N * Lq * M * L * sizeof(float2) + 15) & ~(size_t)15; }
 
 #if MSDA_D32_HAS(0)
 size_t backward_workspace_bytes(int N, int S, int M, int D, int L, int Lq, int P, unsigned flags)
 {
     if (!d32_supported(N, S, M, D, L, Lq, P)) return 0;
-    if (flags & MSDA_FLAG_DETERMINISTIC) {                                    // fp32 slabs of the query chunks (msda_d32_cell.h)
-        const int c = cell_cmax(N, S, M, L, Lq, P);
-        return c > 1 ? (size_t)N * M * c * S * kD * sizeof(float) : 0;
-    }
-    if (flags & MSDA_FLAG_PROLOGUE) {
-        // large problems: role A sees one head per workgroup and leaves the reference-point gradient per head
-        // ([N, Lq, M, L, 2]) for ref_heads_reduce_kernel (the stage plan does not depend on the row type's size here)
-        return plan_lds<float>(N, S, M, L, Lq, P).use ? (size_t)N * Lq * M * L * sizeof(float2) : 0;
-    }
+    // The fused-prologue backward on large problems: role A sees one head per workgroup and leaves the reference-point
+    // gradient per head ([N, Lq, M, L, 2]) for ref_heads_reduce_kernel.  Nothing else needs scratch: the deterministic
+    // kernels (MSDA_FLAG_DETERMINISTIC) order a row's records through per-wavefront counters in LDS.
+    if ((flags & MSDA_FLAG_PROLOGUE) && plan_lds<float>(N, S, M, L, Lq, P).use) return prologue_heads_bytes(N, M, L, Lq);
     return 0;
 }
 #endif
 
-struct CellLaunch { CellPlan pl; long long nB; };
-static CellLaunch plan_cells(int N, int S, int M, int L, int Lq, int P, void *workspace, size_t ws_bytes)
-{
-    CellLaunch cl;
-    const long long pairs = (long long)N * M, NP = (long long)Lq * P;
-    cl.pl.k_chunk = kCellChunkPoints;
-    cl.pl.c_max = 1; cl.pl.slab_rows = 0; cl.pl.slabs = nullptr;
-    const int c = cell_cmax(N, S, M, L, Lq, P);
-    if (c > 1 && workspace != nullptr && ((uintptr_t)workspace & 15) == 0) {
-        const long long rows = (long long)(ws_bytes / (kD * sizeof(float))) / pairs;
-        if (rows >= 2) {
-            cl.pl.c_max = c;
-            cl.pl.slab_rows = (int)(rows < (long long)c * S ? rows : (long long)c * S);
-            cl.pl.slabs = static_cast<float *>(workspace);
-        }
-    }
-    // slots per pair = the item count of a typical pyramid (a level of H*W pixels has about H*W/256 tiles, one more
-    // level-sized tile per extra level, c_max - 1 more chunks per level): a pair with more items has some slots loop,
-    // a pair with fewer leaves workgroups that exit after the level walk — each costs a few us of a CU slot
-    long long slots = (long long)ceil_div(S, kTileRows) + L - 1 + (long long)L * (cl.pl.c_max - 1);
-    (void)NP;
-    while (slots > 1 && slots * pairs > 0x3fffffffLL) slots = (slots + 1) / 2;   // slots only affect balance
-    cl.pl.slots = (int)slots;
-    cl.nB = slots * pairs;
-    return cl;
-}
-
+// ---- MSDA_FLAG_DETERMINISTIC: role B with per-wavefront counters (DET, msda_d32_value.h) as its own launch, then role A.
+// (Not fused: the flag is for reproducibility runs, and one set of DET instantiations is enough; the two launches cost a
+// launch gap over the fused one.)  FUSED = the fused-prologue entry points.
 template <typename VT, typename GT, bool FUSED>
-static int launch_bwd_cells_t(const VT *grad_out, const VT *value, const int64_t *shapes, const int64_t *level_start,
-                              const float *loc, const float *attn, int N, int S, int M, int L, int Lq, int P,
-                              GT *grad_value, float *grad_loc, float *grad_attn, const PrologueOut pro, void *workspace,
-                              size_t ws_bytes, hipStream_t stream)
+static int launch_bwd_det_t(const VT *grad_out, const VT *value, const int64_t *shapes, const int64_t *level_start,
+                            const float *loc, const float *attn, int N, int S, int M, int L, int Lq, int P, GT *grad_value,
+                            float *grad_loc, float *grad_attn, const PrologueOut pro, void *workspace, size_t ws_bytes,
+                            hipStream_t stream)
 {
     const int items = N * Lq * M, LP = L * P;
     const int item_stride = LP * kRecBytes + kItemPad;
     const int ps = pow2_shift(P), lps = pow2_shift(LP), ms = pow2_shift(M);
     const int xcd = xcd_remap();
-    const CellLaunch cl = plan_cells(N, S, M, L, Lq, P, workspace, ws_bytes);
-    int split = pick_split(items, LP);
-    // small launches: all of role B and role A resident at once when role A takes fewer, larger workgroups
-    auto n_a = [&](int sp) { const int ipw = kCWaves * 8 / sp; return (long long)((items + ipw - 1) / ipw); };
-    if (split == 4 && cl.nB + n_a(4) > 512 && cl.nB + n_a(2) <= 512 && (!FUSED || (kCWaves * 8 / 2) % M == 0)) split = 2;
-    static const int skip_a = env_int("MSDA_CELL_SKIP_A", 0), skip_b = env_int("MSDA_CELL_SKIP_B", 0);   // measurement only
-    const int ipw = kCWaves * 8 / split;
-    const size_t lds_a = (size_t)ipw * item_stride + (size_t)ipw * LP * 16;
-    // Large problems: two launches (role B cells, role A query-major), each with its own occupancy.  With the fused
-    // prologue role A needs whole queries per (here 256-thread) workgroup: take fewer wavefronts per octet until M divides
-    // the items per workgroup, or stay with the single launch.
-    int sp_q = pick_split(items, LP);
-    if (FUSED) while (sp_q > 1 && (32 / sp_q) % M != 0) sp_q >>= 1;
-    const bool whole_queries = !FUSED || (32 / sp_q) % M == 0;
-    if (whole_queries && ((long long)Lq * P > kCellChunkPoints || cl.nB + n_a(split) > 1024)) {
-        if (!skip_b) {
-            if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_cell_d32_kernel<VT, GT>), kCellLdsBytes)) return rc;
-            static const int persist = env_int("MSDA_CELL_PERSIST", 0);           // diagnostic builds: 0 = one workgroup per block
-            const long long grid_b = (persist > 0 && cl.nB > persist) ? persist : cl.nB;
-            hipLaunchKernelGGL((bwd_cell_d32_kernel<VT, GT>), dim3((unsigned)grid_b), dim3(kCBlock), kCellLdsBytes, stream, grad_out,
-                               shapes, level_start, loc, attn, S, M, L, Lq, P, ps, cl.pl, grad_value, xcd, (int)cl.nB);
-            if (int rc = check_launch("msda backward (d32, cells)")) return rc;
-            if (cl.pl.c_max > 1) {
-                const int row_blocks = ceil_div(S, 32);
-                hipLaunchKernelGGL((slab_reduce_kernel<GT>), dim3((unsigned)((long long)N * M * row_blocks)), dim3(256), 0, stream,
-                                   shapes, level_start, S, M, L, Lq, P, grad_value, cl.pl, row_blocks);
-                if (int rc = check_launch("msda backward (d32, slab reduce)")) return rc;
-            }
+    const ValuePlan pl = plan_value<GT>(N, S, M, L, Lq, P, bwd_target_wgs(), true);
+    const long long nB = (long long)pl.W * N * M * L;
+    if (nB > 0x7fffffffLL) return set_error(MSDA_ERR_ARGUMENT, "msda backward (d32): too many grad_value workgroups");
+#define MSDA_LAUNCH_BD(AC, PPT_)                                                                       \
+    do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_value_d32_kernel<AC, PPT_, VT, GT, true>), pl.lds)) return rc; \
+         hipLaunchKernelGGL((bwd_value_d32_kernel<AC, PPT_, VT, GT, true>), dim3((unsigned)nB), dim3(kSBlock), pl.lds, stream,    \
+                            grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, ps, pl.tp_cap, pl.W, grad_value, xcd); } while (0)
+    if (pl.acc == kAccNone) MSDA_LAUNCH_BD(kAccNone, kSinglePPT);
+    else if (pl.acc == kAccTile) MSDA_LAUNCH_BD(kAccTile, kMultiPPT);
+    else MSDA_LAUNCH_BD(kAccWide, kSinglePPT);
+#undef MSDA_LAUNCH_BD
+    if (int rc = check_launch("msda backward (d32, deterministic grad_value)")) return rc;
+    // ---- role A ----
+    const LdsPlan lq = plan_lds<VT>(N, S, M, L, Lq, P);
+    if constexpr (!FUSED) {
+        if (lq.use)
+            return launch_query_lds<VT, false>(lq, grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, grad_loc,
+                                               grad_attn, pro, stream);
+    } else {
+        if (lq.use && workspace != nullptr && ws_bytes >= prologue_heads_bytes(N, M, L, Lq) && ((uintptr_t)workspace & 7) == 0) {
+            const PrologueOut pro_h{static_cast<float *>(workspace), pro.off_pad, pro.log_pad};
+            if (int rc = launch_query_lds<VT, true>(lq, grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P,
+                                                    grad_loc, grad_attn, pro_h, stream)) return rc;
+            const long long cells = (long long)N * Lq * L;
+            hipLaunchKernelGGL(ref_heads_reduce_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, stream,
+                               reinterpret_cast<const float2 *>(workspace), N * Lq, M, L, reinterpret_cast<float2 *>(pro.grad_ref));
+            return check_launch("msda backward (d32, reference-point gradient over heads)");
         }
-        if (!skip_a) {
-            const int sp = sp_q;
-            const int ipw_a = 32 / sp;
-            const size_t lds_q = (size_t)ipw_a * item_stride + (size_t)ipw_a * LP * 16;
-            const dim3 qgrid((items + ipw_a - 1) / ipw_a);
-#define MSDA_LAUNCH_Q(SP)                                                                              \
-            hipLaunchKernelGGL((bwd_query_d32_kernel<SP, false, VT, FUSED>), qgrid, dim3(kBlock), lds_q, stream, grad_out, value,    \
-                               shapes, level_start, loc, attn, S, M, L, Lq, P, items, ps, lps, ms, static_cast<VT *>(nullptr),       \
-                               grad_loc, grad_attn, xcd, pro)
-            if (sp == 4) MSDA_LAUNCH_Q(4); else if (sp == 2) MSDA_LAUNCH_Q(2); else MSDA_LAUNCH_Q(1);
-#undef MSDA_LAUNCH_Q
-            return check_launch("msda backward (d32, query-major)");
-        }
-        return MSDA_OK;
     }
-    const long long nA = skip_a ? 0 : n_a(split);
-    CellLaunch clm = cl;
-    if (skip_b) clm.nB = 0;
-    if (clm.nB + nA > 0x7fffffffLL) return set_error(MSDA_ERR_ARGUMENT, "msda backward (d32): too many workgroups");
-    const size_t lds = kCellLdsBytes > lds_a ? kCellLdsBytes : lds_a;
-    const dim3 grid((unsigned)(clm.nB + nA));
-#define MSDA_LAUNCH_C(SP)                                                                              \
-    do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_cell_fused_d32_kernel<SP, VT, FUSED, GT>), lds)) return rc; \
-         hipLaunchKernelGGL((bwd_cell_fused_d32_kernel<SP, VT, FUSED, GT>), grid, dim3(kCBlock), lds, stream, grad_out, value,     \
-                            shapes, level_start, loc, attn, S, M, L, Lq, P, items, ps, lps, ms, (int)clm.nB, cl.pl, grad_value,      \
-                            grad_loc, grad_attn, pro, xcd); } while (0)
-    if (split == 4) MSDA_LAUNCH_C(4); else if (split == 2) MSDA_LAUNCH_C(2); else MSDA_LAUNCH_C(1);
-#undef MSDA_LAUNCH_C
-    if (int rc = check_launch("msda backward (d32, cells + query-major)")) return rc;
-    if (cl.pl.c_max > 1) {
-        const int row_blocks = ceil_div(S, 32);
-        hipLaunchKernelGGL((slab_reduce_kernel<GT>), dim3((unsigned)((long long)N * M * row_blocks)), dim3(256), 0, stream, shapes,
-                           level_start, S, M, L, Lq, P, grad_value, cl.pl, row_blocks);
-        return check_launch("msda backward (d32, slab reduce)");
+    int sp = pick_split(items, LP);
+    if (FUSED) while (sp > 1 && (32 / sp) % M != 0) sp >>= 1;              // whole queries per 256-thread workgroup
+    if (!FUSED || (32 / sp) % M == 0) {
+        const int ipw = 32 / sp;
+        const size_t lds = (size_t)ipw * item_stride + (size_t)ipw * LP * 16;
+        const dim3 qgrid((items + ipw - 1) / ipw);
+#define MSDA_LAUNCH_QD(SP)                                                                             \
+        hipLaunchKernelGGL((bwd_query_d32_kernel<SP, false, VT, FUSED>), qgrid, dim3(kBlock), lds, stream, grad_out, value, shapes,  \
+                           level_start, loc, attn, S, M, L, Lq, P, items, ps, lps, ms, static_cast<VT *>(nullptr), grad_loc,        \
+                           grad_attn, xcd, pro)
+        if (sp == 4) MSDA_LAUNCH_QD(4); else if (sp == 2) MSDA_LAUNCH_QD(2); else MSDA_LAUNCH_QD(1);
+#undef MSDA_LAUNCH_QD
+        return check_launch("msda backward (d32, query-major)");
+    }
+    // more heads than a 256-thread workgroup has items: role A as the 512-thread half of the fused kernel (no role-B blocks)
+    if constexpr (FUSED) {
+        const int split = pick_split(items, LP), ipw_f = kSWaves * 8 / split;
+        const size_t lds_a = (size_t)ipw_f * item_stride + (size_t)ipw_f * LP * 16;
+        const dim3 agrid((unsigned)((items + ipw_f - 1) / ipw_f));
+#define MSDA_LAUNCH_AD(SP)                                                                             \
+        do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_fused_d32_kernel<SP, kAccNone, VT, true, float, false>), lds_a)) return rc; \
+        hipLaunchKernelGGL((bwd_fused_d32_kernel<SP, kAccNone, VT, true, float, false>), agrid, dim3(kSBlock), lds_a, stream, grad_out,   \
+                           value, shapes, level_start, loc, attn, S, M, L, Lq, P, items, ps, lps, ms, pl.tp_cap, pl.W, 0,            \
+                           static_cast<float *>(nullptr), grad_loc, grad_attn, pro, xcd); } while (0)
+        if (split == 4) MSDA_LAUNCH_AD(4); else if (split == 2) MSDA_LAUNCH_AD(2); else MSDA_LAUNCH_AD(1);
+#undef MSDA_LAUNCH_AD
+        return check_launch("msda backward (d32, query-major, 512 threads)");
     }
     return MSDA_OK;
 }
@@ -969,8 +868,8 @@ static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *
     const int items = N * Lq * M, LP = L * P;
     const int item_stride = LP * kRecBytes + kItemPad;
     if (deterministic)
-        return launch_bwd_cells_t<VT, GT, false>(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, grad_value,
-                                                 grad_loc, grad_attn, PrologueOut{nullptr, 0, 0}, workspace, ws_bytes, stream);
+        return launch_bwd_det_t<VT, GT, false>(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, grad_value,
+                                               grad_loc, grad_attn, PrologueOut{nullptr, 0, 0}, workspace, ws_bytes, stream);
     // tuning / A-B knobs, read once per process: MSDA_BWD_MODE=atomic selects the v1 global-atomic
     // scatter (fp32 only), =split launches role B and role A as two kernels; MSDA_BWD_WGS is the number
     // of role-B workgroups to aim for on small problems.
@@ -1087,7 +986,7 @@ bool prologue_supported(int N, int S, int M, int D, int L, int Lq, int P)
     const int LP = L * P;
     if (pow2_shift(LP) < 0 || pow2_shift(P) < 0 || LP > 64) return false;     // lane-group reductions
     const int split = pick_split(N * Lq * M, LP);
-    if ((kSWaves * 8 / split) % M != 0 || (kCWaves * 8 / split) % M != 0) return false;   // whole queries per role-A workgroup
+    if ((kSWaves * 8 / split) % M != 0) return false;                           // whole queries per role-A workgroup
     static const bool plain_modes = tuning_str("MSDA_BWD_MODE") != nullptr;
     return !plain_modes;                                                        // A/B knobs select the unfused kernels
 }
@@ -1128,8 +1027,8 @@ static int launch_bwd_prologue_t(const VT *grad_out, const VT *value, const int6
     const int item_stride = LP * kRecBytes + kItemPad;
     const PrologueOut pro_c{grad_ref, (int)((ld_grad_offsets - 2LL * M * LP) / 2), (int)(ld_grad_logits - (long long)M * LP)};
     if (deterministic)
-        return launch_bwd_cells_t<VT, float, true>(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P,
-                                                   grad_value, grad_offsets, grad_logits, pro_c, workspace, ws_bytes, stream);
+        return launch_bwd_det_t<VT, float, true>(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P,
+                                                 grad_value, grad_offsets, grad_logits, pro_c, workspace, ws_bytes, stream);
     const int split = pick_split(items, LP);
     const int ps = pow2_shift(P), lps = pow2_shift(LP), ms = pow2_shift(M);
     const ValuePlan pl = plan_value<float>(N, S, M, L, Lq, P, bwd_target_wgs());
@@ -1143,7 +1042,7 @@ static int launch_bwd_prologue_t(const VT *grad_out, const VT *value, const int6
     const PrologueOut pro{grad_ref, (int)((ld_grad_offsets - 2LL * M * LP) / 2), (int)(ld_grad_logits - (long long)M * LP)};
     // ---- large problems: role A on the LDS-stage body; it leaves grad_ref per head in the caller's scratch ----
     const LdsPlan lq = plan_lds<VT>(N, S, M, L, Lq, P);
-    const size_t heads_bytes = (size_t)N * Lq * M * L * sizeof(float2);
+    const size_t heads_bytes = prologue_heads_bytes(N, M, L, Lq);
     if (lq.use && workspace != nullptr && ws_bytes >= heads_bytes && ((uintptr_t)workspace & 7) == 0 &&
         (pl.acc == kAccNone || pl.acc == kAccWide) && nB + (long long)N * M * lq.chunks <= 0x7fffffffLL) {
         const PrologueOut pro_h{static_cast<float *>(workspace), pro.off_pad, pro.log_pad};

@@ -54,8 +54,50 @@ namespace msda {
 //             whenever the taps this workgroup KEEPS fit the record array (a workgroup owns 1/W of a level, so
 //             it keeps ~1/W of the level's taps), chunked kAccRmw passes otherwise.
 // ------------------------------------------------------------------------------------------
+// DET (MSDA_FLAG_DETERMINISTIC): the same algorithm with a record order that is a pure function of the inputs.  What varies
+// from run to run above is only the ORDER of a row's records — the rank an LDS atomic hands out depends on which wavefront
+// got there first — and with it the association of the row's floating-point sum.  DET keeps one counter per (row,
+// WAVEFRONT), eight 16-bit counters packed in four words per row: a wavefront's taps are ranked among themselves (lanes of
+// one atomic instruction in lane order, instructions in program order — both fixed), the prefix sum runs over (row,
+// wavefront) pairs, and a row's records end up wavefront-major in point order.  The kept-taps pass lists a wavefront's
+// points in that wavefront's own list segment and every later pass has the same wavefront revisit them in the same order.
+// It costs LDS (24 instead of 8 bytes per row), not a second algorithm: the reference's atomicAdd scatter
+// (ms_deform_im2col_cuda.cuh:125-152) has no deterministic counterpart at all.
 constexpr int kSBlock = 512;
 constexpr int kSWaves = kSBlock / kWave;
+static_assert(kSWaves == 8, "DET packs eight 16-bit per-wavefront counters into four words per row");
+
+// DET counters: word (row * 4 + wave / 2), low half for even wavefronts.  Returns this wavefront's previous count.
+__device__ __forceinline__ int det_count(int *cntw, int row, int wave)
+{
+    const int old = atomicAdd(&cntw[row * 4 + (wave >> 1)], (wave & 1) ? 0x10000 : 1);
+    return (wave & 1) ? (int)((unsigned)old >> 16) : (old & 0xffff);
+}
+__device__ __forceinline__ void det_count_only(int *cntw, int row, int wave)
+{
+    atomicAdd(&cntw[row * 4 + (wave >> 1)], (wave & 1) ? 0x10000 : 1);
+}
+// Row `r` of the packed counters: returns the row's total and replaces the eight counts by their exclusive prefix within the row.
+__device__ __forceinline__ int det_row_prefix(int *cntw, int r)
+{
+    int4 c = *reinterpret_cast<int4 *>(cntw + r * 4);
+    const int w[4] = {c.x, c.y, c.z, c.w};
+    int run = 0, out[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int lo = w[k] & 0xffff, hi = (int)((unsigned)w[k] >> 16);
+        out[k] = run | ((run + lo) << 16);
+        run += lo + hi;
+    }
+    *reinterpret_cast<int4 *>(cntw + r * 4) = make_int4(out[0], out[1], out[2], out[3]);
+    return run;
+}
+// This wavefront's exclusive prefix within row `row` (after det_row_prefix).
+__device__ __forceinline__ int det_wave_base(const int *cntw, int row, int wave)
+{
+    const int v = cntw[row * 4 + (wave >> 1)];
+    return (wave & 1) ? (int)((unsigned)v >> 16) : (v & 0xffff);
+}
 constexpr int kAccNone = 0, kAccRmw = 1, kAccTile = 2, kAccWide = 3;
 struct alignas(8) SRec { float w; int q; };
 // Fixed-capacity segments (FIXED = true: steps 1-3 in one scan, for problems small enough that every workgroup
@@ -359,7 +401,7 @@ __device__ __forceinline__ void gather_split(const VT *__restrict__ go_base, GT 
     }
 }
 
-template <typename VT, typename GT>
+template <typename VT, typename GT, bool DET>
 __device__ __forceinline__ void bwd_value_wide_body(const VT *__restrict__, const int64_t *__restrict__, const int64_t *__restrict__,
                                                     const float *__restrict__, const float *__restrict__, int, int, int, int, int,
                                                     int, int, GT *__restrict__, int, int, int, int, unsigned char *);   // kAccWide, below
@@ -369,24 +411,28 @@ __device__ __forceinline__ void bwd_value_wide_body(const VT *__restrict__, cons
 // step 1 and step 3, so loc / attn are read exactly once and step 3 needs no atomics.
 // VT = storage type of grad_out, GT = storage type of grad_value (the same, or float for bf16 rows with an
 // fp32 grad_value: no rounding between passes, kAccRmw instead of the LDS tile).
-template <int ACC, int PPT, typename VT, typename GT = VT, bool FIXED = false>
+template <int ACC, int PPT, typename VT, typename GT = VT, bool FIXED = false, bool DET = false>
 __device__ __forceinline__ void bwd_value_body(
     const VT *__restrict__ grad_out, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ level_start, const float *__restrict__ loc,
     const float *__restrict__ attn, int S, int M, int L, int Lq, int P, int p_shift, int tp_cap,
     GT *__restrict__ grad_value, int ti, int W, int l, int pr, unsigned char *smem)
 {
+    static_assert(!(FIXED && DET), "the fixed-capacity segments take ranks in arrival order");
     if constexpr (ACC == kAccWide) {
-        bwd_value_wide_body<VT, GT>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, tp_cap, grad_value,
-                                    ti, W, l, pr, smem);
+        bwd_value_wide_body<VT, GT, DET>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, tp_cap, grad_value,
+                                         ti, W, l, pr, smem);
         return;
     }
     constexpr int NPC = PPT * kSBlock;                       // points per pass
-    // LDS: [tile: tp_cap*32 floats if kAccTile] [cnt tp_cap] [start tp_cap] [wsum 32] [rec] [ovf kOvfCap]
+    // LDS: [tile: tp_cap*32 floats if kAccTile] [cnt tp_cap (DET: 4 words per row)] [start tp_cap] [DET: row totals tp_cap]
+    //      [wsum 32] [rec] [ovf kOvfCap]
+    constexpr int CW = DET ? 4 : 1;
     float *tile = reinterpret_cast<float *>(smem);
     int *cnt = reinterpret_cast<int *>(smem + (ACC == kAccTile ? (size_t)tp_cap * kD * 4 : 0));
-    int *start = cnt + tp_cap;
-    int *wsum = start + tp_cap;
+    int *start = cnt + tp_cap * CW;
+    int *tot = DET ? start + tp_cap : cnt;                   // records per row, as the gathers read them
+    int *wsum = DET ? tot + tp_cap : start + tp_cap;
     SRec *rec = reinterpret_cast<SRec *>(wsum + 32);
     int *novf_p = wsum + 8, *total_p = wsum + 9;             // wsum[0..7]: per-wavefront sums of the prefix scan, [16..23]: longest row
 
@@ -431,7 +477,7 @@ __device__ __forceinline__ void bwd_value_body(
                 qq[k] = q;
             }
         }
-        for (int i = tid; i < npx; i += kSBlock) cnt[i] = 0;
+        for (int i = tid; i < npx * CW; i += kSBlock) cnt[i] = 0;
         if (FIXED && tid == 0) { *novf_p = 0; *total_p = 0; }
         __syncthreads();
         MSDA_STAMP(1);
@@ -497,13 +543,19 @@ __device__ __forceinline__ void bwd_value_body(
 #pragma unroll
         for (int k = 0; k < PPT; ++k)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) { rank[k][t] = 0; if (dest[k][t] >= 0) rank[k][t] = atomicAdd(&cnt[dest[k][t]], 1); }
+            for (int t = 0; t < 4; ++t) {
+                rank[k][t] = 0;
+                if (dest[k][t] >= 0) rank[k][t] = DET ? det_count(cnt, dest[k][t], wave) : atomicAdd(&cnt[dest[k][t]], 1);
+            }
         __syncthreads();
         MSDA_STAMP(2);
         // ---- 2. exclusive prefix sum over the rows (512 threads x CH consecutive rows) ----
         const int CH = (npx + kSBlock - 1) / kSBlock;
         const int r0 = tid * CH;
         int mine = 0, big = 0;
+        if (DET) {                                           // row totals; the packed counts become within-row prefixes
+            for (int k = 0; k < CH; ++k) if (r0 + k < npx) { const int t = det_row_prefix(cnt, r0 + k); tot[r0 + k] = t; mine += t; big = max(big, t); }
+        } else
         for (int k = 0; k < CH; ++k) if (r0 + k < npx) { mine += cnt[r0 + k]; big = max(big, cnt[r0 + k]); }
         int incl = mine;
 #pragma unroll
@@ -521,31 +573,34 @@ __device__ __forceinline__ void bwd_value_body(
             const int4 ma = *reinterpret_cast<const int4 *>(wsum + 16), mb = *reinterpret_cast<const int4 *>(wsum + 20);
             longest = max(max(max(ma.x, ma.y), max(ma.z, ma.w)), max(max(mb.x, mb.y), max(mb.z, mb.w)));
         }
-        for (int k = 0; k < CH; ++k) if (r0 + k < npx) { start[r0 + k] = excl; excl += cnt[r0 + k]; }
+        for (int k = 0; k < CH; ++k) if (r0 + k < npx) { start[r0 + k] = excl; excl += tot[r0 + k]; }
         __syncthreads();
         MSDA_STAMP(3);
-        // ---- 3. counting sort: each tap's record goes to start[row] + rank ----
+        // ---- 3. counting sort: each tap's record goes to start[row] (+ DET: this wavefront's share of the row) + rank ----
 #pragma unroll
         for (int k = 0; k < PPT; ++k)
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-                if (dest[k][t] >= 0) { SRec r; r.w = tw[k][t]; r.q = qq[k]; rec[start[dest[k][t]] + rank[k][t]] = r; }
+                if (dest[k][t] >= 0) {
+                    SRec r; r.w = tw[k][t]; r.q = qq[k];
+                    rec[start[dest[k][t]] + (DET ? det_wave_base(cnt, dest[k][t], wave) : 0) + rank[k][t]] = r;
+                }
         __syncthreads();
         MSDA_STAMP(4);
         // ---- 4. gather; lanes per row chosen from the mean segment length (uniform) ----
         // rows of comparable length (the longest no more than one lane group's share): the balanced walk
         if (ACC != kAccTile && longest * 64 <= max(total, 1024)) {
-            gather_balanced<VT, GT, false>(go_base, gv_base, cnt, start, RecAos{rec, row_stride}, reinterpret_cast<int *>(ovf), npx,
+            gather_balanced<VT, GT, false>(go_base, gv_base, tot, start, RecAos{rec, row_stride}, reinterpret_cast<int *>(ovf), npx,
                                            row_stride, total, ACC == kAccNone || first);
             if (ACC != kAccNone) __syncthreads();
             MSDA_STAMP(5);
             continue;
         }
         const int mean2 = (2 * total) / npx;                                  // 2 x mean records per row
-        if (mean2 <= 8)       gather_rows<1, ACC, VT, GT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
-        else if (mean2 <= 16) gather_rows<2, ACC, VT, GT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
-        else if (mean2 <= 32) gather_rows<4, ACC, VT, GT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
-        else                  gather_rows<8, ACC, VT, GT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first);
+        if (mean2 <= 8)       gather_rows<1, ACC, VT, GT>(go_base, gv_base, tot, start, rec, tile, npx, row_stride, first);
+        else if (mean2 <= 16) gather_rows<2, ACC, VT, GT>(go_base, gv_base, tot, start, rec, tile, npx, row_stride, first);
+        else if (mean2 <= 32) gather_rows<4, ACC, VT, GT>(go_base, gv_base, tot, start, rec, tile, npx, row_stride, first);
+        else                  gather_rows<8, ACC, VT, GT>(go_base, gv_base, tot, start, rec, tile, npx, row_stride, first);
         if (ACC != kAccNone) __syncthreads();                // next pass reuses the LDS arrays / re-reads rows
         MSDA_STAMP(5);
     }
@@ -579,9 +634,9 @@ constexpr int kWideLdsBudget = 80 * 1024;           // two workgroups per CU
 // Capacities of a kAccWide workgroup, the same on the host (plan_value) and on the device: what is left of the LDS budget
 // after the row arrays goes to the list (16-bit entries, one per listed point; at least the 8 KB the gathers use as
 // scratch once the list is dead) and to the 6-byte records.
-__host__ __device__ inline void wide_caps(int tp_cap, int NP, int &rec_cap, int &list_cap)
+__host__ __device__ inline void wide_caps(int tp_cap, int NP, int &rec_cap, int &list_cap, bool det = false)
 {
-    const int fixed = 8 * tp_cap + 128;                                       // cnt, start, wsum
+    const int fixed = (det ? 24 : 8) * tp_cap + 128;                          // cnt (DET: 4 words per row + row totals), start, wsum
     int lc = ((NP < kWideMaxStep ? NP : kWideMaxStep) + 7) & ~7;
     const int list_bytes = 2 * lc > 8192 ? 2 * lc : 8192;
     int rc = (kWideLdsBudget - fixed - list_bytes) / 6;
@@ -589,30 +644,36 @@ __host__ __device__ inline void wide_caps(int tp_cap, int NP, int &rec_cap, int 
     rec_cap = rc & ~7;
     list_cap = (lc < rec_cap ? lc : rec_cap) & ~7;
 }
-__host__ __device__ inline int wide_lds_bytes(int tp_cap, int NP)
+__host__ __device__ inline int wide_lds_bytes(int tp_cap, int NP, bool det = false)
 {
     int rc, lc;
-    wide_caps(tp_cap, NP, rc, lc);
-    return 8 * tp_cap + 128 + (2 * lc > 8192 ? 2 * lc : 8192) + 6 * rc;
+    wide_caps(tp_cap, NP, rc, lc, det);
+    return (det ? 24 : 8) * tp_cap + 128 + (2 * lc > 8192 ? 2 * lc : 8192) + 6 * rc;
 }
 
-template <typename VT, typename GT>
+template <typename VT, typename GT, bool DET>
 __device__ __forceinline__ void bwd_value_wide_body(
     const VT *__restrict__ grad_out, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ level_start, const float *__restrict__ loc,
     const float *__restrict__ attn, int S, int M, int L, int Lq, int P, int p_shift, int tp_cap,
     GT *__restrict__ grad_value, int ti, int W, int l, int pr, unsigned char *smem)
 {
-    // LDS: [cnt tp_cap] [start tp_cap] [wsum 32] [list: list_cap x u16, at least 8 KB] [weights rec_cap x f32] [queries rec_cap x u16]
+    // LDS: [cnt tp_cap (DET: 4 words per row)] [start tp_cap] [DET: row totals tp_cap] [wsum 32] [list: list_cap x u16, at least
+    //      8 KB] [weights rec_cap x f32] [queries rec_cap x u16]
     int rec_cap, list_cap;
-    wide_caps(tp_cap, Lq * P, rec_cap, list_cap);
+    wide_caps(tp_cap, Lq * P, rec_cap, list_cap, DET);
+    constexpr int CW = DET ? 4 : 1;
     int *cnt = reinterpret_cast<int *>(smem);
-    int *start = cnt + tp_cap;
-    int *wsum = start + tp_cap;
+    int *start = cnt + tp_cap * CW;
+    int *tot = DET ? start + tp_cap : cnt;                   // records per row, as the gathers read them
+    int *wsum = DET ? tot + tp_cap : start + tp_cap;
+    // DET: every wavefront lists its points in its own eighth of the list (wsum[24 + w] entries) and is the one that revisits them
+    const int seg = DET ? (list_cap / kSWaves) & ~1 : list_cap;
+    int *kept_w = wsum + 24;
     uint16_t *list = reinterpret_cast<uint16_t *>(wsum + 32);             // wsum[16..23]: per-wavefront longest row
     float *rw = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(list) + (2 * list_cap > 8192 ? 2 * list_cap : 8192));
     uint16_t *rq = reinterpret_cast<uint16_t *>(rw + rec_cap);
-    const int wide_chunk = min(rec_cap / 4, list_cap);       // points whose taps and list entries always fit
+    const int wide_chunk = min(rec_cap / 4, DET ? (list_cap / kSWaves) & ~1 : list_cap);      // points whose taps and list entries always fit
     int *kept_p = wsum + 8;                                  // wsum[0..7]: per-wavefront sums of the prefix scan
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -656,8 +717,9 @@ __device__ __forceinline__ void bwd_value_wide_body(
 
     // steps 1-2 for the points [p0, p1); returns the number of kept taps
     auto count_points = [&](int p0, int p1) -> int {
-        for (int i = tid; i < npx; i += kSBlock) cnt[i] = 0;
+        for (int i = tid; i < npx * CW; i += kSBlock) cnt[i] = 0;
         if (tid == 0) *kept_p = 0;
+        if (DET && tid < kSWaves) kept_w[tid] = 0;
         __syncthreads();
         // 1a. the points that MAY have a tap on this workgroup's rows -> list.  No histogram yet (an LDS atomic costs
         // ~30 cycles per wavefront instruction however few lanes take part, and here ~1/W of them would); the test is
@@ -695,12 +757,18 @@ __device__ __forceinline__ void bwd_value_wide_body(
             }
             if (n == 0) continue;                                               // uniform
             int wbase = 0;
-            if (lane == 0) wbase = atomicAdd(kept_p, n);
-            wbase = __shfl(wbase, 0, kWave);
+            if (DET) {                                                          // this wavefront's own cursor: no atomic, no race
+                wbase = kept_w[wave];
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) { kept_w[wave] = wbase + n; atomicAdd(kept_p, n); }
+            } else {
+                if (lane == 0) wbase = atomicAdd(kept_p, n);
+                wbase = __shfl(wbase, 0, kWave);
+            }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int pos = wbase + __popcll(mask[u] & ((1ull << lane) - 1ull));
-                if (((mask[u] >> lane) & 1ull) && pos < list_cap) list[pos] = (uint16_t)(base - p0 + u * kSBlock + tid);
+                if (((mask[u] >> lane) & 1ull) && pos < seg) list[(DET ? wave * seg : 0) + pos] = (uint16_t)(base - p0 + u * kSBlock + tid);
                 wbase += __popcll(mask[u]);
             }
         }
@@ -708,25 +776,29 @@ __device__ __forceinline__ void bwd_value_wide_body(
         MSDA_STAMP(1);
         // 1b. histogram of the listed points' taps (dense lanes: ~4 atomics per 64 listed points)
         {
-            const int kept = min(*kept_p, list_cap);
+            // DET: the wavefront walks its own list segment (64 entries per step); else all threads share one list
+            const int kept = DET ? min(kept_w[wave], seg) : min(*kept_p, list_cap);
+            const uint16_t *mylist = list + (DET ? wave * seg : 0);
+            const int me = DET ? lane : tid, stride = DET ? kWave : kSBlock;
             // up to 8 loads in flight per thread (a coarse level lists several thousand points); the slots past the
             // list's end are skipped as a whole (uniform test)
             constexpr int UH = 8;
-            for (int base = 0; base < kept; base += kSBlock * UH) {
+            for (int base = 0; base < kept; base += stride * UH) {
                 float2 xy[UH];
 #pragma unroll
                 for (int u = 0; u < UH; ++u) {
-                    const int i = base + u * kSBlock + tid;
+                    const int i = base + u * stride + me;
                     xy[u] = make_float2(-8.f, -8.f);
-                    if (i < kept) { int q; xy[u] = loc2[point_of(p0 + list[i], q)]; }
+                    if (i < kept) { int q; xy[u] = loc2[point_of(p0 + mylist[i], q)]; }
                 }
 #pragma unroll
                 for (int u = 0; u < UH; ++u) {
-                    if (base + u * kSBlock >= kept) break;
+                    if (base + u * stride >= kept) break;
                     int dest[4]; PointGeom<float> g;
                     taps_of(xy[u], dest, g);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) if (dest[t] >= 0) atomicAdd(&cnt[dest[t]], 1);
+                    for (int t = 0; t < 4; ++t)
+                        if (dest[t] >= 0) { if (DET) det_count_only(cnt, dest[t], wave); else atomicAdd(&cnt[dest[t]], 1); }
                 }
             }
         }
@@ -736,6 +808,9 @@ __device__ __forceinline__ void bwd_value_wide_body(
         const int CH = (npx + kSBlock - 1) / kSBlock;
         const int r0 = tid * CH;
         int mine = 0, big = 0;
+        if (DET) {                                           // row totals; the packed counts become within-row prefixes (cursors)
+            for (int k = 0; k < CH; ++k) if (r0 + k < npx) { const int t = det_row_prefix(cnt, r0 + k); tot[r0 + k] = t; mine += t; big = max(big, t); }
+        } else
         for (int k = 0; k < CH; ++k) if (r0 + k < npx) { mine += cnt[r0 + k]; big = max(big, cnt[r0 + k]); }
         int incl = mine;
 #pragma unroll
@@ -751,7 +826,7 @@ __device__ __forceinline__ void bwd_value_wide_body(
 #pragma unroll
             for (int w2 = 0; w2 < kSWaves; ++w2) { if (w2 < wave) excl += ws[w2]; total += ws[w2]; }
         }
-        for (int k = 0; k < CH; ++k) if (r0 + k < npx) { start[r0 + k] = excl; excl += cnt[r0 + k]; }
+        for (int k = 0; k < CH; ++k) if (r0 + k < npx) { start[r0 + k] = excl; excl += tot[r0 + k]; }
         __syncthreads();
         MSDA_STAMP(3);
         return total;
@@ -763,23 +838,25 @@ __device__ __forceinline__ void bwd_value_wide_body(
 
     // steps 3-4 for the listed points.  A record = {weight, query relative to the chunk's first query (16 bits)}.
     auto scatter_and_gather = [&](int p0, int total, bool first) {
-        const int kept = *kept_p;
+        const int kept = DET ? kept_w[wave] : *kept_p;
+        const uint16_t *mylist = list + (DET ? wave * seg : 0);
+        const int me = DET ? lane : tid, stride = DET ? kWave : kSBlock;
         const int qbase = fdiv(p0, P, p_shift);
         constexpr int U = 8;
-        for (int base = 0; base < kept; base += kSBlock * U) {
+        for (int base = 0; base < kept; base += stride * U) {
             float2 xy[U]; float at[U]; int qq[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int i = base + u * kSBlock + tid;
+                const int i = base + u * stride + me;
                 xy[u] = make_float2(-8.f, -8.f); at[u] = 0.f; qq[u] = 0;
                 if (i < kept) {
-                    const unsigned pi = point_of(p0 + list[i], qq[u]);
+                    const unsigned pi = point_of(p0 + mylist[i], qq[u]);
                     xy[u] = loc2[pi]; at[u] = attn[pi];
                 }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if (base + u * kSBlock >= kept) break;                           // uniform
+                if (base + u * stride >= kept) break;                            // uniform
                 int dest[4]; PointGeom<float> g;
                 taps_of(xy[u], dest, g);
                 const float hh = 1.f - g.lh, hw = 1.f - g.lw;
@@ -787,14 +864,18 @@ __device__ __forceinline__ void bwd_value_wide_body(
                 const uint16_t qrel = (uint16_t)(qq[u] - qbase);
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
-                    if (dest[t] >= 0) { const int pos = atomicAdd(&start[dest[t]], 1); rw[pos] = tw[t]; rq[pos] = qrel; }
+                    if (dest[t] >= 0) {
+                        // DET: the cursor is this wavefront's 16-bit share of the row (start[] stays the row's beginning)
+                        const int pos = DET ? start[dest[t]] + det_count(cnt, dest[t], wave) : atomicAdd(&start[dest[t]], 1);
+                        rw[pos] = tw[t]; rq[pos] = qrel;
+                    }
             }
         }
         __syncthreads();
         MSDA_STAMP(4);
         // rows of comparable length (the longest no more than one lane group's share): the balanced walk
         if (longest_row() * 64 <= max(total, 1024)) {
-            gather_balanced<VT, GT, true>(go_base, gv_base, cnt, start, RecSoa{rw, rq, qbase, row_stride}, reinterpret_cast<int *>(list), npx,
+            gather_balanced<VT, GT, !DET>(go_base, gv_base, tot, start, RecSoa{rw, rq, qbase, row_stride}, reinterpret_cast<int *>(list), npx,
                                           row_stride, total, first);
             MSDA_STAMP(5);
             return;
@@ -802,7 +883,7 @@ __device__ __forceinline__ void bwd_value_wide_body(
         // rows of very different lengths (coarse levels): equal stretches of records, parts combined by the row's owner.
         // (Measured against it: the split gather for every row mix — same at cfg-2 / cfg-4 encoder, but on the single-pass
         // path 784 six-record rows cost 19.5 instead of 14.5 us; gather_rows here: 20.2 instead of 11.3 us per workgroup.)
-        gather_split<VT, GT, true>(go_base, gv_base, cnt, start, RecSoa{rw, rq, qbase, row_stride}, reinterpret_cast<float4 *>(list), npx,
+        gather_split<VT, GT, !DET>(go_base, gv_base, tot, start, RecSoa{rw, rq, qbase, row_stride}, reinterpret_cast<float4 *>(list), npx,
                                    row_stride, total, first);
         MSDA_STAMP(5);
     };
@@ -816,7 +897,12 @@ __device__ __forceinline__ void bwd_value_wide_body(
         const int a1 = min(NP, a + step);
         __syncthreads();                                     // the previous attempt / gather still reads the LDS arrays
         const int t = count_points(a, a1);
-        if (t > rec_cap || *kept_p > list_cap) {             // uniform: LDS values read after a barrier
+        bool list_full = *kept_p > list_cap;
+        if (DET) {
+#pragma unroll
+            for (int w2 = 0; w2 < kSWaves; ++w2) list_full = list_full || kept_w[w2] > seg;
+        }
+        if (t > rec_cap || list_full) {                      // uniform: LDS values read after a barrier
             const long long even = (long long)(a1 - a) * (rec_cap - rec_cap / 8) / max(t, 1);
             step = max(wide_chunk, (int)min(even, (long long)(a1 - a) / 2));
             continue;
