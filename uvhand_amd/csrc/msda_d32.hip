@@ -610,18 +610,31 @@ static int allow_lds(const void *fn, size_t bytes);
 // CU, 512 threads each) unless that would leave fewer than one sub-batch per workgroup; MSDA_LDS=0/1 overrides (tuning).
 struct LdsPlan { bool use; int chunks, qw, stage_rows; size_t lds; };
 template <typename VT>
-static LdsPlan plan_lds(int N, int S, int M, int L, int Lq, int P)
+static LdsPlan plan_lds(int N, int S, int M, int L, int Lq, int P, long long role_b_wgs = 0)
 {
     static const int mode = env_int("MSDA_LDS", -1);
-    static const int target = env_int("MSDA_LDS_WGS", 512);              // two 512-thread workgroups per CU: ONE round
+    static const int target_alone = env_int("MSDA_LDS_WGS", 512);        // two 512-thread workgroups per CU: ONE round
+    static const int target_fused = env_int("MSDA_LDS_WGS_BWD", 0);      // role A inside the fused backward launch (0: rule below)
+    // Inside the fused backward role B's workgroups are dispatched first.  If they leave slots free (a launch of fewer than
+    // the 512 resident workgroups), role A gets one round in exactly those slots; behind several rounds of role B it is cut
+    // finer, so that the launch does not end on a few long role-A workgroups (cfg-2 encoder: 384 role-B workgroups -> 128
+    // for role A, 59.4 -> 57.0 us; cfg-4 encoder: 2048 -> 1024, 219 -> 215 us; profiles/r03_notes.md).
+    int target = target_alone;
+    if (role_b_wgs > 0) target = target_fused > 0 ? target_fused : role_b_wgs < 512 ? (int)max(64LL, 512 - role_b_wgs) : 1024;
     LdsPlan pl;
     const long long pairs = (long long)N * M, items = pairs * Lq;
     pl.stage_rows = min(S, kLStageBytes / (int)(kD * sizeof(VT)));
-    // chunks per pair: the whole launch resident at once when possible (every workgroup stages its pair's levels once and
-    // all of them finish together), but at least one octet per wavefront; qw a multiple of 8 queries
+    // chunks per pair: about `target` workgroups in all, at least one octet per wavefront — and at least two per wavefront
+    // when cutting finer than one resident round (10 octets on 8 wavefronts leave six of them idle half the time:
+    // cfg-4 decoder 76 -> 82 us)
     const int octets = ceil_div(Lq, 8);
-    const int want_chunks = (int)max(1LL, min((long long)ceil_div(octets, kLWaves), (target + pairs - 1) / pairs));
-    pl.qw = 8 * ceil_div(octets, want_chunks);
+    auto octets_per_wg = [&](int tgt) {
+        const int want_chunks = (int)max(1LL, min((long long)ceil_div(octets, kLWaves), (tgt + pairs - 1) / pairs));
+        return ceil_div(octets, want_chunks);
+    };
+    int opw = octets_per_wg(target);
+    if (target > 512 && opw < 2 * kLWaves) opw = octets_per_wg(512);
+    pl.qw = 8 * opw;
     pl.chunks = ceil_div(Lq, pl.qw);
     pl.lds = lds_variant_bytes<VT>(pl.stage_rows, L * P);
     const bool large = items >= 32768 && Lq >= kLItems;                       // below that the launch is latency-bound
@@ -895,6 +908,7 @@ static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *
         const ValuePlan pl = plan_value<GT>(N, S, M, L, Lq, P, target_wgs);
         const long long nB = (long long)pl.W * N * M * L;
         // ---- large problems: one launch, role A on the LDS-stage body ----
+        if (lds_a.use) lds_a = plan_lds<VT>(N, S, M, L, Lq, P, nB);      // cut role A for the slots role B leaves
         if (bwd_mode == 0 && lds_a.use && pl.ppt == kSinglePPT && (pl.acc == kAccNone || pl.acc == kAccWide) &&
             nB + (long long)N * M * lds_a.chunks <= 0x7fffffffLL) {
             const dim3 fgrid((unsigned)(nB + (long long)N * M * lds_a.chunks));
@@ -1041,7 +1055,7 @@ static int launch_bwd_prologue_t(const VT *grad_out, const VT *value, const int6
         return set_error(MSDA_ERR_ARGUMENT, "msda backward (fused prologue): geometry not supported");
     const PrologueOut pro{grad_ref, (int)((ld_grad_offsets - 2LL * M * LP) / 2), (int)(ld_grad_logits - (long long)M * LP)};
     // ---- large problems: role A on the LDS-stage body; it leaves grad_ref per head in the caller's scratch ----
-    const LdsPlan lq = plan_lds<VT>(N, S, M, L, Lq, P);
+    const LdsPlan lq = plan_lds<VT>(N, S, M, L, Lq, P, nB);
     const size_t heads_bytes = prologue_heads_bytes(N, M, L, Lq);
     if (lq.use && workspace != nullptr && ws_bytes >= heads_bytes && ((uintptr_t)workspace & 7) == 0 &&
         (pl.acc == kAccNone || pl.acc == kAccWide) && nB + (long long)N * M * lq.chunks <= 0x7fffffffLL) {
