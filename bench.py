@@ -20,9 +20,15 @@ the same line also carries `eager_ms_per_step` (plain autograd calls, what a dro
 module runs) and `graph1_ms_per_step` (one graph launch per step) next to the headline.
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra
 objects: `roofline` (dominant kernel = backward; algorithmic bytes / HIP-event time
-against the 8 TB/s HBM peak) and `cpu_baseline` (the PyTorch-CPU fallback port timed
-on the host cores of this node; test infrastructure under oracle/, never the thing
-measured as `value`).
+against the 8 TB/s HBM peak; `traffic` = HBM bytes per launch from the PMC passes, only
+while the kernel sources are the profiled ones) and `cpu_baseline` (the PyTorch-CPU
+fallback port timed on the host cores of this node; test infrastructure under oracle/,
+never the thing measured as `value`).  At N = 1 the same line carries the rest of
+DESIGN.md's performance table, measured in the same run (none of it is `value`):
+`workloads` — cfg2_encoder / cfg4_decoder / cfg4_encoder in fp32 and cfg2_decoder with
+bf16 rows: graph-replay step, the two kernels on their own, algorithmic bytes and
+fractions — and `modules` — the MSDeformAttn module forward+backward at cfg2_decoder and
+cfg4_encoder, fp32 and autocast-bf16, per HIP graph and eager wall time (--no-table skips both).
 """
 import argparse
 import json
