@@ -207,3 +207,15 @@ def test_argument_errors_are_reported_before_anything_is_launched(native):
     lib.msda_unflatten_workspace_bytes.argtypes = [I, V, V, I, I]
     hs4, ws4 = (I * 4)(28, 14, 7, 4), (I * 4)(28, 14, 7, 4)
     assert lib.msda_unflatten_workspace_bytes(4, hs4, ws4, 32, 256) == 32 * (13 + 4 + 1 + 1) * 4 * 64 * 4
+
+
+def test_int32_row_offsets_bound_the_d32_family():
+    """Role B's gathers form q * M*32 in 32 bits: the tiled family only takes geometries with N*Lq*M*32 < 2^31 (others go to
+    the generic kernels, whose indices are 64-bit).  Host logic only: no launch."""
+    import ctypes
+    lib = ctypes.CDLL(os.path.join(ROOT, "uvhand_amd", "libmsda_hip.so"))
+    lib.msda_prologue_supported.restype = ctypes.c_int
+    lib.msda_prologue_supported.argtypes = [ctypes.c_int] * 7
+    # N = 1, M = 8, L = 1, P = 4: every other limit of the family (items < 2^30, items*L*P*2 < 2^31) still holds at Lq = 2^23
+    assert lib.msda_prologue_supported(1, 64, 8, 32, 1, (1 << 23) - 8, 4) == 1          # 2^31 - 2048 elements of out / grad_out
+    assert lib.msda_prologue_supported(1, 64, 8, 32, 1, 1 << 23, 4) == 0               # exactly 2^31
