@@ -225,7 +225,7 @@ int msda_backward_prologue_bf16_gv32(const uint16_t *grad_out, const uint16_t *v
  * (models/ops/modules/ms_deform_attn.py:96,100,101,139), as a split-M fp32-MFMA kernel with a
  * fixed-order reduction (bitwise reproducible).  N and K must be multiples of 4; grad_bias may be
  * NULL; `workspace` must hold msda_linear_wgrad_workspace_bytes(M, N, K) bytes (may be 0 -> NULL ok).
- * The forward GEMM and the input gradient stay on the vendor BLAS. */
+ * The forward GEMM and the input gradient: msda_linear_forward_f32 / msda_linear_dgrad_f32 below. */
 unsigned long long msda_linear_wgrad_workspace_bytes(int M, int N, int K);
 int msda_linear_wgrad_f32(const float *grad_out, const float *input, int M, int N, int K,
                           float *grad_weight, float *grad_bias, void *workspace, msda_stream_t stream);
@@ -246,6 +246,20 @@ int msda_linear_wgrad_masked_f32(const float *grad_out, const float *input, cons
 int msda_linear_wgrad_masked_bf16(const uint16_t *grad_out, const uint16_t *input, const uint8_t *row_mask, int M, int N, int K,
                                   float *grad_weight, float *grad_bias, void *workspace, msda_stream_t stream);
 int msda_zero_masked_rows_f32(float *x, const uint8_t *row_mask, long long rows, int cols, msda_stream_t stream);
+
+/* Forward and input gradient of the same fp32 layers (nn.Linear semantics, models/ops/modules/ms_deform_attn.py:96,100,101,139
+ * and what autograd derives for them):
+ *     output[rows, out]    = input[rows, in] . weight[out, in]^T + bias[out]        (bias may be NULL)
+ *     grad_input[rows, in] = grad_out[rows, out] . weight[out, in]
+ * as one plain fp32-MFMA launch each (exact fp32 products, fixed summation order: bitwise reproducible) — at this module's
+ * shapes the vendor BLAS path costs more on the host (~27 us per GEMM through torch) than these kernels run for.  row_mask
+ * (may be NULL; one byte per row): rows with a non-zero byte are WRITTEN AS ZEROS — value.masked_fill(padding_mask, 0) after
+ * value_proj (modules/ms_deform_attn.py:97-98) and its backward, without a second pass.  out_features and in_features must
+ * be multiples of 4, all operands 16-byte aligned and contiguous. */
+int msda_linear_forward_f32(const float *input, const float *weight, const float *bias, const uint8_t *row_mask, long long rows,
+                            int out_features, int in_features, float *output, msda_stream_t stream);
+int msda_linear_dgrad_f32(const float *grad_out, const float *weight, const uint8_t *row_mask, long long rows, int out_features,
+                          int in_features, float *grad_input, msda_stream_t stream);
 
 /* Thread-local description of the last failure on the calling thread ("" if none). */
 /* ---- Residual add + LayerNorm of the layers around the op --------------------------
@@ -286,7 +300,7 @@ const char *msda_last_error(void);
 /* Library/ABI version (major*100 + minor) and the kernel family a geometry maps to.  MSDA_ABI_VERSION is what a binding
  * compiled against THIS header expects msda_version() to return at run time (uvhand_amd/_ext.py compares the two);
  * it changes whenever a declaration in this file does. */
-#define MSDA_ABI_VERSION 112
+#define MSDA_ABI_VERSION 113
 int msda_version(void);
 int msda_path_for(int elem_bytes, int M, int D, int L, int P);
 

@@ -50,7 +50,11 @@ def test_bracket_linear_equals_nn_linear():
     x.grad = None; lin.zero_grad()
     y_ref = lin(x)
     y_ref.backward(go)
-    assert torch.equal(y, y_ref)                                       # same forward GEMM
+    # a small layer: the library's own forward / input-gradient kernels (exact fp32 MFMA) — both sides against fp64
+    y64 = x.detach().double() @ lin.weight.detach().double().t() + lin.bias.detach().double()
+    gx64 = go.double() @ lin.weight.detach().double()
+    assert rel_err(y.detach().cpu().numpy(), y64.cpu().numpy()) < 2e-6 and rel_err(y_ref.detach().cpu().numpy(), y64.cpu().numpy()) < 2e-6
+    assert rel_err(got[0].cpu().numpy(), gx64.cpu().numpy()) < 2e-6
     assert torch.allclose(got[0], x.grad, rtol=1e-5, atol=1e-5)
     assert rel_err(got[1].cpu().numpy(), lin.weight.grad.cpu().numpy()) < 2e-6
     assert rel_err(got[2].cpu().numpy(), lin.bias.grad.cpu().numpy()) < 2e-6
@@ -82,6 +86,22 @@ def test_masked_wgrad_and_zero_rows(M, N, K, frac):
         _native.linear_wgrad(dy, x, row_mask=mask[:-1])
 
 
+def test_large_bracket_linear_keeps_the_vendor_gemm():
+    """Beyond ~5000 rows x 256 features the forward and the input gradient stay on the vendor BLAS (its macro-tiles run 1.3x
+    faster there): bit-identical to nn.Linear."""
+    from uvhand_amd.functions.linear_func import bracket_linear
+    torch.manual_seed(2)
+    lin = torch.nn.Linear(256, 256).cuda()
+    x = torch.randn(2, 3060, 256).cuda().requires_grad_(True)
+    go = torch.randn(2, 3060, 256).cuda()
+    y = bracket_linear(x, lin)
+    y.backward(go)
+    gx = x.grad.clone(); x.grad = None
+    y_ref = lin(x)
+    y_ref.backward(go)
+    assert torch.equal(y, y_ref) and torch.equal(gx, x.grad)
+
+
 def test_bracket_linear_masked_equals_linear_then_masked_fill():
     """value_proj + padding mask (modules/ms_deform_attn.py:96-98) through the masked-rows path."""
     from uvhand_amd.functions.linear_func import bracket_linear_masked
@@ -98,7 +118,8 @@ def test_bracket_linear_masked_equals_linear_then_masked_fill():
     x.grad = None; lin.zero_grad()
     y_ref = lin(x).masked_fill(mask[..., None], 0.0)
     y_ref.backward(go)
-    assert torch.equal(y, y_ref)
+    y64 = (x.detach().double() @ lin.weight.detach().double().t() + lin.bias.detach().double()).masked_fill(mask[..., None], 0.0)
+    assert rel_err(y.detach().cpu().numpy(), y64.cpu().numpy()) < 2e-6 and not y[mask].any()
     assert torch.allclose(got[0], x.grad, rtol=1e-5, atol=1e-5) and not got[0][mask].any()
     assert rel_err(got[1].cpu().numpy(), lin.weight.grad.cpu().numpy()) < 2e-6
     assert rel_err(got[2].cpu().numpy(), lin.bias.grad.cpu().numpy()) < 2e-6
@@ -182,3 +203,62 @@ def test_bracket_linear_under_bf16_autocast_uses_the_kernel_and_tracks_stock_aut
     assert torch.equal(got[0], y2.detach().float())                       # same forward
     for a, b in ((got[1], x.grad), (got[2], layer.weight.grad), (got[3], layer.bias.grad)):
         assert (a - b).abs().max().item() < 2e-2 * b.abs().max().item()   # stock rounds dW to bf16; the kernel does not
+
+
+# ---- forward and input gradient of the same layers (msda_linear_forward_f32 / msda_linear_dgrad_f32) ----
+
+def _random_rows_shapes(n, seed):
+    rng = np.random.RandomState(seed)
+    out = [(600, 256, 256, 0.0), (600, 384, 256, 0.0), (6120, 256, 256, 0.1), (33440, 256, 256, 0.0), (1, 4, 4, 0.0),
+           (63, 64, 32, 0.5), (65, 68, 36, 0.0), (129, 132, 100, 1.0), (2, 1024, 256, 0.0), (300, 256, 1024, 0.2)]
+    for _ in range(n):
+        out.append((int(rng.randint(1, 700)), 4 * int(rng.randint(1, 100)), 4 * int(rng.randint(1, 100)), float(rng.choice([0.0, 0.3]))))
+    return out
+
+
+@pytest.mark.parametrize("rows,out_f,in_f,frac", _random_rows_shapes(12, 11))
+def test_linear_forward_and_dgrad_match_fp64(rows, out_f, in_f, frac):
+    """nn.Linear forward (modules/ms_deform_attn.py:96,100,101,139) and its input gradient, masked rows written as zeros
+    (modules/ms_deform_attn.py:97-98), against the fp64 composition; exact-fp32 MFMA: tolerance of an fp32 dot product."""
+    from uvhand_amd import _native
+    g = torch.Generator().manual_seed(rows * 31 + out_f * 7 + in_f)
+    x = torch.randn(rows, in_f, generator=g).cuda()
+    w = (torch.randn(out_f, in_f, generator=g) * 0.1).cuda()
+    b = torch.randn(out_f, generator=g).cuda()
+    gy = torch.randn(rows, out_f, generator=g).cuda()
+    mask = (torch.rand(rows, generator=g) < frac).cuda() if frac > 0 else None
+    y = _native.linear_forward(x, w, b, mask)
+    y_nb = _native.linear_forward(x, w, None, None)
+    gx = _native.linear_dgrad(gy, w, mask)
+    y64 = x.double() @ w.double().t() + b.double()
+    gx64 = gy.double() @ w.double()
+    if mask is not None:
+        y64 = y64.masked_fill(mask[:, None], 0.0)
+        gx64 = gx64.masked_fill(mask[:, None], 0.0)
+        assert (y[mask] == 0).all() and (gx[mask] == 0).all()              # exact zeros, not small numbers
+    assert rel_err(y.cpu().numpy(), y64.cpu().numpy()) < 2e-6
+    assert rel_err(y_nb.cpu().numpy(), (x.double() @ w.double().t()).cpu().numpy()) < 2e-6
+    assert rel_err(gx.cpu().numpy(), gx64.cpu().numpy()) < 2e-6
+    # reproducible
+    assert torch.equal(_native.linear_forward(x, w, b, mask), y) and torch.equal(_native.linear_dgrad(gy, w, mask), gx)
+
+
+def test_linear_forward_handles_nan_free_padding_and_empty():
+    """Rows past the matrix and columns past the weight never leak into the result (poisoned neighbours), rows = 0 is a no-op."""
+    from uvhand_amd import _native
+    big = torch.full((70 * 40 + 64,), float("nan"), device="cuda")
+    x = big[32:32 + 70 * 40].view(70, 40)
+    x.copy_(torch.randn(70, 40))
+    wbig = torch.full((36 * 40 + 64,), float("nan"), device="cuda")
+    w = wbig[32:32 + 36 * 40].view(36, 40)
+    w.copy_(torch.randn(36, 40))
+    y = _native.linear_forward(x, w)
+    assert torch.isfinite(y).all()
+    assert rel_err(y.cpu().numpy(), (x.double() @ w.double().t()).cpu().numpy()) < 2e-6
+    gy = torch.randn(70, 36, device="cuda")
+    assert torch.isfinite(_native.linear_dgrad(gy, w)).all()
+    assert _native.linear_forward(x[:0], w).shape == (0, 36)
+    with pytest.raises(RuntimeError):
+        _native.linear_forward(torch.randn(8, 6, device="cuda"), torch.randn(8, 6, device="cuda"))     # 6 % 4 != 0
+    with pytest.raises(RuntimeError):
+        _native.linear_forward(x.double(), w.double())

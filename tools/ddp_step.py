@@ -20,6 +20,7 @@ Per rank: batch 1 x window `--window` frames folded into the batch (tempo_infere
 224x224 crops -> levels 28/14/7/4 (S = 1045), i.e. BASELINE cfg-4.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -115,6 +116,13 @@ def main():
                          "(engine.py:617-625, util/misc.py:186-192)")
     ap.add_argument("--host-matcher", action="store_true",
                     help="f4 A/B: Hungarian matching on the host inside the step (models/matcher.py:120-123: C.cpu() + scipy)")
+    ap.add_argument("--no-cpp-node", action="store_true",
+                    help="A/B: the attention modules as the Python composition of their kernels instead of one C++ autograd node")
+    ap.add_argument("--no-gc-freeze", action="store_true",
+                    help="A/B: leave the interpreter's collector as it is.  By default everything alive after the warm-up is moved "
+                         "to the permanent generation (gc.freeze): a full collection walks the ~10^6 objects `import torch` "
+                         "leaves behind in 8-9 ms, and with few Python objects per step (the C++ nodes) those pauses land in "
+                         "the clip + optimizer phase, where nothing is queued behind them (profiles/r03_notes.md §8)")
     ap.add_argument("--plain-layers", action="store_true",
                     help="A/B: stock add + LayerNorm and stock FFN weight gradients inside the layers")
     ap.add_argument("--amp", default="", choices=["", "bf16"],
@@ -154,10 +162,10 @@ def main():
     valid_ratios = torch.ones(args.window, len(shapes_list), 2, device=device)         # unpadded crops
     enc_ref = encoder_reference_points(shapes_list, valid_ratios, device)               # [window, S, L, 2]
 
-    if args.amp == "bf16":
-        for mod in model.modules():
-            if isinstance(mod, MSDeformAttn):
-                mod.bf16_storage = True
+    for mod in model.modules():
+        if isinstance(mod, MSDeformAttn):
+            mod.bf16_storage = args.amp == "bf16"
+            mod.cpp_node = not args.no_cpp_node
 
     num_err = torch.zeros(1, dtype=torch.int64, device=device)
 
@@ -189,6 +197,9 @@ def main():
 
     for _ in range(args.warmup):
         loss = step()
+    if not args.no_gc_freeze:
+        gc.collect()
+        gc.freeze()
     harness.barrier(device)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -213,6 +224,8 @@ def main():
                           "per_rank": {"window": args.window, "S": S, "queries": args.queries, "enc": args.enc,
                                        "dec": args.dec, "ballast_mb": args.ballast_mb, "amp": args.amp or None,
                                        "dropout": args.dropout, "layers": "plain" if args.plain_layers else "fused",
+                                       "attention_modules": "python" if args.no_cpp_node else "cpp_node",
+                                       "gc_frozen": not args.no_gc_freeze,
                                        "vote": args.vote, "find_unused_parameters": args.find_unused,
                                        "reduce_dict": args.reduce_dict, "host_matcher": args.host_matcher},
                           "runtime": runtime,

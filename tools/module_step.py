@@ -19,6 +19,7 @@ torch.manual_seed(0)
 mod = MSDeformAttn(M * D, len(shapes), M, P).to(dev)
 mod.fused_prologue = fused
 mod.merged_projection = merged
+mod.cpp_node = os.environ.get("MODULE_CPP_NODE", "1") != "0"        # 0: the Python composition of the same kernels
 with torch.no_grad():
     for p in mod.parameters():
         p.add_(torch.randn_like(p) * 0.02)
@@ -58,9 +59,13 @@ with torch.cuda.stream(st):
     for _ in range(3):
         run()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    import time
+    st.synchronize(); t0 = time.perf_counter()
     e0.record(st)
     for _ in range(iters):
         run()
+    t_enq = time.perf_counter() - t0
     e1.record(st); e1.synchronize()
-print("%s module fwd+bwd%s%s: %.1f us per step" % (name, " (autocast bf16 + bf16 storage)" if amp else "",
-      " [HIP graph]" if use_graph else " [eager]", e0.elapsed_time(e1) * 1e3 / iters))
+print("%s module fwd+bwd%s%s%s: %.1f us per step (host enqueue %.1f us per step)" % (
+      name, " (autocast bf16 + bf16 storage)" if amp else "", " [HIP graph]" if use_graph else " [eager]",
+      "" if mod.cpp_node else " [Python composition]", e0.elapsed_time(e1) * 1e3 / iters, t_enq * 1e6 / iters))

@@ -29,7 +29,7 @@ _SYMBOLS = (
     "msda_add_layernorm_workspace_bytes", "msda_add_layernorm_forward_f32", "msda_add_layernorm_backward_f32",
     "msda_flatten_levels_f32", "msda_unflatten_levels_f32", "msda_unflatten_workspace_bytes",
     "msda_linear_wgrad_f32", "msda_linear_wgrad_masked_f32", "msda_linear_wgrad_masked_bf16", "msda_linear_wgrad_workspace_bytes",
-    "msda_zero_masked_rows_f32",
+    "msda_zero_masked_rows_f32", "msda_linear_forward_f32", "msda_linear_dgrad_f32",
     "msda_prologue_supported", "msda_forward_prologue_f32", "msda_backward_prologue_f32",
     "msda_last_error", "msda_version", "msda_path_for", "msda_force_path",
 )
@@ -344,6 +344,49 @@ def linear_wgrad(grad_out, inp, want_bias=True, row_mask=None):
     if rc != 0:
         _raise(lib, rc, "linear_wgrad")
     return gw, gb
+
+
+def linear_rows_supported(a, weight, reduce_dim):
+    """fp32 contiguous [rows, reduce] matrix and [out, in] weight on one GPU, both feature counts multiples of 4, 16-byte aligned."""
+    return (a.is_cuda and weight.is_cuda and a.device == weight.device and a.dtype == torch.float32 and weight.dtype == torch.float32
+            and a.dim() == 2 and weight.dim() == 2 and a.is_contiguous() and weight.is_contiguous()
+            and a.shape[1] == weight.shape[reduce_dim] and weight.shape[0] % 4 == 0 and weight.shape[1] % 4 == 0
+            and a.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0)
+
+
+def linear_forward(inp, weight, bias=None, row_mask=None):
+    """inp[rows, in] @ weight[out, in].T + bias, rows with row_mask[r] True written as zeros — include/msda.h
+    (msda_linear_forward_f32): one fp32-MFMA launch, fixed summation order."""
+    lib = _lib or load()
+    if not linear_rows_supported(inp, weight, 1) or (bias is not None and not (
+            bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == weight.shape[0]
+            and bias.device == inp.device and bias.data_ptr() % 16 == 0)):
+        raise RuntimeError("linear_forward: expected contiguous fp32 CUDA [rows, in] and [out, in] (+ [out]) with in, out % 4 == 0")
+    rows, out_f, in_f = inp.shape[0], weight.shape[0], weight.shape[1]
+    with _DeviceGuard(inp.device):
+        y = torch.empty((rows, out_f), dtype=torch.float32, device=inp.device)
+        rc = _entry(lib, "msda_linear_forward_f32", [_VP, _VP, _VP, _VP, _LL, _CI, _CI, _VP, _VP])(
+            inp.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None,
+            _row_mask_ptr(row_mask, rows, inp.device), rows, out_f, in_f, y.data_ptr(), _raw_stream(inp.device))
+    if rc != 0:
+        _raise(lib, rc, "linear_forward")
+    return y
+
+
+def linear_dgrad(grad_out, weight, row_mask=None):
+    """grad_out[rows, out] @ weight[out, in], rows with row_mask[r] True written as zeros — include/msda.h (msda_linear_dgrad_f32)."""
+    lib = _lib or load()
+    if not linear_rows_supported(grad_out, weight, 0):
+        raise RuntimeError("linear_dgrad: expected contiguous fp32 CUDA [rows, out] and [out, in] with in, out % 4 == 0")
+    rows, out_f, in_f = grad_out.shape[0], weight.shape[0], weight.shape[1]
+    with _DeviceGuard(grad_out.device):
+        gx = torch.empty((rows, in_f), dtype=torch.float32, device=grad_out.device)
+        rc = _entry(lib, "msda_linear_dgrad_f32", [_VP, _VP, _VP, _LL, _CI, _CI, _VP, _VP])(
+            grad_out.data_ptr(), weight.data_ptr(), _row_mask_ptr(row_mask, rows, grad_out.device), rows, out_f, in_f,
+            gx.data_ptr(), _raw_stream(grad_out.device))
+    if rc != 0:
+        _raise(lib, rc, "linear_dgrad")
+    return gx
 
 
 def prologue_supported(value, reference_points, sampling_offsets, attn_logits):

@@ -2,6 +2,7 @@
 // selection, error reporting.  No torch types, no allocation, no device synchronisation.
 #include <cstdio>
 #include <cstring>
+#include <string>
 
 #include "msda_launch.h"
 
@@ -479,6 +480,36 @@ int msda_zero_masked_rows_f32(float *x, const uint8_t *row_mask, long long rows,
     if (rows > 4LL * 0x7fffffffLL) return msda::set_error(MSDA_ERR_ARGUMENT, "msda_zero_masked_rows_f32: too many rows");
     msda::begin_call();
     return msda::launch_zero_masked_rows(x, row_mask, rows, cols, (hipStream_t)stream);
+}
+
+static int check_linear_rows(const char *who, const void *a, const void *w, const void *bias, const void *out, long long rows,
+                             int out_features, int in_features)
+{
+    if (rows < 0 || out_features <= 0 || in_features <= 0 || (out_features & 3) || (in_features & 3))
+        return msda::set_error(MSDA_ERR_ARGUMENT, (std::string(who) + ": need rows >= 0 and out_features, in_features > 0 and "
+                                                                       "multiples of 4").c_str());
+    if (w == nullptr || (rows > 0 && (a == nullptr || out == nullptr)))
+        return msda::set_error(MSDA_ERR_ARGUMENT, (std::string(who) + ": null device pointer").c_str());
+    if (((uintptr_t)a | (uintptr_t)w | (uintptr_t)out | (uintptr_t)bias) & 15)
+        return msda::set_error(MSDA_ERR_ARGUMENT, (std::string(who) + ": operands must be 16-byte aligned").c_str());
+    return MSDA_OK;
+}
+
+int msda_linear_forward_f32(const float *input, const float *weight, const float *bias, const uint8_t *row_mask, long long rows,
+                            int out_features, int in_features, float *output, msda_stream_t stream)
+{
+    if (int rc = check_linear_rows("msda_linear_forward_f32", input, weight, bias, output, rows, out_features, in_features)) return rc;
+    msda::begin_call();
+    return msda::launch_linear_forward(input, weight, bias, row_mask, rows, out_features, in_features, output, (hipStream_t)stream);
+}
+
+int msda_linear_dgrad_f32(const float *grad_out, const float *weight, const uint8_t *row_mask, long long rows, int out_features,
+                          int in_features, float *grad_input, msda_stream_t stream)
+{
+    if (int rc = check_linear_rows("msda_linear_dgrad_f32", grad_out, weight, nullptr, grad_input, rows, out_features, in_features))
+        return rc;
+    msda::begin_call();
+    return msda::launch_linear_dgrad(grad_out, weight, row_mask, rows, out_features, in_features, grad_input, (hipStream_t)stream);
 }
 
 static int check_layernorm_args(const char *who, long long rows, int d, const void *const *ptrs, int n)

@@ -101,6 +101,12 @@ int launch_linear_wgrad_bf16(const uint16_t *dY, const uint16_t *X, const uint8_
                              float *db, float *workspace, hipStream_t stream);
 int launch_zero_masked_rows(float *x, const uint8_t *mask, long long rows, int cols, hipStream_t stream);
 
+// ---- forward and input gradient of the same layers (msda_gemm.hip); row_mask (may be null): rows written as zeros ----
+int launch_linear_forward(const float *x, const float *w, const float *bias, const uint8_t *row_mask, long long rows,
+                          int out_features, int in_features, float *y, hipStream_t stream);
+int launch_linear_dgrad(const float *grad_out, const float *w, const uint8_t *row_mask, long long rows, int out_features,
+                        int in_features, float *grad_in, hipStream_t stream);
+
 // ---- transformer input assembly (msda_flatten.hip): per-level NCHW <-> the flattened [N, S, C] layout ----
 struct FlattenPlan {
     int L;

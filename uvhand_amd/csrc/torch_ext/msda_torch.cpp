@@ -256,6 +256,54 @@ inline at::Tensor wgrad_into(const at::Tensor &dY2, const at::Tensor &X2, const 
     return gw;
 }
 
+// nn.Linear forward / input gradient of the module's projections.  While the problem is small the library's own fp32-MFMA
+// kernels (msda_linear_forward_f32 / msda_linear_dgrad_f32: one plain launch, ~7 us on the host against ~18-27 us for a GEMM
+// through torch, and as fast on the GPU up to ~5000 rows at 256 features — tools/gemm_time.py); the vendor BLAS beyond, where
+// its 256 x 144 macro-tiles run 1.3x faster.  rmask (may be null): rows written as zeros.
+static bool own_linear(const at::Tensor &a2, const at::Tensor &w)
+{
+    const int64_t rows = a2.size(0), out_f = w.size(0), in_f = w.size(1);
+    return rows * out_f <= 4800LL * 256 && in_f <= 512 && out_f % 4 == 0 && in_f % 4 == 0 && w.is_contiguous() &&
+           a2.is_contiguous() && (reinterpret_cast<uintptr_t>(a2.data_ptr()) & 15) == 0 &&
+           (reinterpret_cast<uintptr_t>(w.data_ptr()) & 15) == 0;
+}
+
+static const uint8_t *mask_bytes(const at::Tensor *rmask)
+{
+    return rmask ? reinterpret_cast<const uint8_t *>(rmask->data_ptr<bool>()) : nullptr;
+}
+
+static at::Tensor linear_rows_forward(const at::Tensor &x2, const at::Tensor &w, const at::Tensor &b, const at::Tensor *rmask,
+                                      msda_stream_t stream)
+{
+    const int64_t rows = x2.size(0);
+    if (own_linear(x2, w) && b.is_contiguous() && (reinterpret_cast<uintptr_t>(b.data_ptr()) & 15) == 0) {
+        at::Tensor y = at::empty({rows, w.size(0)}, x2.options());
+        raise_if(msda_linear_forward_f32(x2.data_ptr<float>(), w.data_ptr<float>(), b.data_ptr<float>(), mask_bytes(rmask), rows,
+                                         (int)w.size(0), (int)w.size(1), y.data_ptr<float>(), stream), "msda_linear_forward");
+        return y;
+    }
+    at::Tensor y = at::addmm(b, x2, w.t());
+    if (rmask) raise_if(msda_zero_masked_rows_f32(y.data_ptr<float>(), mask_bytes(rmask), rows, (int)w.size(0), stream),
+                        "msda_zero_masked_rows");
+    return y;
+}
+
+static at::Tensor linear_rows_dgrad(const at::Tensor &g2, const at::Tensor &w, const at::Tensor *rmask, msda_stream_t stream)
+{
+    const int64_t rows = g2.size(0);
+    if (own_linear(g2, w)) {
+        at::Tensor gx = at::empty({rows, w.size(1)}, g2.options());
+        raise_if(msda_linear_dgrad_f32(g2.data_ptr<float>(), w.data_ptr<float>(), mask_bytes(rmask), rows, (int)w.size(0),
+                                       (int)w.size(1), gx.data_ptr<float>(), stream), "msda_linear_dgrad");
+        return gx;
+    }
+    at::Tensor gx = at::mm(g2, w);
+    if (rmask) raise_if(msda_zero_masked_rows_f32(gx.data_ptr<float>(), mask_bytes(rmask), rows, (int)w.size(1), stream),
+                        "msda_zero_masked_rows");
+    return gx;
+}
+
 class MSDAModuleFunction : public torch::autograd::Function<MSDAModuleFunction> {
 public:
     // inputs 0..2 may need gradients (query, centre = reference point per level, input_flatten), 5..12 are the parameters
@@ -277,13 +325,11 @@ public:
         at::Tensor rmask;
         if (mask.has_value() && mask->defined()) rmask = mask->reshape({-1}).contiguous();
         // value_proj (+ the padding mask on the masked rows only)
-        at::Tensor value = at::linear(x2, w_val, b_val);                                      // [N, S, C]
-        if (rmask.defined())
-            raise_if(msda_zero_masked_rows_f32(value.data_ptr<float>(), reinterpret_cast<const uint8_t *>(rmask.data_ptr<bool>()),
-                                               (long long)N * S, C, stream), "msda_zero_masked_rows");
+        const at::Tensor value = linear_rows_forward(x2.view({(int64_t)N * S, C}), w_val, b_val, rmask.defined() ? &rmask : nullptr,
+                                                     stream);                                 // [N*S, C]
         // sampling_offsets and attention_weights as ONE GEMM (both read the same query); the kernels read its output in place
         const at::Tensor wm = at::cat({w_off, w_attn}, 0), bm = at::cat({b_off, b_attn}, 0);
-        const at::Tensor projected = at::linear(q2, wm, bm);                                  // [N, Lq, 3*mlp]
+        const at::Tensor projected = linear_rows_forward(q2.view({(int64_t)N * Lq, C}), wm, bm, nullptr, stream);   // [N*Lq, 3*mlp]
         auto sampled = at::empty({N, Lq, C}, q2.options());
         auto loc = at::empty({N, Lq, M, L, P, 2}, q2.options()), attn = at::empty({N, Lq, M, L, P}, q2.options());
         raise_if(msda_forward_prologue_f32(value.data_ptr<float>(), shapes.data_ptr<int64_t>(), lsi.data_ptr<int64_t>(),
@@ -294,7 +340,7 @@ public:
         ctx->save_for_backward({q2, x2, rmask.defined() ? rmask : at::Tensor(), value, loc, attn, sampled, wm, w_val, w_out, shapes, lsi});
         ctx->saved_data["dims"] = std::vector<int64_t>{N, S, M, D, L, Lq, P, C};
         ctx->saved_data["det"] = deterministic;
-        return at::linear(sampled, w_out, b_out);
+        return linear_rows_forward(sampled.view({(int64_t)N * Lq, C}), w_out, b_out, nullptr, stream).view({N, Lq, C});
     }
 
     static torch::autograd::variable_list backward(torch::autograd::AutogradContext *ctx, torch::autograd::variable_list grads)
@@ -311,7 +357,7 @@ public:
         const at::Tensor *maskp = rmask.defined() ? &rmask : nullptr;
         // output_proj
         at::Tensor gb_out, gb_m, gb_val;
-        const at::Tensor g_sampled = at::matmul(go2, w_out);                                   // [N*Lq, C]
+        const at::Tensor g_sampled = linear_rows_dgrad(go2, w_out, nullptr, stream);           // [N*Lq, C]
         const at::Tensor gw_out = wgrad_into(go2, sampled.view({(int64_t)N * Lq, C}), nullptr, gb_out, true, stream);
         // the sampling kernels: gradients of value, of the raw offsets / logits (one tensor, the projection's layout) and of
         // the reference points
@@ -330,18 +376,12 @@ public:
                  "ms_deform_attn_backward_prologue");
         // merged projection
         at::Tensor g_query;
-        if (ctx->needs_input_grad(0)) g_query = at::matmul(gproj, wm).view({N, Lq, C});
+        if (ctx->needs_input_grad(0)) g_query = linear_rows_dgrad(gproj, wm, nullptr, stream).view({N, Lq, C});
         const at::Tensor gw_m = wgrad_into(gproj, q2.view({(int64_t)N * Lq, C}), nullptr, gb_m, true, stream);
         // value_proj: masked rows of grad_value count as zero (weight gradient) and get a zero input gradient
         const at::Tensor gv2 = gv.view({(int64_t)N * S, C});
         at::Tensor g_input;
-        if (ctx->needs_input_grad(2)) {
-            g_input = at::matmul(gv2, w_val);
-            if (maskp)
-                raise_if(msda_zero_masked_rows_f32(g_input.data_ptr<float>(), reinterpret_cast<const uint8_t *>(rmask.data_ptr<bool>()),
-                                                   (long long)N * S, C, stream), "msda_zero_masked_rows");
-            g_input = g_input.view({N, S, C});
-        }
+        if (ctx->needs_input_grad(2)) g_input = linear_rows_dgrad(gv2, w_val, maskp, stream).view({N, S, C});
         const at::Tensor gw_val = wgrad_into(gv2, x2.view({(int64_t)N * S, C}), maskp, gb_val, true, stream);
         return {g_query, gref, g_input, at::Tensor(), at::Tensor(), at::Tensor(),
                 gw_m.narrow(0, 0, 2 * mlp), gb_m.narrow(0, 0, 2 * mlp), gw_m.narrow(0, 2 * mlp, mlp), gb_m.narrow(0, 2 * mlp, mlp),

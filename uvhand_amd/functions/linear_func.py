@@ -2,8 +2,9 @@
 (UVHand models/ops/modules/ms_deform_attn.py:96,100,101,139) with the weight / bias gradient on the
 hand-written split-M MFMA kernel (``msda_linear_wgrad_f32``, include/msda.h).
 
-Why only that GEMM: the forward ``x @ W^T + b`` and the input gradient ``dy @ W`` run at 38-97 TFLOP/s
-on the vendor BLAS at these shapes, while the weight gradient ``dy^T @ x`` with few rows (600 at the
+The forward ``x @ W^T + b`` and the input gradient ``dy @ W`` run at 38-97 TFLOP/s on the vendor BLAS at
+these shapes and stay there when the layer is large; small layers take the library's own plain-launch kernels
+(``_own_rows`` below: host cost).  The weight gradient ``dy^T @ x`` with few rows (600 at the
 300-query decoder shape) is run by hipBLASLt as one 256x256 tile on one CU — 141 us, 0.6 TFLOP/s
 (tools/gemm_baseline.py).  Numerics: fp32 MFMA is an exact fp32 fma chain; the split-M partial sums
 are combined in a fixed order, so the result is reproducible run to run.
@@ -23,12 +24,40 @@ from torch.autograd.function import once_differentiable
 from .. import _native as MSDA
 
 
+def _own_rows(a2, weight, reduce_dim):
+    """The library's plain-launch fp32-MFMA forward / input-gradient kernels (msda_linear_forward_f32 / _dgrad_f32) take the
+    layer while it is small — ~7 us of host time per call against ~18-27 us for a GEMM through torch, and as fast on the
+    GPU up to ~5000 rows at 256 features (tools/gemm_time.py); beyond, the vendor BLAS's large macro-tiles run 1.3x faster.
+    The same rule as own_linear() in csrc/torch_ext/msda_torch.cpp, so both forms of the module run the same kernels."""
+    return (a2.shape[0] * weight.shape[0] <= 4800 * 256 and weight.shape[1] <= 512
+            and MSDA.linear_rows_supported(a2, weight, reduce_dim))
+
+
+def _rows_forward(x, weight, bias, mask=None):
+    x2 = x.reshape(-1, x.shape[-1])
+    if (x2.is_contiguous() and _own_rows(x2, weight, 1) and bias is not None and bias.is_contiguous()
+            and bias.data_ptr() % 16 == 0):
+        return MSDA.linear_forward(x2, weight, bias, mask).view(*x.shape[:-1], weight.shape[0])
+    y = F.linear(x, weight, bias)
+    if mask is not None:
+        MSDA.zero_masked_rows_(y.view(-1, y.shape[-1]), mask)
+    return y
+
+
+def _rows_dgrad(go2, weight, mask=None):
+    """go2: contiguous [rows, out]; a fresh [rows, in] buffer."""
+    if _own_rows(go2, weight, 0):
+        return MSDA.linear_dgrad(go2, weight, mask)
+    gx2 = go2 @ weight
+    return MSDA.zero_masked_rows_(gx2, mask) if mask is not None else gx2
+
+
 class _BracketLinearFn(Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return F.linear(x, weight, bias)
+        return _rows_forward(x, weight, bias)
 
     @staticmethod
     @once_differentiable
@@ -38,7 +67,7 @@ class _BracketLinearFn(Function):
         go2 = grad_out.reshape(-1, grad_out.shape[-1])
         grad_x = grad_w = grad_b = None
         if need_x:
-            grad_x = (go2 @ weight).view_as(x)
+            grad_x = _rows_dgrad(go2.contiguous(), weight).view_as(x)
         if need_w or (need_b and ctx.has_bias):
             x2 = x.reshape(-1, x.shape[-1])
             go2c, x2c = go2.contiguous(), x2.contiguous()
@@ -96,9 +125,8 @@ class _MaskedBracketLinearFn(Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, row_mask):
-        y = F.linear(x, weight, bias)
         mask = row_mask.reshape(-1).contiguous()
-        MSDA.zero_masked_rows_(y.view(-1, y.shape[-1]), mask)
+        y = _rows_forward(x, weight, bias, mask)
         ctx.save_for_backward(x, weight, mask)
         ctx.has_bias = bias is not None
         return y
@@ -111,8 +139,7 @@ class _MaskedBracketLinearFn(Function):
         go2 = grad_out.reshape(-1, grad_out.shape[-1]).contiguous()
         grad_x = grad_w = grad_b = None
         if need_x:
-            gx2 = go2 @ weight                                      # fresh buffer: safe to edit in place
-            grad_x = MSDA.zero_masked_rows_(gx2, mask).view_as(x)
+            grad_x = _rows_dgrad(go2, weight, mask).view_as(x)
         if need_w or (need_b and ctx.has_bias):
             x2 = x.reshape(-1, x.shape[-1]).contiguous()
             if MSDA.linear_wgrad_supported(go2, x2):
