@@ -134,13 +134,13 @@ int msda_backward_passes(int Lq, int P);
  * both differ in the last bits between runs.  With the flag the D = 32 kernels run the same sort + gather with one
  * counter per (pixel row, WAVEFRONT) — eight 16-bit counters packed in four LDS words per row — so that a row's
  * records end up wavefront-major in sampling-point order, a pure function of the inputs (uvhand_amd/csrc/
- * msda_d32_value.h, DET); grad_value's role runs as its own launch.  It needs no scratch: `workspace` may be NULL
+ * msda_d32_value.h, DET), inside the same single launch as the default mode.  It needs no scratch: `workspace` may be NULL
  * (msda_backward_workspace_bytes() says what a call can use; with this flag alone that is nothing).
  * Shapes that are inconsistent with S (a level whose pixels do not lie in [0, S)) never cause an
  * out-of-range access on this path: such a level contributes nothing and pixels no level covers get zeros.
  * Outside the D = 32 family (any D, fp64, element-aligned views) the flag selects a destination-major kernel that
  * adds a pixel's contributions in (query, point) order — no atomics, no scratch, rows x Lq*P point tests of work.
- * Cost on the D = 32 family: profiles/r03_notes.md.  Replaces the same reference functions as msda_backward_*. */
+ * Cost on the D = 32 family: 3-15 % over the default backward (profiles/r03_notes.md section 4).  Replaces the same reference functions as msda_backward_*. */
 #define MSDA_FLAG_DETERMINISTIC 1u
 /* msda_backward_workspace_bytes only: the size is asked for a msda_backward_prologue_* call (on large problems its
  * grad_sampling_loc / grad_attn_weight workgroups see one head each and leave the reference-point gradient per head in

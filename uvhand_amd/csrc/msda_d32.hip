@@ -504,7 +504,7 @@ __global__ __launch_bounds__(kSBlock) void bwd_value_d32_kernel(
 // (~1.5 us) and lets role A's short workgroups fill the CUs around role B's longer ones.
 // (second launch bound: 4 wavefronts per SIMD = two 512-thread workgroups per CU.  The kAccWide instantiations sit at
 // 127-128 VGPRs; one more would silently halve the occupancy — measured: cfg-4 encoder 304 -> 442 us.)
-template <int SPLIT, int ACC, typename VT, bool FUSED = false, typename GT = VT, bool FIXED = false>
+template <int SPLIT, int ACC, typename VT, bool FUSED = false, typename GT = VT, bool FIXED = false, bool DET = false>
 __global__ __launch_bounds__(kSBlock, 4) void bwd_fused_d32_kernel(
     const VT *__restrict__ grad_out, const VT *__restrict__ value,
     const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
@@ -519,8 +519,8 @@ __global__ __launch_bounds__(kSBlock, 4) void bwd_fused_d32_kernel(
         if (xcd) bid = xcd_block(bid, nB);
         int pr, l, ti, Wl;
         value_block_to_range(bid, W, L, shapes, pr, l, ti, Wl, ACC != kAccWide);
-        bwd_value_body<ACC, kSinglePPT, VT, GT, FIXED>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift,
-                                                     tp_cap, grad_value, ti, Wl, l, pr, smem);
+        bwd_value_body<ACC, kSinglePPT, VT, GT, FIXED, DET>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift,
+                                                          tp_cap, grad_value, ti, Wl, l, pr, smem);
     } else {
         // role A never touches grad_value unless it scatters with atomics (separate kernel, MSDA_BWD_MODE=atomic)
         bwd_query_body<SPLIT, false, kSBlock, VT, FUSED>(grad_out, value, shapes, level_start, loc, attn, S, M, L, Lq, P,
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(kSBlock, 4) void bwd_fused_d32_kernel(
 
 // The same single launch for LARGE problems: role B as above, role A on the LDS-stage body of msda_d32_lds.h (chunks of
 // one (batch, head) pair's queries, coarse levels served from LDS).  Both roles are 512-thread workgroups, two per CU.
-template <int ACC, typename VT, bool FUSED, typename GT, int NS>
+template <int ACC, typename VT, bool FUSED, typename GT, int NS, bool DET = false>
 __global__ __launch_bounds__(kSBlock, 4) void bwd_fused_lds_d32_kernel(
     const VT *__restrict__ grad_out, const VT *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ level_start, const float *__restrict__ loc, const float *__restrict__ attn, int S, int M, int L,
@@ -545,8 +545,8 @@ __global__ __launch_bounds__(kSBlock, 4) void bwd_fused_lds_d32_kernel(
         if (xcd) bid = xcd_block(bid, nB);
         int pr, l, ti, Wl;
         value_block_to_range(bid, W, L, shapes, pr, l, ti, Wl, ACC != kAccWide);
-        bwd_value_body<ACC, kSinglePPT, VT, GT, false>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, tp_cap,
-                                                       grad_value, ti, Wl, l, pr, smem);
+        bwd_value_body<ACC, kSinglePPT, VT, GT, false, DET>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift,
+                                                            tp_cap, grad_value, ti, Wl, l, pr, smem);
     } else {
         bwd_query_lds_body<VT, FUSED, NS>(grad_out, value, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, lp_shift, chunks,
                                           qw, stage_rows, grad_loc, grad_attn, pro,
@@ -620,7 +620,9 @@ static LdsPlan plan_lds(int N, int S, int M, int L, int Lq, int P, long long rol
     // finer, so that the launch does not end on a few long role-A workgroups (cfg-2 encoder: 384 role-B workgroups -> 128
     // for role A, 59.4 -> 57.0 us; cfg-4 encoder: 2048 -> 1024, 219 -> 215 us; profiles/r03_notes.md).
     int target = target_alone;
-    if (role_b_wgs > 0) target = target_fused > 0 ? target_fused : role_b_wgs < 512 ? (int)max(64LL, 512 - role_b_wgs) : 1024;
+    // (fewer than 128 free slots make role A's few workgroups the tail instead: deterministic cfg-2 encoder, 448 role-B
+    // workgroups -> 64 for role A 88 us, 1024 62 us)
+    if (role_b_wgs > 0) target = target_fused > 0 ? target_fused : role_b_wgs <= 512 - 128 ? (int)(512 - role_b_wgs) : 1024;
     LdsPlan pl;
     const long long pairs = (long long)N * M, items = pairs * Lq;
     pl.stage_rows = min(S, kLStageBytes / (int)(kD * sizeof(VT)));
@@ -768,7 +770,7 @@ static int allow_lds(const void *fn, size_t bytes)
 // the backward is one latency chain and role B takes the short sort (FIXED, see SOvf); bigger problems keep
 // the prefix-sum sort, whose phases hide behind other workgroups' gathers.  MSDA_BWD_FIXED=0 disables both.
 struct FusedPlan { int split; bool fixed; };
-static FusedPlan plan_fused(int items, int LP, int split, long long nB, int acc, int whole_queries_of = 0)
+static FusedPlan plan_fused(int items, int LP, int split, long long nB, int acc, int whole_queries_of = 0, bool det = false)
 {
     // whole_queries_of = M when role A must hold whole queries per workgroup (fused prologue), else 0
     static const int enabled = env_int("MSDA_BWD_FIXED", 1);
@@ -779,7 +781,7 @@ static FusedPlan plan_fused(int items, int LP, int split, long long nB, int acc,
     if (nB + n_a(split) > kResident && split == 4 && LP >= 2 && nB + n_a(2) <= kResident &&
         (whole_queries_of == 0 || (64 / 2) % whole_queries_of == 0))
         fp.split = 2;
-    fp.fixed = nB + n_a(fp.split) <= kResident;
+    fp.fixed = !det && nB + n_a(fp.split) <= kResident;      // the short sort ranks records in arrival order
     return fp;
 }
 
@@ -798,79 +800,6 @@ size_t backward_workspace_bytes(int N, int S, int M, int D, int L, int Lq, int P
 }
 #endif
 
-// ---- MSDA_FLAG_DETERMINISTIC: role B with per-wavefront counters (DET, msda_d32_value.h) as its own launch, then role A.
-// (Not fused: the flag is for reproducibility runs, and one set of DET instantiations is enough; the two launches cost a
-// launch gap over the fused one.)  FUSED = the fused-prologue entry points.
-template <typename VT, typename GT, bool FUSED>
-static int launch_bwd_det_t(const VT *grad_out, const VT *value, const int64_t *shapes, const int64_t *level_start,
-                            const float *loc, const float *attn, int N, int S, int M, int L, int Lq, int P, GT *grad_value,
-                            float *grad_loc, float *grad_attn, const PrologueOut pro, void *workspace, size_t ws_bytes,
-                            hipStream_t stream)
-{
-    const int items = N * Lq * M, LP = L * P;
-    const int item_stride = LP * kRecBytes + kItemPad;
-    const int ps = pow2_shift(P), lps = pow2_shift(LP), ms = pow2_shift(M);
-    const int xcd = xcd_remap();
-    const ValuePlan pl = plan_value<GT>(N, S, M, L, Lq, P, bwd_target_wgs(), true);
-    const long long nB = (long long)pl.W * N * M * L;
-    if (nB > 0x7fffffffLL) return set_error(MSDA_ERR_ARGUMENT, "msda backward (d32): too many grad_value workgroups");
-#define MSDA_LAUNCH_BD(AC, PPT_)                                                                       \
-    do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_value_d32_kernel<AC, PPT_, VT, GT, true>), pl.lds)) return rc; \
-         hipLaunchKernelGGL((bwd_value_d32_kernel<AC, PPT_, VT, GT, true>), dim3((unsigned)nB), dim3(kSBlock), pl.lds, stream,    \
-                            grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, ps, pl.tp_cap, pl.W, grad_value, xcd); } while (0)
-    if (pl.acc == kAccNone) MSDA_LAUNCH_BD(kAccNone, kSinglePPT);
-    else if (pl.acc == kAccTile) MSDA_LAUNCH_BD(kAccTile, kMultiPPT);
-    else MSDA_LAUNCH_BD(kAccWide, kSinglePPT);
-#undef MSDA_LAUNCH_BD
-    if (int rc = check_launch("msda backward (d32, deterministic grad_value)")) return rc;
-    // ---- role A ----
-    const LdsPlan lq = plan_lds<VT>(N, S, M, L, Lq, P);
-    if constexpr (!FUSED) {
-        if (lq.use)
-            return launch_query_lds<VT, false>(lq, grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, grad_loc,
-                                               grad_attn, pro, stream);
-    } else {
-        if (lq.use && workspace != nullptr && ws_bytes >= prologue_heads_bytes(N, M, L, Lq) && ((uintptr_t)workspace & 7) == 0) {
-            const PrologueOut pro_h{static_cast<float *>(workspace), pro.off_pad, pro.log_pad};
-            if (int rc = launch_query_lds<VT, true>(lq, grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P,
-                                                    grad_loc, grad_attn, pro_h, stream)) return rc;
-            const long long cells = (long long)N * Lq * L;
-            hipLaunchKernelGGL(ref_heads_reduce_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, stream,
-                               reinterpret_cast<const float2 *>(workspace), N * Lq, M, L, reinterpret_cast<float2 *>(pro.grad_ref));
-            return check_launch("msda backward (d32, reference-point gradient over heads)");
-        }
-    }
-    int sp = pick_split(items, LP);
-    if (FUSED) while (sp > 1 && (32 / sp) % M != 0) sp >>= 1;              // whole queries per 256-thread workgroup
-    if (!FUSED || (32 / sp) % M == 0) {
-        const int ipw = 32 / sp;
-        const size_t lds = (size_t)ipw * item_stride + (size_t)ipw * LP * 16;
-        const dim3 qgrid((items + ipw - 1) / ipw);
-#define MSDA_LAUNCH_QD(SP)                                                                             \
-        hipLaunchKernelGGL((bwd_query_d32_kernel<SP, false, VT, FUSED>), qgrid, dim3(kBlock), lds, stream, grad_out, value, shapes,  \
-                           level_start, loc, attn, S, M, L, Lq, P, items, ps, lps, ms, static_cast<VT *>(nullptr), grad_loc,        \
-                           grad_attn, xcd, pro)
-        if (sp == 4) MSDA_LAUNCH_QD(4); else if (sp == 2) MSDA_LAUNCH_QD(2); else MSDA_LAUNCH_QD(1);
-#undef MSDA_LAUNCH_QD
-        return check_launch("msda backward (d32, query-major)");
-    }
-    // more heads than a 256-thread workgroup has items: role A as the 512-thread half of the fused kernel (no role-B blocks)
-    if constexpr (FUSED) {
-        const int split = pick_split(items, LP), ipw_f = kSWaves * 8 / split;
-        const size_t lds_a = (size_t)ipw_f * item_stride + (size_t)ipw_f * LP * 16;
-        const dim3 agrid((unsigned)((items + ipw_f - 1) / ipw_f));
-#define MSDA_LAUNCH_AD(SP)                                                                             \
-        do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_fused_d32_kernel<SP, kAccNone, VT, true, float, false>), lds_a)) return rc; \
-        hipLaunchKernelGGL((bwd_fused_d32_kernel<SP, kAccNone, VT, true, float, false>), agrid, dim3(kSBlock), lds_a, stream, grad_out,   \
-                           value, shapes, level_start, loc, attn, S, M, L, Lq, P, items, ps, lps, ms, pl.tp_cap, pl.W, 0,            \
-                           static_cast<float *>(nullptr), grad_loc, grad_attn, pro, xcd); } while (0)
-        if (split == 4) MSDA_LAUNCH_AD(4); else if (split == 2) MSDA_LAUNCH_AD(2); else MSDA_LAUNCH_AD(1);
-#undef MSDA_LAUNCH_AD
-        return check_launch("msda backward (d32, query-major, 512 threads)");
-    }
-    return MSDA_OK;
-}
-
 // VT = storage of value / grad_out, GT = storage of grad_value (VT, or float for bf16 rows)
 template <typename VT, typename GT = VT>
 static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *shapes,
@@ -880,16 +809,15 @@ static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *
 {
     const int items = N * Lq * M, LP = L * P;
     const int item_stride = LP * kRecBytes + kItemPad;
-    if (deterministic)
-        return launch_bwd_det_t<VT, GT, false>(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, grad_value,
-                                               grad_loc, grad_attn, PrologueOut{nullptr, 0, 0}, workspace, ws_bytes, stream);
+    // deterministic (MSDA_FLAG_DETERMINISTIC): the same launches with role B's DET instantiations (per-wavefront counters,
+    // msda_d32_value.h) and without the short sort, which ranks a row's records in arrival order
     // tuning / A-B knobs, read once per process: MSDA_BWD_MODE=atomic selects the v1 global-atomic
     // scatter (fp32 only), =split launches role B and role A as two kernels; MSDA_BWD_WGS is the number
     // of role-B workgroups to aim for on small problems.
     static const int bwd_mode_env = [] {                   // 0 fused (default), 1 split launches, 2 v1 atomics
         const char *v = tuning_str("MSDA_BWD_MODE");
         return (v && !strcmp(v, "atomic")) ? 2 : (v && !strcmp(v, "split")) ? 1 : 0; }();
-    const int bwd_mode = (bwd_mode_env == 2 && sizeof(VT) != 4) ? 0 : bwd_mode_env;
+    const int bwd_mode = (bwd_mode_env == 2 && (sizeof(VT) != 4 || deterministic)) ? 0 : bwd_mode_env;
     const int target_wgs = bwd_target_wgs();
     const int split = pick_split(items, LP);
     const int ps = pow2_shift(P), lps = pow2_shift(LP), ms = pow2_shift(M);
@@ -905,7 +833,7 @@ static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *
     } else
 #endif
     {
-        const ValuePlan pl = plan_value<GT>(N, S, M, L, Lq, P, target_wgs);
+        const ValuePlan pl = plan_value<GT>(N, S, M, L, Lq, P, target_wgs, deterministic);
         const long long nB = (long long)pl.W * N * M * L;
         // ---- large problems: one launch, role A on the LDS-stage body ----
         if (lds_a.use) lds_a = plan_lds<VT>(N, S, M, L, Lq, P, nB);      // cut role A for the slots role B leaves
@@ -913,32 +841,36 @@ static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *
             nB + (long long)N * M * lds_a.chunks <= 0x7fffffffLL) {
             const dim3 fgrid((unsigned)(nB + (long long)N * M * lds_a.chunks));
             const size_t flds = pl.lds > lds_a.lds ? pl.lds : lds_a.lds;
-#define MSDA_LAUNCH_FLD(AC, NS_)                                                                       \
-            do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_fused_lds_d32_kernel<AC, VT, false, GT, NS_>), flds)) return rc; \
-            hipLaunchKernelGGL((bwd_fused_lds_d32_kernel<AC, VT, false, GT, NS_>), fgrid, dim3(kSBlock), flds, stream, grad_out,  \
+#define MSDA_LAUNCH_FLD_(AC, NS_, DT)                                                                  \
+            do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_fused_lds_d32_kernel<AC, VT, false, GT, NS_, DT>), flds)) return rc; \
+            hipLaunchKernelGGL((bwd_fused_lds_d32_kernel<AC, VT, false, GT, NS_, DT>), fgrid, dim3(kSBlock), flds, stream, grad_out,  \
                                value, shapes, level_start, loc, attn, S, M, L, Lq, P, ps, lps, pl.tp_cap, pl.W, (int)nB,          \
                                lds_a.chunks, lds_a.qw, lds_a.stage_rows, grad_value, grad_loc, grad_attn,                        \
                                PrologueOut{nullptr, 0, 0}, xcd); } while (0)
+#define MSDA_LAUNCH_FLD(AC, NS_) do { if (deterministic) MSDA_LAUNCH_FLD_(AC, NS_, true); else MSDA_LAUNCH_FLD_(AC, NS_, false); } while (0)
             const bool one_slot = 8 * LP <= kWave;
             if (pl.acc == kAccNone) { if (one_slot) MSDA_LAUNCH_FLD(kAccNone, 1); else MSDA_LAUNCH_FLD(kAccNone, 2); }
             else                    { if (one_slot) MSDA_LAUNCH_FLD(kAccWide, 1); else MSDA_LAUNCH_FLD(kAccWide, 2); }
 #undef MSDA_LAUNCH_FLD
+#undef MSDA_LAUNCH_FLD_
             return check_launch("msda backward (d32, fused, LDS stage)");
         }
         // ---- whole backward in one launch when role A's workgroups can share the CUs (LDS) ----
         if (bwd_mode == 0 && pl.ppt == kSinglePPT && pl.acc != kAccTile && !lds_a.use) {
-            const FusedPlan fp = plan_fused(items, LP, split, nB, pl.acc);
+            const FusedPlan fp = plan_fused(items, LP, split, nB, pl.acc, 0, deterministic);
             const int ipw_f = 64 / fp.split;                            // 512-thread role-A workgroups
             const size_t lds_a = (size_t)ipw_f * item_stride + (size_t)ipw_f * LP * 16;
             const long long nA = (items + ipw_f - 1) / ipw_f;
             if (nB + nA <= 0x7fffffffLL) {
                 const dim3 fgrid((unsigned)(nB + nA));
                 const size_t flds = pl.lds > lds_a ? pl.lds : lds_a;
-#define MSDA_LAUNCH_F(SP, AC, FX)                                                                      \
-                do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_fused_d32_kernel<SP, AC, VT, false, GT, FX>), flds)) return rc; \
-                hipLaunchKernelGGL((bwd_fused_d32_kernel<SP, AC, VT, false, GT, FX>), fgrid, dim3(kSBlock), flds, stream,  \
+#define MSDA_LAUNCH_F_(SP, AC, FX, DT)                                                                 \
+                do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_fused_d32_kernel<SP, AC, VT, false, GT, FX, DT>), flds)) return rc; \
+                hipLaunchKernelGGL((bwd_fused_d32_kernel<SP, AC, VT, false, GT, FX, DT>), fgrid, dim3(kSBlock), flds, stream,  \
                                    grad_out, value, shapes, level_start, loc, attn, S, M, L, Lq, P, items, ps, lps, ms,  \
                                    pl.tp_cap, pl.W, (int)nB, grad_value, grad_loc, grad_attn, PrologueOut{nullptr, 0, 0}, xcd); } while (0)
+                // (FX, the short sort, is never planned together with the deterministic flag)
+#define MSDA_LAUNCH_F(SP, AC, FX) do { if (deterministic && !(FX)) MSDA_LAUNCH_F_(SP, AC, false, true); else MSDA_LAUNCH_F_(SP, AC, FX, false); } while (0)
                 if (fp.fixed)                { if (fp.split == 4) MSDA_LAUNCH_F(4, kAccNone, true); else if (fp.split == 2) MSDA_LAUNCH_F(2, kAccNone, true); else MSDA_LAUNCH_F(1, kAccNone, true); }
                 else if (pl.acc == kAccNone) { if (fp.split == 4) MSDA_LAUNCH_F(4, kAccNone, false); else if (fp.split == 2) MSDA_LAUNCH_F(2, kAccNone, false); else MSDA_LAUNCH_F(1, kAccNone, false); }
                 else if (pl.acc == kAccWide) { if (fp.split == 4) MSDA_LAUNCH_F(4, kAccWide, false); else if (fp.split == 2) MSDA_LAUNCH_F(2, kAccWide, false); else MSDA_LAUNCH_F(1, kAccWide, false); }
@@ -948,16 +880,18 @@ static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *
                 else return set_error(MSDA_ERR_LAUNCH, "msda backward (d32): unplanned accumulation mode");
 #endif
 #undef MSDA_LAUNCH_F
+#undef MSDA_LAUNCH_F_
                 return check_launch("msda backward (d32, fused)");
             }
         }
         // ---- role B as its own launch (large record arrays / bf16 tile / A-B knob) ----
         if (nB > 0x7fffffffLL) return set_error(MSDA_ERR_ARGUMENT, "msda backward (d32): too many grad_value workgroups");
         const dim3 grid((unsigned)nB);
-#define MSDA_LAUNCH_B(AC, PPT_)                                                                        \
-        do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_value_d32_kernel<AC, PPT_, VT, GT>), pl.lds)) return rc; \
-             hipLaunchKernelGGL((bwd_value_d32_kernel<AC, PPT_, VT, GT>), grid, dim3(kSBlock), pl.lds, stream, grad_out,    \
+#define MSDA_LAUNCH_B_(AC, PPT_, DT)                                                                   \
+        do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_value_d32_kernel<AC, PPT_, VT, GT, DT>), pl.lds)) return rc; \
+             hipLaunchKernelGGL((bwd_value_d32_kernel<AC, PPT_, VT, GT, DT>), grid, dim3(kSBlock), pl.lds, stream, grad_out,    \
                                 shapes, level_start, loc, attn, S, M, L, Lq, P, ps, pl.tp_cap, pl.W, grad_value, xcd); } while (0)
+#define MSDA_LAUNCH_B(AC, PPT_) do { if (deterministic) MSDA_LAUNCH_B_(AC, PPT_, true); else MSDA_LAUNCH_B_(AC, PPT_, false); } while (0)
         if (pl.acc == kAccNone) MSDA_LAUNCH_B(kAccNone, kSinglePPT);
         else if (pl.acc == kAccTile) MSDA_LAUNCH_B(kAccTile, kMultiPPT);
         else if (pl.acc == kAccWide) MSDA_LAUNCH_B(kAccWide, kSinglePPT);
@@ -968,6 +902,7 @@ static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *
         else return set_error(MSDA_ERR_LAUNCH, "msda backward (d32): unplanned accumulation mode");
 #endif
 #undef MSDA_LAUNCH_B
+#undef MSDA_LAUNCH_B_
         if (int rc = check_launch("msda backward (d32, grad_value sort+gather)")) return rc;
     }
     if (lds_a.use)
@@ -1039,15 +974,11 @@ static int launch_bwd_prologue_t(const VT *grad_out, const VT *value, const int6
 {
     const int items = N * Lq * M, LP = L * P;
     const int item_stride = LP * kRecBytes + kItemPad;
-    const PrologueOut pro_c{grad_ref, (int)((ld_grad_offsets - 2LL * M * LP) / 2), (int)(ld_grad_logits - (long long)M * LP)};
-    if (deterministic)
-        return launch_bwd_det_t<VT, float, true>(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P,
-                                                 grad_value, grad_offsets, grad_logits, pro_c, workspace, ws_bytes, stream);
     const int split = pick_split(items, LP);
     const int ps = pow2_shift(P), lps = pow2_shift(LP), ms = pow2_shift(M);
-    const ValuePlan pl = plan_value<float>(N, S, M, L, Lq, P, bwd_target_wgs());
+    const ValuePlan pl = plan_value<float>(N, S, M, L, Lq, P, bwd_target_wgs(), deterministic);
     const long long nB = (long long)pl.W * N * M * L;
-    const FusedPlan fp = plan_fused(items, LP, split, nB, pl.acc, M);
+    const FusedPlan fp = plan_fused(items, LP, split, nB, pl.acc, M, deterministic);
     const int ipw_f = kSWaves * 8 / fp.split;
     const size_t lds_a = (size_t)ipw_f * item_stride + (size_t)ipw_f * LP * 16;
     const long long nA = (items + ipw_f - 1) / ipw_f;
@@ -1062,15 +993,17 @@ static int launch_bwd_prologue_t(const VT *grad_out, const VT *value, const int6
         const PrologueOut pro_h{static_cast<float *>(workspace), pro.off_pad, pro.log_pad};
         const dim3 lgrid((unsigned)(nB + (long long)N * M * lq.chunks));
         const size_t llds = pl.lds > lq.lds ? pl.lds : lq.lds;
-#define MSDA_LAUNCH_BPL(AC, NS_)                                                                       \
-        do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_fused_lds_d32_kernel<AC, VT, true, float, NS_>), llds)) return rc; \
-        hipLaunchKernelGGL((bwd_fused_lds_d32_kernel<AC, VT, true, float, NS_>), lgrid, dim3(kSBlock), llds, stream, grad_out,   \
+#define MSDA_LAUNCH_BPL(AC, NS_) do { if (deterministic) MSDA_LAUNCH_BPL_(AC, NS_, true); else MSDA_LAUNCH_BPL_(AC, NS_, false); } while (0)
+#define MSDA_LAUNCH_BPL_(AC, NS_, DT)                                                                  \
+        do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_fused_lds_d32_kernel<AC, VT, true, float, NS_, DT>), llds)) return rc; \
+        hipLaunchKernelGGL((bwd_fused_lds_d32_kernel<AC, VT, true, float, NS_, DT>), lgrid, dim3(kSBlock), llds, stream, grad_out,   \
                            value, shapes, level_start, loc, attn, S, M, L, Lq, P, ps, lps, pl.tp_cap, pl.W, (int)nB, lq.chunks,   \
                            lq.qw, lq.stage_rows, grad_value, grad_offsets, grad_logits, pro_h, xcd_remap()); } while (0)
         const bool one_slot = 8 * LP <= kWave;
         if (pl.acc == kAccNone) { if (one_slot) MSDA_LAUNCH_BPL(kAccNone, 1); else MSDA_LAUNCH_BPL(kAccNone, 2); }
         else                    { if (one_slot) MSDA_LAUNCH_BPL(kAccWide, 1); else MSDA_LAUNCH_BPL(kAccWide, 2); }
 #undef MSDA_LAUNCH_BPL
+#undef MSDA_LAUNCH_BPL_
         if (int rc = check_launch("msda backward (d32, fused prologue, LDS stage)")) return rc;
         const long long cells = (long long)N * Lq * L;
         hipLaunchKernelGGL(ref_heads_reduce_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, stream,
@@ -1079,9 +1012,10 @@ static int launch_bwd_prologue_t(const VT *grad_out, const VT *value, const int6
     }
     const dim3 fgrid((unsigned)(nB + nA));
     const size_t flds = pl.lds > lds_a ? pl.lds : lds_a;
-#define MSDA_LAUNCH_BP(SP, AC, FX)                                                                     \
-    do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_fused_d32_kernel<SP, AC, VT, true, float, FX>), flds)) return rc; \
-    hipLaunchKernelGGL((bwd_fused_d32_kernel<SP, AC, VT, true, float, FX>), fgrid, dim3(kSBlock), flds, stream, grad_out, \
+#define MSDA_LAUNCH_BP(SP, AC, FX) do { if (deterministic && !(FX)) MSDA_LAUNCH_BP_(SP, AC, false, true); else MSDA_LAUNCH_BP_(SP, AC, FX, false); } while (0)
+#define MSDA_LAUNCH_BP_(SP, AC, FX, DT)                                                                \
+    do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_fused_d32_kernel<SP, AC, VT, true, float, FX, DT>), flds)) return rc; \
+    hipLaunchKernelGGL((bwd_fused_d32_kernel<SP, AC, VT, true, float, FX, DT>), fgrid, dim3(kSBlock), flds, stream, grad_out, \
                        value, shapes, level_start, loc, attn, S, M, L, Lq, P, items, ps, lps, ms, pl.tp_cap, pl.W, (int)nB,  \
                        grad_value, grad_offsets, grad_logits, pro, xcd_remap()); } while (0)
     if (fp.fixed)                { if (fp.split == 4) MSDA_LAUNCH_BP(4, kAccNone, true); else if (fp.split == 2) MSDA_LAUNCH_BP(2, kAccNone, true); else MSDA_LAUNCH_BP(1, kAccNone, true); }
@@ -1093,6 +1027,7 @@ static int launch_bwd_prologue_t(const VT *grad_out, const VT *value, const int6
     else return set_error(MSDA_ERR_LAUNCH, "msda backward (d32, fused prologue): unplanned accumulation mode");
 #endif
 #undef MSDA_LAUNCH_BP
+#undef MSDA_LAUNCH_BP_
     return check_launch("msda backward (d32, fused prologue)");
 }
 
