@@ -13,6 +13,8 @@ dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 mod = MSDeformAttn(M * D, len(shapes), M, P).to(dev)
 mod.cpp_node = "--no-cpp-node" not in sys.argv
+amp = "--amp" in sys.argv                      # autocast(bfloat16) + bf16 rows, as bench.py's `modules` rows with amp
+mod.bf16_storage = amp
 sh = torch.tensor(shapes, dtype=torch.long, device=dev)
 lsi = torch.cat((sh.new_zeros(1), sh.prod(1).cumsum(0)[:-1]))
 S = int(sh.prod(1).sum())
@@ -25,7 +27,12 @@ go = torch.randn(N, Lq, M * D, device=dev)
 def step():
     mod.zero_grad(set_to_none=True)
     q.grad = src.grad = ref.grad = None
-    mod(q, ref, src, sh, lsi).backward(go)
+    if amp:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = mod(q, ref, src, sh, lsi)
+        out.backward(go.to(out.dtype))
+    else:
+        mod(q, ref, src, sh, lsi).backward(go)
 
 
 for _ in range(20):
@@ -44,9 +51,13 @@ tf = tb = 0.0
 for _ in range(100):
     mod.zero_grad(set_to_none=True); q.grad = src.grad = ref.grad = None
     torch.cuda.synchronize(); a = time.perf_counter()
-    out = mod(q, ref, src, sh, lsi)
+    if amp:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = mod(q, ref, src, sh, lsi)
+    else:
+        out = mod(q, ref, src, sh, lsi)
     b = time.perf_counter()
-    out.backward(go)
+    out.backward(go.to(out.dtype))
     c = time.perf_counter()
     tf += b - a; tb += c - b
 print("host: forward %.1f us, backward %.1f us (GPU idle at the start of each)" % (1e4 * tf, 1e4 * tb))

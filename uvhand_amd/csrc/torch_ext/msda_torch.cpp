@@ -389,6 +389,140 @@ public:
     }
 };
 
+// Weight / bias gradient from bf16 operands on the bf16 MFMA (fp32 result for the fp32 master parameter).
+inline at::Tensor wgrad_into_bf16(const at::Tensor &dY2, const at::Tensor &X2, at::Tensor &gb, msda_stream_t stream)
+{
+    const int M = (int)dY2.size(0), N = (int)dY2.size(1), K = (int)X2.size(1);
+    const auto f32 = dY2.options().dtype(at::kFloat);
+    auto gw = at::empty({N, K}, f32);
+    gb = at::empty({N}, f32);
+    const unsigned long long nbytes = msda_linear_wgrad_workspace_bytes(M, N, K);
+    at::Tensor ws;
+    if (nbytes) ws = at::empty({(int64_t)nbytes}, dY2.options().dtype(at::kByte));
+    raise_if(msda_linear_wgrad_masked_bf16(reinterpret_cast<const uint16_t *>(dY2.data_ptr<at::BFloat16>()),
+                                           reinterpret_cast<const uint16_t *>(X2.data_ptr<at::BFloat16>()), nullptr, M, N, K,
+                                           gw.data_ptr<float>(), gb.data_ptr<float>(), nbytes ? ws.data_ptr() : nullptr, stream),
+             "msda_linear_wgrad (bf16 operands)");
+    return gw;
+}
+
+// The module under torch.autocast(bfloat16) with bf16 rows (MSDeformAttn.bf16_storage) as ONE node — the same steps, in the same
+// order, as the Python composition takes there (modules/ms_deform_attn.py; functions/linear_func.py: _BracketLinearAmpFn):
+// value_proj and output_proj on bf16 operands (what autocast runs), the query projection, offsets, logits, reference points
+// and every gradient in float32, bf16 rows through the sampling kernels, grad_value accumulated in float32, weight gradients
+// from bf16 operands on the bf16 MFMA with float32 results.
+class MSDAModuleBF16Function : public torch::autograd::Function<MSDAModuleBF16Function> {
+public:
+    static at::Tensor forward(torch::autograd::AutogradContext *ctx, const at::Tensor &query, const at::Tensor &centre,
+                              const at::Tensor &input_flatten, const c10::optional<at::Tensor> &mask, const at::Tensor &shapes,
+                              const at::Tensor &lsi, const at::Tensor &w_off, const at::Tensor &b_off, const at::Tensor &w_attn,
+                              const at::Tensor &b_attn, const at::Tensor &w_val, const at::Tensor &b_val, const at::Tensor &w_out,
+                              const at::Tensor &b_out, int64_t n_heads, int64_t n_levels, int64_t n_points, int64_t im2col_step,
+                              bool deterministic)
+    {
+        const int N = (int)query.size(0), Lq = (int)query.size(1), C = (int)query.size(2), S = (int)input_flatten.size(1);
+        const int M = (int)n_heads, L = (int)n_levels, P = (int)n_points, D = C / M, mlp = M * L * P;
+        TORCH_CHECK(msda_prologue_supported(N, S, M, D, L, Lq, P), "MSDeformAttn (C++ node): geometry outside the fused prologue");
+        const int64_t step = std::min<int64_t>(N, im2col_step);
+        TORCH_CHECK(N == 0 || (step > 0 && N % step == 0), "batch(", N, ") must divide im2col_step(", step, ")");
+        c10::hip::HIPGuardMasqueradingAsCUDA guard(query.device());
+        auto stream = (msda_stream_t)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(query.device().index()).stream();
+        // the casts are spelled out below: autocast must not re-cast the float32 query projection
+        c10::impl::ExcludeDispatchKeyGuard no_autocast(c10::DispatchKeySet(c10::DispatchKey::AutocastCUDA));
+        const at::Tensor q2 = query.contiguous(), c2 = centre.contiguous();
+        at::Tensor rmask;
+        if (mask.has_value() && mask->defined()) rmask = mask->reshape({-1}).contiguous();
+        // value_proj on bf16 operands, then the padding mask
+        const at::Tensor xb = input_flatten.to(at::kBFloat16).contiguous(), wvb = w_val.to(at::kBFloat16);
+        at::Tensor value = at::linear(xb, wvb, b_val.to(at::kBFloat16));                // [N, S, C] bf16
+        if (rmask.defined()) value = value.masked_fill(rmask.view({N, S, 1}), 0);
+        // the query projection stays float32
+        const at::Tensor wm = at::cat({w_off, w_attn}, 0), bm = at::cat({b_off, b_attn}, 0);
+        const at::Tensor projected = linear_rows_forward(q2.view({(int64_t)N * Lq, C}), wm, bm, nullptr, stream);
+        auto sampled = at::empty({N, Lq, C}, xb.options());
+        auto loc = at::empty({N, Lq, M, L, P, 2}, q2.options()), attn = at::empty({N, Lq, M, L, P}, q2.options());
+        raise_if(msda_forward_prologue_bf16(reinterpret_cast<const uint16_t *>(value.data_ptr<at::BFloat16>()),
+                                            shapes.data_ptr<int64_t>(), lsi.data_ptr<int64_t>(), c2.data_ptr<float>(),
+                                            projected.data_ptr<float>(), projected.data_ptr<float>() + 2 * mlp, N, S, M, D, L, Lq,
+                                            P, 3LL * mlp, 3LL * mlp, reinterpret_cast<uint16_t *>(sampled.data_ptr<at::BFloat16>()),
+                                            loc.data_ptr<float>(), attn.data_ptr<float>(), stream),
+                 "ms_deform_attn_forward_prologue (bf16 rows)");
+        const at::Tensor wob = w_out.to(at::kBFloat16);
+        ctx->save_for_backward({q2, xb, rmask.defined() ? rmask : at::Tensor(), value, loc, attn, sampled, wm, wvb, wob, shapes, lsi});
+        ctx->saved_data["dims"] = std::vector<int64_t>{N, S, M, D, L, Lq, P, C};
+        ctx->saved_data["det"] = deterministic;
+        ctx->saved_data["x_float"] = input_flatten.scalar_type() == at::kFloat;
+        return at::linear(sampled, wob, b_out.to(at::kBFloat16));                       // [N, Lq, C] bf16
+    }
+
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext *ctx, torch::autograd::variable_list grads)
+    {
+        const auto sv = ctx->get_saved_variables();
+        const at::Tensor &q2 = sv[0], &xb = sv[1], &rmask = sv[2], &value = sv[3], &loc = sv[4], &attn = sv[5], &sampled = sv[6],
+                         &wm = sv[7], &wvb = sv[8], &wob = sv[9], &shapes = sv[10], &lsi = sv[11];
+        const auto dims = ctx->saved_data["dims"].toIntVector();
+        const int N = (int)dims[0], S = (int)dims[1], M = (int)dims[2], D = (int)dims[3], L = (int)dims[4], Lq = (int)dims[5],
+                  P = (int)dims[6], C = (int)dims[7], mlp = M * L * P;
+        c10::hip::HIPGuardMasqueradingAsCUDA guard(q2.device());
+        auto stream = (msda_stream_t)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(q2.device().index()).stream();
+        // output_proj
+        const at::Tensor go2 = grads[0].reshape({(int64_t)N * Lq, C}).to(at::kBFloat16).contiguous();
+        at::Tensor gb_out, gb_m, gb_val;
+        const at::Tensor g_sampled = at::mm(go2, wob);                                  // [N*Lq, C] bf16
+        const at::Tensor gw_out = wgrad_into_bf16(go2, sampled.view({(int64_t)N * Lq, C}), gb_out, stream);
+        // the sampling kernels: bf16 rows in, float32 gradients out
+        const bool det = ctx->saved_data["det"].toBool() || at::globalContext().deterministicAlgorithms();
+        const unsigned flags = MSDA_FLAG_PROLOGUE | (det ? MSDA_FLAG_DETERMINISTIC : 0u);
+        const unsigned long long nbytes = msda_backward_workspace_bytes(N, S, M, D, L, Lq, P, flags);
+        at::Tensor ws;
+        if (nbytes) ws = at::empty({(int64_t)nbytes}, q2.options().dtype(at::kByte));
+        auto gv = at::empty({N, S, C}, q2.options()), gproj = at::empty({(int64_t)N * Lq, 3LL * mlp}, q2.options());
+        auto gref = at::empty({N, Lq, L, 2}, q2.options());
+        raise_if(msda_backward_prologue_bf16_gv32(reinterpret_cast<const uint16_t *>(g_sampled.data_ptr<at::BFloat16>()),
+                                                  reinterpret_cast<const uint16_t *>(value.data_ptr<at::BFloat16>()),
+                                                  shapes.data_ptr<int64_t>(), lsi.data_ptr<int64_t>(), loc.data_ptr<float>(),
+                                                  attn.data_ptr<float>(), N, S, M, D, L, Lq, P, 3LL * mlp, 3LL * mlp,
+                                                  gv.data_ptr<float>(), gproj.data_ptr<float>(), gproj.data_ptr<float>() + 2 * mlp,
+                                                  gref.data_ptr<float>(), nbytes ? ws.data_ptr() : nullptr, nbytes,
+                                                  det ? MSDA_FLAG_DETERMINISTIC : 0u, stream),
+                 "ms_deform_attn_backward_prologue (bf16 rows)");
+        // merged projection (float32)
+        at::Tensor g_query;
+        if (ctx->needs_input_grad(0)) g_query = linear_rows_dgrad(gproj, wm, nullptr, stream).view({N, Lq, C});
+        const at::Tensor gw_m = wgrad_into(gproj, q2.view({(int64_t)N * Lq, C}), nullptr, gb_m, true, stream);
+        // value_proj: grad_value goes back to the rows' type, the mask's rows to zero, then the two GEMMs on bf16 operands
+        at::Tensor gvb = gv.to(at::kBFloat16);
+        if (rmask.defined()) gvb = gvb.masked_fill(rmask.view({N, S, 1}), 0);
+        const at::Tensor gvb2 = gvb.view({(int64_t)N * S, C});
+        at::Tensor g_input;
+        if (ctx->needs_input_grad(2)) {
+            g_input = at::mm(gvb2, wvb).view({N, S, C});
+            if (ctx->saved_data["x_float"].toBool()) g_input = g_input.to(at::kFloat);
+        }
+        const at::Tensor gw_val = wgrad_into_bf16(gvb2, xb.view({(int64_t)N * S, C}), gb_val, stream);
+        return {g_query, gref, g_input, at::Tensor(), at::Tensor(), at::Tensor(),
+                gw_m.narrow(0, 0, 2 * mlp), gb_m.narrow(0, 0, 2 * mlp), gw_m.narrow(0, 2 * mlp, mlp), gb_m.narrow(0, 2 * mlp, mlp),
+                gw_val, gb_val, gw_out, gb_out, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+    }
+};
+
+at::Tensor module_forward_bf16(const at::Tensor &query, const at::Tensor &centre, const at::Tensor &input_flatten,
+                               const c10::optional<at::Tensor> &mask, const at::Tensor &shapes, const at::Tensor &lsi,
+                               const at::Tensor &w_off, const at::Tensor &b_off, const at::Tensor &w_attn, const at::Tensor &b_attn,
+                               const at::Tensor &w_val, const at::Tensor &b_val, const at::Tensor &w_out, const at::Tensor &b_out,
+                               int64_t n_heads, int64_t n_levels, int64_t n_points, int64_t im2col_step, bool deterministic)
+{
+    for (const at::Tensor *t : {&query, &centre, &w_off, &b_off, &w_attn, &b_attn, &w_val, &b_val, &w_out, &b_out})
+        TORCH_CHECK(t->is_cuda() && t->scalar_type() == at::kFloat && t->device() == query.device(),
+                    "MSDeformAttn (C++ node, bf16 rows): float32 CUDA tensors on one device expected");
+    TORCH_CHECK(input_flatten.is_cuda() && (input_flatten.scalar_type() == at::kFloat || input_flatten.scalar_type() == at::kBFloat16),
+                "MSDeformAttn (C++ node, bf16 rows): float32 or bfloat16 input_flatten expected");
+    TORCH_CHECK(shapes.is_cuda() && lsi.is_cuda() && shapes.scalar_type() == at::kLong && lsi.scalar_type() == at::kLong,
+                "expected scalar type Long for spatial_shapes / level_start_index (on the device)");
+    return MSDAModuleBF16Function::apply(query, centre, input_flatten, mask, shapes, lsi, w_off, b_off, w_attn, b_attn, w_val,
+                                         b_val, w_out, b_out, n_heads, n_levels, n_points, im2col_step, deterministic);
+}
+
 at::Tensor module_forward(const at::Tensor &query, const at::Tensor &centre, const at::Tensor &input_flatten,
                           const c10::optional<at::Tensor> &mask, const at::Tensor &shapes, const at::Tensor &lsi,
                           const at::Tensor &w_off, const at::Tensor &b_off, const at::Tensor &w_attn, const at::Tensor &b_attn,
@@ -413,6 +547,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("ms_deform_attn_backward", &backward, "replaces MSDA.ms_deform_attn_backward (vision.cpp:15)");
     m.def("apply", &apply, "MSDeformAttnFunction.apply as a C++ autograd node");
     m.def("apply_bf16", &apply_bf16, "MSDeformAttnBF16Function.apply as a C++ autograd node");
+    m.def("module_forward_bf16", &module_forward_bf16,
+          "MSDeformAttn.forward under autocast(bfloat16) with bf16 rows as one C++ autograd node");
     m.def("module_forward", &module_forward, "MSDeformAttn.forward (fp32, fused prologue + merged projection) as one C++ autograd node");
     // the header this file was COMPILED against (not the loaded library's msda_version(): _ext.py compares the two)
     m.def("abi_version", [] { return (int)MSDA_ABI_VERSION; });

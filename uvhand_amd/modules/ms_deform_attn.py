@@ -29,7 +29,7 @@ from torch import nn
 from .. import _ext, _native
 from ..functions import (MSDeformAttnBF16Function, MSDeformAttnFunction, MSDeformAttnMergedPrologueFunction,
                          MSDeformAttnPrologueFunction)
-from ..functions.linear_func import bracket_linear, bracket_linear_masked, bracket_linear_wb
+from ..functions.linear_func import _autocast_dtype, bracket_linear, bracket_linear_masked, bracket_linear_wb
 
 
 # The reference asserts sum_l H_l*W_l == Len_in on every call of every layer (:93) — a device->host sync
@@ -124,15 +124,24 @@ class MSDeformAttn(nn.Module):
         nn.init.constant_(self.output_proj.bias.data, 0.0)
 
     def _cpp_node(self, query, reference_points, input_flatten, spatial_shapes, level_start_index, padding_mask):
-        """The torch extension, if this call can run as its one-node form of the fp32 fused path (module_forward in
-        csrc/torch_ext/msda_torch.cpp): float32 CUDA tensors outside autocast, 2-d / 42-d reference points, plain nn.Linear
-        projections with biases, a geometry the fused prologue takes.  None -> the Python composition below."""
-        if not (self.cpp_node and self.fused_prologue and self.merged_projection and not self.bf16_storage):
+        """The torch extension, if this call can run as one of its one-node forms of the fused path (module_forward /
+        module_forward_bf16 in csrc/torch_ext/msda_torch.cpp): float32 CUDA tensors — outside autocast, or under
+        autocast(bfloat16) with bf16_storage — 2-d / 42-d reference points, plain nn.Linear projections with biases, a
+        geometry the fused prologue takes.  None -> the Python composition below."""
+        if not (self.cpp_node and self.fused_prologue and self.merged_projection):
             return None
         ext = _ext.get()
         if ext is None or not hasattr(ext, "module_forward") or _native._forced_path != -1:
             return None
-        if torch.is_autocast_enabled() or not torch.is_grad_enabled() or reference_points.shape[-1] not in (2, 42):
+        if not torch.is_grad_enabled() or reference_points.shape[-1] not in (2, 42):
+            return None
+        # float32 outside autocast -> module_forward; bf16 rows under autocast(bfloat16) -> module_forward_bf16 (the two
+        # configurations the training loop runs); bf16 rows without autocast, other autocast types: the composition
+        autocast = torch.is_autocast_enabled()
+        if autocast != bool(self.bf16_storage):
+            return None
+        if autocast and not (hasattr(ext, "module_forward_bf16") and _autocast_dtype() == torch.bfloat16
+                             and self.d_model % 8 == 0):
             return None
         tensors = (query, reference_points, input_flatten)
         layers = (self.sampling_offsets, self.attention_weights, self.value_proj, self.output_proj)
@@ -175,7 +184,8 @@ class MSDeformAttn(nn.Module):
         if ext is not None:
             centre = reference_points if reference_points.shape[-1] == 2 else torch.stack(
                 [reference_points[..., 0::2].mean(-1), reference_points[..., 1::2].mean(-1)], -1)
-            return ext.module_forward(
+            node = ext.module_forward_bf16 if self.bf16_storage else ext.module_forward
+            return node(
                 query, centre, input_flatten, input_padding_mask, input_spatial_shapes, input_level_start_index,
                 self.sampling_offsets.weight, self.sampling_offsets.bias, self.attention_weights.weight,
                 self.attention_weights.bias, self.value_proj.weight, self.value_proj.bias, self.output_proj.weight,
