@@ -181,6 +181,105 @@ __global__ __launch_bounds__(kWgBlock) void linear_wgrad_partial_kernel(
 
 #undef MSDA_LOAD_STAGE
 
+// ---- few rows: 32 x 32 output tiles, 16x16x4 MFMA --------------------------------------------------------------------------
+// At M = 600 the kernel above is 128 workgroups of three stages each plus the reduction launch: 9 us however it is split.
+// Here a workgroup owns a 32 x 32 tile (64 of them at N = K = 256), each wavefront a 16 x 16 block whose MFMA chain is a
+// quarter as long per row, and ~512 workgroups in all: M = 600 7.5 us (8.9), 2400 11.6 (15.3) including the
+// reduction.  (One workgroup per tile walking ALL 600 rows, no slabs and no second launch: 10.0 us — ten stages whose loads
+// are two stages ahead of sixteen short MFMAs each is a latency chain; kept only below 128 rows.)  Stages of 64 rows, LDS rows of 48 floats (the four lane groups of a 16x16x4 operand read rows 4s .. 4s+3: with
+// 48 the two groups of a 32-lane phase fall on disjoint banks).  fp32 operands.
+constexpr int kSmTile = 32, kSmStage = 64, kSmRow = 48;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__global__ __launch_bounds__(kWgBlock) void linear_wgrad_small_kernel(
+    const float *__restrict__ dY, const float *__restrict__ X, const uint8_t *__restrict__ row_mask, int M, int N, int K,
+    int chunk, int tiles, int splits, long long slab, float *__restrict__ out_w, float *__restrict__ out_b)
+{
+    __shared__ __attribute__((aligned(16))) float At[2][kSmStage][kSmRow];
+    __shared__ __attribute__((aligned(16))) float Bs[2][kSmStage][kSmRow];
+    const int tiles_k = (K + kSmTile - 1) / kSmTile;
+    int tile, split;
+    tile_and_split((int)blockIdx.x, tiles, splits, tile, split);
+    const int n0 = (tile / tiles_k) * kSmTile, k0 = (tile % tiles_k) * kSmTile;
+    const int m_begin = split * chunk, m_end = min(M, m_begin + chunk);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int i0 = (wave >> 1) * 16, j0 = (wave & 1) * 16, g = lane >> 4, c = lane & 15;
+
+    // staging: 64 rows x 32 floats per operand = 2 float4 per thread and operand (rows lrow, lrow + 32)
+    const int lrow = tid >> 3, lcol = (tid & 7) * 4;
+    const bool a_ok = n0 + lcol < N, b_ok = k0 + lcol < K;
+    float4 ra[2], rb[2];
+    unsigned mk[2];
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+#define MSDA_LOAD_SM(m0_)                                                                                           \
+    do {                                                                                                            \
+        _Pragma("unroll") for (int r = 0; r < 2; ++r) {                                                             \
+            const int m = (m0_) + lrow + 32 * r;                                                                    \
+            mk[r] = 0;                                                                                              \
+            if (row_mask != nullptr && m < m_end) mk[r] = row_mask[m];                                              \
+            ra[r] = zero; rb[r] = zero;                                                                             \
+            if (a_ok && m < m_end) ra[r] = *reinterpret_cast<const float4 *>(dY + (long long)m * N + n0 + lcol);    \
+            if (b_ok && m < m_end) rb[r] = *reinterpret_cast<const float4 *>(X + (long long)m * K + k0 + lcol);     \
+        }                                                                                                           \
+    } while (0)
+#define MSDA_STORE_SM(buf_)                                                                                         \
+    do {                                                                                                            \
+        _Pragma("unroll") for (int r = 0; r < 2; ++r) {                                                             \
+            *reinterpret_cast<float4 *>(&At[buf_][lrow + 32 * r][lcol]) = keep4(ra[r], mk[r] == 0);                 \
+            *reinterpret_cast<float4 *>(&Bs[buf_][lrow + 32 * r][lcol]) = rb[r];                                    \
+        }                                                                                                           \
+    } while (0)
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // bias gradient (k0 == 0 tiles): thread t sums column t & 31 over the 8 stage rows 8 (t >> 5) ...
+    float bsum = 0.f;
+    const bool do_bias = out_b != nullptr && k0 == 0;
+    const int bcol = tid & 31, brow = (tid >> 5) * 8;
+
+    MSDA_LOAD_SM(m_begin);
+    MSDA_STORE_SM(0);
+    MSDA_LOAD_SM(m_begin + kSmStage);
+    __syncthreads();
+    int cur = 0;
+    for (int m0 = m_begin; m0 < m_end; m0 += kSmStage) {
+        float av[kSmStage / 4], bv[kSmStage / 4];
+#pragma unroll
+        for (int s = 0; s < kSmStage / 4; ++s) { av[s] = At[cur][4 * s + g][i0 + c]; bv[s] = Bs[cur][4 * s + g][j0 + c]; }
+        if (do_bias) {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) bsum += At[cur][brow + kk][bcol];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < kSmStage / 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc, 0, 0, 0);
+        if (m0 + kSmStage < m_end) {
+            MSDA_STORE_SM(cur ^ 1);
+            if (m0 + 2 * kSmStage < m_end) MSDA_LOAD_SM(m0 + 2 * kSmStage);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+#undef MSDA_LOAD_SM
+#undef MSDA_STORE_SM
+    // C/D layout of the 16x16 MFMA: column = lane & 15, row = 4 * (lane >> 4) + reg
+    float *ow = out_w + (long long)split * slab;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = n0 + i0 + 4 * g + r, j = k0 + j0 + c;
+        if (i < N && j < K) ow[(long long)i * K + j] = acc[r];
+    }
+    if (do_bias) {
+        float *bpart = &At[0][0][0];                                    // the stage buffers are free now (barrier above)
+        bpart[tid] = bsum;
+        __syncthreads();
+        if (tid < kSmTile && n0 + tid < N) {
+            float t = bpart[tid];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) t += bpart[tid + 32 * q];
+            out_b[(long long)split * slab + n0 + tid] = t;
+        }
+    }
+}
+
 // ---- bf16 operands on the bf16 MFMA (v_mfma_f32_32x32x16_bf16: 16x the rate of the f32-input form the kernel above uses) ----
 // Under autocast dY and X arrive as bf16.  A product of two bf16 values is exact in fp32 and the MFMA accumulates in fp32, so
 // this loses nothing the widening kernel keeps; it only stops spending 15/16 of the matrix cores' time.
@@ -379,24 +478,36 @@ int launch_zero_masked_rows(float *x, const uint8_t *mask, long long rows, int c
 }
 
 
-// Number of M-splits: enough workgroups to fill the chip (a few per CU: the kernel hides its barriers and
-// LDS round trips behind other wavefronts' MFMAs), at least two stages per chunk, and — when there are 8 or
-// more — a multiple of 8 so that whole splits go to one XCD (tile_and_split).
-static int wgrad_splits(int M, int N, int K)
+// Kernel and number of M-splits.  Splits: enough workgroups to fill the chip (a few per CU: the kernels hide their barriers and
+// LDS round trips behind other wavefronts' MFMAs), at least two stages per chunk, and — when there are 8 or more — a multiple
+// of 8 so that whole splits go to one XCD (tile_and_split).  fp32 operands with at most 4096 rows take the 32-tile kernel (at 6120 rows it is level at N = 256, 20.0 against 21.3 us, and behind at N = 384, 30.1 against 25.0)
+// (~512 workgroups; one per tile, without slabs, below 128 rows).
+struct WgradPlan { bool small; int splits; };
+static WgradPlan wgrad_plan(int M, int N, int K, bool fp32_operands)
 {
     static const int target = tuning_int("MSDA_WGRAD_WGS", 768);
-    const int tiles = ((N + kWgTile - 1) / kWgTile) * ((K + kWgTile - 1) / kWgTile);
-    int splits = (target + tiles - 1) / tiles;
-    const int max_splits = (M + 2 * kWgStage - 1) / (2 * kWgStage);
+    static const int small_rows = tuning_int("MSDA_WGRAD_SMALL_ROWS", 4096);
+    static const int small_target = tuning_int("MSDA_WGRAD_SMALL_WGS", 512);
+    static const int small_single = tuning_int("MSDA_WGRAD_SMALL_SINGLE", 128);
+    WgradPlan pl;
+    pl.small = fp32_operands && M <= small_rows;
+    const int tile = pl.small ? kSmTile : kWgTile, stage = pl.small ? kSmStage : kWgStage;
+    const int tiles = ((N + tile - 1) / tile) * ((K + tile - 1) / tile);
+    int splits = ((pl.small ? small_target : target) + tiles - 1) / tiles;
+    if (pl.small && M <= small_single) splits = 1;
+    const int max_splits = (M + 2 * stage - 1) / (2 * stage);
     if (splits > max_splits) splits = max_splits;
     if (splits >= 8) splits = (splits + 4) & ~7;                        // nearest multiple of 8
     if (splits > max_splits) splits -= 8;
-    return splits < 1 ? 1 : splits;
+    pl.splits = splits < 1 ? 1 : splits;
+    return pl;
 }
 
 size_t linear_wgrad_workspace_bytes(int M, int N, int K)
 {
-    const int splits = wgrad_splits(M, N, K);
+    // one size for both operand types: the larger of the two plans
+    const int s32 = wgrad_plan(M, N, K, true).splits, s16 = wgrad_plan(M, N, K, false).splits;
+    const int splits = s32 > s16 ? s32 : s16;
     return splits <= 1 ? 0 : sizeof(float) * (size_t)splits * ((size_t)N * K + (size_t)N);
 }
 
@@ -404,18 +515,24 @@ template <typename OT>
 static int launch_linear_wgrad_t(const OT *dY, const OT *X, const uint8_t *row_mask, int M, int N, int K, float *dW, float *db,
                                  float *workspace, hipStream_t stream)
 {
-    const int splits = wgrad_splits(M, N, K);
+    const WgradPlan pl = wgrad_plan(M, N, K, sizeof(OT) == 4);
+    const int splits = pl.splits;
     int chunk = (M + splits - 1) / splits;
-    constexpr int stage = sizeof(OT) == 2 ? (kBfStage > kWgStage ? kBfStage : kWgStage) : kWgStage;
+    constexpr int stage16 = kBfStage > kWgStage ? kBfStage : kWgStage;
+    const int stage = pl.small ? kSmStage : sizeof(OT) == 2 ? stage16 : kWgStage;
     chunk = ((chunk + stage - 1) / stage) * stage;
-    const int tiles = ((N + kWgTile - 1) / kWgTile) * ((K + kWgTile - 1) / kWgTile);
+    const int tile = pl.small ? kSmTile : kWgTile;
+    const int tiles = ((N + tile - 1) / tile) * ((K + tile - 1) / tile);
     const dim3 grid((unsigned)(tiles * splits));
-    auto partial = linear_wgrad_partial_kernel<OT>;
+    void (*partial)(const OT *, const OT *, const uint8_t *, int, int, int, int, int, int, long long, float *, float *) =
+        linear_wgrad_partial_kernel<OT>;
     if constexpr (sizeof(OT) == 2) {
         // bf16 operands: the bf16-MFMA kernel whenever whole 16-byte chunks of 8 columns can be moved (else the widening one)
         static const int use_bf16_mfma = tuning_int("MSDA_WGRAD_BF16_MFMA", 1);
         if (use_bf16_mfma && N % 8 == 0 && K % 8 == 0 && (((uintptr_t)dY | (uintptr_t)X) & 15) == 0)
             partial = linear_wgrad_partial_bf16_kernel;
+    } else {
+        if (pl.small) partial = linear_wgrad_small_kernel;
     }
     if (splits == 1) {
         hipLaunchKernelGGL(partial, grid, dim3(kWgBlock), 0, stream, dY, X, row_mask, M, N, K, chunk, tiles, splits, 0LL, dW, db);
