@@ -480,8 +480,9 @@ int launch_zero_masked_rows(float *x, const uint8_t *mask, long long rows, int c
 
 // Kernel and number of M-splits.  Splits: enough workgroups to fill the chip (a few per CU: the kernels hide their barriers and
 // LDS round trips behind other wavefronts' MFMAs), at least two stages per chunk, and — when there are 8 or more — a multiple
-// of 8 so that whole splits go to one XCD (tile_and_split).  fp32 operands with at most 4096 rows take the 32-tile kernel (at 6120 rows it is level at N = 256, 20.0 against 21.3 us, and behind at N = 384, 30.1 against 25.0)
-// (~512 workgroups; one per tile, without slabs, below 128 rows).
+// of 8 so that whole splits go to one XCD (tile_and_split).  fp32 operands with at most 4096 rows take the 32-tile kernel
+// (~512 workgroups; one per tile, without slabs, below 128 rows); at 6120 rows it is level at N = 256 (20.0 against 21.3 us)
+// and behind at N = 384 (30.1 against 25.0).
 struct WgradPlan { bool small; int splits; };
 static WgradPlan wgrad_plan(int M, int N, int K, bool fp32_operands)
 {
