@@ -663,5 +663,11 @@ def test_beyond_int32_element_offsets_uses_the_generic_kernels(native):
     torch.cuda.synchronize()
     g = value.grad[0, y * W + x]
     assert torch.all(g == 2.0) and value.grad.sum().item() == 2.0 * M * D     # two queries hit that pixel, nothing else
-    del value, out
+    # the deterministic flag on the same geometry: the destination-major kernel walks 2^26 (pixel, head) rows, more
+    # wavefronts than one launch holds threads for — it strides over them
+    gv, gl, ga = native.ms_deform_attn_backward(value.detach(), shapes, lsi, loc, attn, torch.ones_like(out.detach()), 64,
+                                                deterministic=True)
+    torch.cuda.synchronize()
+    assert torch.all(gv[0, y * W + x] == 2.0) and gv.sum().item() == 2.0 * M * D
+    del value, out, gv
     torch.cuda.empty_cache()

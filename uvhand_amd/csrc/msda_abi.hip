@@ -477,7 +477,7 @@ int msda_zero_masked_rows_f32(float *x, const uint8_t *row_mask, long long rows,
                                                   "16-byte aligned rows");
     if (rows > 0 && (x == nullptr || row_mask == nullptr))
         return msda::set_error(MSDA_ERR_ARGUMENT, "msda_zero_masked_rows_f32: null device pointer");
-    if (rows > 4LL * 0x7fffffffLL) return msda::set_error(MSDA_ERR_ARGUMENT, "msda_zero_masked_rows_f32: too many rows");
+    if (rows > (1LL << 26) - 4) return msda::set_error(MSDA_ERR_ARGUMENT, "msda_zero_masked_rows_f32: too many rows");   // < 2^32 threads
     msda::begin_call();
     return msda::launch_zero_masked_rows(x, row_mask, rows, cols, (hipStream_t)stream);
 }

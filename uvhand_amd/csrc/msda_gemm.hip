@@ -221,7 +221,7 @@ static int launch_linear_rows_t(const float *A, const float *B, const float *bia
     const int tiles_n = (Nc + tile - 1) / tile;
     const long long tiles = ((M + tile - 1) / tile) * tiles_n;
     const long long grid = 8 * ((tiles + 7) / 8);
-    if (grid > 0x7fffffffLL) return set_error(MSDA_ERR_ARGUMENT, "linear: too many rows for one launch");
+    if (grid * kGmBlock > 0xffffffffLL) return set_error(MSDA_ERR_ARGUMENT, "linear: too many rows for one launch");   // < 2^32 threads
     if (tile == 32)
         hipLaunchKernelGGL((linear_rows_kernel<B_KMAJOR, 32, 64>), dim3((unsigned)grid), dim3(kGmBlock), 0, stream, A, B, bias,
                            row_mask, C, M, Nc, Kr, tiles_n, tiles);

@@ -156,8 +156,9 @@ __global__ __launch_bounds__(kGenericBlock) void bwd_generic_value_det_kernel(
     T *__restrict__ grad_value)
 {
     const int lane = threadIdx.x & (kWave - 1);
-    const long long row = (long long)blockIdx.x * kGenericItemsPerBlock + (threadIdx.x >> 6);
-    if (row >= rows) return;                              // whole wavefront leaves together
+    // grid-stride over the rows: a launch holds fewer than 2^32 threads, a 2048 x 4096 map with 8 heads has 2^26 rows
+    for (long long row = (long long)blockIdx.x * kGenericItemsPerBlock + (threadIdx.x >> 6); row < rows;
+         row += (long long)gridDim.x * kGenericItemsPerBlock) {   // (whole wavefronts leave together)
     const int m = (int)(row % M);
     const int sp = (int)((row / M) % S);
     const long long b = row / ((long long)M * S);
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(kGenericBlock) void bwd_generic_value_det_kernel(
     }
     if (l < 0) {                                          // a pixel no level covers: zeros (include/msda.h)
         for (int c = lane; c < D; c += kWave) gv[c] = 0;
-        return;
+        continue;
     }
     const int h = pix / W, w = pix - h * W, LP = L * P;
     const long long NP = (long long)Lq * P;
@@ -213,6 +214,7 @@ __global__ __launch_bounds__(kGenericBlock) void bwd_generic_value_det_kernel(
             if (c < D) gv[c] = acc[k];
         }
     }
+    }
 }
 
 template <typename T, typename VT>
@@ -222,7 +224,7 @@ int launch_fwd_generic(const VT *value, const int64_t *shapes, const int64_t *le
 {
     const long long items = (long long)N * Lq * M;
     const long long blocks = (items + kGenericItemsPerBlock - 1) / kGenericItemsPerBlock;
-    if (blocks > 0x7fffffffLL) return set_error(MSDA_ERR_ARGUMENT, "N*Lq*M too large for one launch");
+    if (blocks * kGenericBlock > 0xffffffffLL) return set_error(MSDA_ERR_ARGUMENT, "N*Lq*M too large for one launch");
     hipLaunchKernelGGL((fwd_generic_kernel<T, VT>), dim3((unsigned)blocks), dim3(kGenericBlock), 0, stream,
                        value, shapes, level_start, loc, attn, S, M, D, L, Lq, P, items, out);
     return check_launch("msda forward (generic)");
@@ -236,10 +238,11 @@ int launch_bwd_generic(const VT *grad_out, const VT *value, const int64_t *shape
 {
     const long long items = (long long)N * Lq * M;
     const long long blocks = (items + kGenericItemsPerBlock - 1) / kGenericItemsPerBlock;
-    if (blocks > 0x7fffffffLL) return set_error(MSDA_ERR_ARGUMENT, "N*Lq*M too large for one launch");
+    if (blocks * kGenericBlock > 0xffffffffLL) return set_error(MSDA_ERR_ARGUMENT, "N*Lq*M too large for one launch");
     if (deterministic) {
-        const long long rows = (long long)N * S * M, rblocks = (rows + kGenericItemsPerBlock - 1) / kGenericItemsPerBlock;
-        if (rblocks > 0x7fffffffLL) return set_error(MSDA_ERR_ARGUMENT, "N*S*M too large for one launch");
+        const long long rows = (long long)N * S * M;
+        long long rblocks = (rows + kGenericItemsPerBlock - 1) / kGenericItemsPerBlock;
+        if (rblocks > (1LL << 22)) rblocks = 1LL << 22;                  // the kernel strides over the rows
         hipLaunchKernelGGL((bwd_generic_kernel<T, VT, false>), dim3((unsigned)blocks), dim3(kGenericBlock), 0, stream,
                            grad_out, value, shapes, level_start, loc, attn, S, M, D, L, Lq, P, items,
                            grad_value, grad_loc, grad_attn);
