@@ -158,6 +158,25 @@ def test_cpp_bf16_module_node_equals_python_composition_under_autocast(case):
     assert rel_err(a[0].float().cpu().numpy(), z["out"]) < 3e-2
 
 
+def test_cpp_module_node_under_no_grad_is_the_same_forward():
+    """Inference: the one-node form runs its forward only and returns exactly what the training-mode call returns."""
+    from uvhand_amd import _ext
+    if _ext.get() is None or not hasattr(_ext.get(), "module_forward"):
+        pytest.skip("torch extension not built")
+    z = load_golden("module_2d")
+    mod = _module()
+    args = [torch.from_numpy(z[k]).cuda() for k in ("query", "refp", "src", "shapes", "level_start", "mask")]
+    ref = mod(*args)
+    assert "MSDAModuleFunction" in ref.grad_fn.name()
+    with torch.no_grad():
+        out = mod(*args)
+    assert out.grad_fn is None and not out.requires_grad and torch.equal(out, ref.detach())
+    with torch.inference_mode():
+        out2 = mod(*args)
+    assert torch.equal(out2, ref.detach())
+    assert rel_err(out.cpu().numpy(), z["out"]) < 1e-4
+
+
 def test_half_module_follows_the_dino_amp_branch():
     """module.half() with half inputs: the op runs in float32 and its output returns to half before output_proj
     (models/dino/ops/modules/ms_deform_attn.py:124-131)."""

@@ -133,7 +133,7 @@ class MSDeformAttn(nn.Module):
         ext = _ext.get()
         if ext is None or not hasattr(ext, "module_forward") or _native._forced_path != -1:
             return None
-        if not torch.is_grad_enabled() or reference_points.shape[-1] not in (2, 42):
+        if reference_points.shape[-1] not in (2, 42):               # (under no_grad the node runs its forward only)
             return None
         # float32 outside autocast -> module_forward; bf16 rows under autocast(bfloat16) -> module_forward_bf16 (the two
         # configurations the training loop runs); bf16 rows without autocast, other autocast types: the composition
