@@ -175,14 +175,15 @@ def time_cpu_baseline(workload, budget_s=8.0):
 
 
 def kernel_sources_sha16():
-    """Fingerprint of the sampling kernels' sources (msda_d32*.hip / .h, msda_generic.hip and the shared device header under
-    uvhand_amd/csrc, names and contents): PMC traffic figures are only valid for the kernels they were profiled on.  The
-    projections' GEMM / LayerNorm / flatten kernels are not part of the op's launches and do not enter."""
+    """Fingerprint of the sources of the kernels the bench workloads launch (the D = 32 family: msda_d32*.hip / .h and the
+    shared device header under uvhand_amd/csrc, names and contents): PMC traffic figures are only valid for the kernels they
+    were profiled on.  The generic family (other D, fp64), the projections' GEMM / LayerNorm / flatten kernels are not part
+    of these launches and do not enter."""
     import hashlib
     h = hashlib.sha256()
     src = os.path.join(ROOT, "uvhand_amd", "csrc")
     for name in sorted(os.listdir(src)):
-        if name.endswith((".hip", ".h")) and (name.startswith("msda_d32") or name in ("msda_generic.hip", "msda_common.h")):
+        if name.endswith((".hip", ".h")) and (name.startswith("msda_d32") or name == "msda_common.h"):
             h.update(name.encode() + b"\0")
             with open(os.path.join(src, name), "rb") as f:
                 h.update(f.read())
