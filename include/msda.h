@@ -300,9 +300,19 @@ const char *msda_last_error(void);
 /* Library/ABI version (major*100 + minor) and the kernel family a geometry maps to.  MSDA_ABI_VERSION is what a binding
  * compiled against THIS header expects msda_version() to return at run time (uvhand_amd/_ext.py compares the two);
  * it changes whenever a declaration in this file does. */
-#define MSDA_ABI_VERSION 113
+#define MSDA_ABI_VERSION 114
 int msda_version(void);
 int msda_path_for(int elem_bytes, int M, int D, int L, int P);
+
+/* Diagnostics (tests, bench, tools/ktime.py --sweep): which launch plan a call of this geometry takes, as text, e.g.
+ * "fwd=lds(chunks=2,qw=528,...) bwd=fused_lds(acc=wide,W=2,...)" — the same host-side plan functions the launchers run,
+ * nothing is launched.  row_bytes 4 (fp32 rows) or 2 (bf16 rows; grad_value_bytes then 2 or 4); flags as for
+ * msda_backward_workspace_bytes (MSDA_FLAG_PROLOGUE: the fused-prologue entry points; has_workspace: whether the caller
+ * passes the scratch that call can use).  "generic" outside the D = 32 family.  Returns the length written (NUL-terminated,
+ * truncated to buf_len - 1).  No reference counterpart: the reference's dispatch is the switch over `channels` at
+ * models/ops/src/cuda/ms_deform_im2col_cuda.cuh:971-1320. */
+int msda_describe_plan(int row_bytes, int grad_value_bytes, int N, int S, int M, int D, int L, int Lq, int P, unsigned flags,
+                       int has_workspace, char *buf, int buf_len);
 
 /* Test hook: force the kernel family for the CALLING THREAD's subsequent calls (-1 = automatic, default; MSDA_PATH_GENERIC).
  * Thread-local, so no caller can change the kernels under another thread's launch; not meant for production callers. */

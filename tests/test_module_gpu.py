@@ -1,5 +1,7 @@
 """Module-level parity on the GPU: uvhand_amd.modules.MSDeformAttn against golden vectors captured from
 the reference module (models/ops/modules/ms_deform_attn.py:80-140) with a fixed state_dict."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -526,3 +528,41 @@ def test_module_under_inference_mode():
         out = mod(*args)
         out2 = mod(*args)
     assert rel_err(out.cpu().numpy(), z["out"]) < 1e-4 and torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("cpp", [True, False], ids=["cpp_node", "python_composition"])
+def test_module_at_encoder_geometry_above_the_lds_stage_threshold(cpp):
+    """The reference module at ENCODER geometry with N*Lq*M = 33 440 >= 32 768 items (tests/golden/gen_golden_r04.py:
+    d_model 256 / 8 heads, N = 4, 28/14/7/4, Lq = S = 1045, padding mask): here the default path runs the fused-prologue
+    LDS-stage kernels and ref_heads_reduce_kernel (msda_d32.hip: plan_lds) — what every encoder layer of the cfg-4 training
+    step runs.  Inputs are rebuilt from numpy's frozen generator (tests/golden/big_inputs.py), the fixture holds every 4th
+    row of the big outputs, per-row sums of all rows, and every parameter gradient."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import big_inputs
+    from uvhand_amd import _ext, _native
+    z, gold = big_inputs.module_enc_big_inputs(), load_golden("module_enc_big")
+    assert np.array_equal(big_inputs.checksums(z), gold["input_checksums"])       # the inputs the reference saw
+    if cpp and (_ext.get() is None or not hasattr(_ext.get(), "module_forward")):
+        pytest.skip("torch extension not built")
+    N, S, C = z["query"].shape
+    plan = _native.describe_plan(N, S, 8, 32, 4, S, 4, prologue=True)
+    assert "fwd=lds(" in plan and "bwd=fused_lds(" in plan, plan
+    mod = _module()
+    mod.cpp_node = cpp
+    query = torch.from_numpy(z["query"]).cuda().requires_grad_(True)
+    src = torch.from_numpy(z["src"]).cuda().requires_grad_(True)
+    refp = torch.from_numpy(z["refp"]).cuda().requires_grad_(True)
+    out = mod(query, refp, src, torch.from_numpy(z["shapes"]).cuda(), torch.from_numpy(z["level_start"]).cuda(),
+              torch.from_numpy(z["mask"]).cuda())
+    assert ("MSDAModuleFunction" in out.grad_fn.name()) == cpp
+    out.backward(torch.from_numpy(z["gout"]).cuda())
+    torch.cuda.synchronize()
+    step = big_inputs.ROW_STEP
+    for name, t, tol in (("out", out.detach(), 1e-4), ("grad_query", query.grad, 2e-4), ("grad_src", src.grad, 2e-4)):
+        assert rel_err(t[:, ::step].cpu().numpy(), gold[name + "_rows"]) < tol, name
+        # every row through its sum (256 terms: the tolerance is relative to the largest row sum)
+        assert rel_err(t.double().sum(-1).cpu().numpy(), gold[name + "_rowsum"]) < 2 * tol, name
+    assert rel_err(refp.grad.cpu().numpy(), gold["grad_refp"]) < 2e-4
+    for name, p in mod.named_parameters():
+        assert rel_err(p.grad.cpu().numpy(), gold["pgrad." + name]) < 3e-4, name

@@ -1,6 +1,8 @@
 """Pins the oracle (oracle/msda_oracle.c, oracle/torch_fallback.py) to the golden vectors that
 tests/golden/gen_golden.py produced by running the reference's own fallback
 (UVHand models/ops/functions/ms_deform_attn_func.py:42-62) and autograd through it.  CPU only."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -116,3 +118,12 @@ def test_oracle_properties(oracle):
     gv1, _, _ = oracle.backward(go, value, shapes, lsi, loc, attn)
     oracle.set_num_threads(0)
     assert np.array_equal(gv1, gv)
+
+
+def test_rebuilt_inputs_of_the_big_module_fixture_are_the_ones_the_reference_saw():
+    """tests/golden/big_inputs.py regenerates three 4 MB inputs instead of storing them; the fixture carries their checksums."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import big_inputs
+    z = big_inputs.module_enc_big_inputs()
+    assert np.array_equal(big_inputs.checksums(z), load_golden("module_enc_big")["input_checksums"])

@@ -8,6 +8,7 @@
 #include "../../uvhand_amd/csrc/msda_generic.hip"
 #include "../../uvhand_amd/csrc/msda_d32.hip"
 #include "../../uvhand_amd/csrc/msda_linear.hip"
+#include "../../uvhand_amd/csrc/msda_gemm.hip"
 #include "../../uvhand_amd/csrc/msda_layernorm.hip"
 #include "../../uvhand_amd/csrc/msda_flatten.hip"
 

@@ -31,7 +31,7 @@ _SYMBOLS = (
     "msda_linear_wgrad_f32", "msda_linear_wgrad_masked_f32", "msda_linear_wgrad_masked_bf16", "msda_linear_wgrad_workspace_bytes",
     "msda_zero_masked_rows_f32", "msda_linear_forward_f32", "msda_linear_dgrad_f32",
     "msda_prologue_supported", "msda_forward_prologue_f32", "msda_backward_prologue_f32",
-    "msda_last_error", "msda_version", "msda_path_for", "msda_force_path",
+    "msda_last_error", "msda_version", "msda_path_for", "msda_force_path", "msda_describe_plan",
 )
 
 
@@ -62,6 +62,8 @@ def load():
     lib.msda_add_layernorm_workspace_bytes.argtypes = [ctypes.c_longlong, ctypes.c_int]
     lib.msda_linear_wgrad_workspace_bytes.restype = ctypes.c_ulonglong
     lib.msda_linear_wgrad_workspace_bytes.argtypes = [ctypes.c_int] * 3
+    lib.msda_describe_plan.restype = ctypes.c_int
+    lib.msda_describe_plan.argtypes = [ctypes.c_int] * 9 + [ctypes.c_uint, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
     _lib = lib
     return lib
 
@@ -484,7 +486,7 @@ def ms_deform_attn_forward_prologue(value, spatial_shapes, level_start_index, re
 
 
 def ms_deform_attn_backward_prologue(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output,
-                                     merged=False, deterministic=None):
+                                     merged=False, deterministic=None, use_workspace=True):
     """Returns (grad_value (float32, also for bf16 rows), grad_sampling_offsets, grad_attn_logits[N,Lq,M,L*P],
     grad_reference_points[N,Lq,L,2]).
     merged=True: the two raw gradients are the column blocks [0, 2*M*L*P) and [2*M*L*P, 3*M*L*P) of ONE
@@ -515,8 +517,9 @@ def ms_deform_attn_backward_prologue(value, spatial_shapes, level_start_index, s
             ld_off = ld_log = 0
         gref = torch.empty((N, Lq, L, 2), dtype=torch.float32, device=value.device)
         det = deterministic_requested() if deterministic is None else bool(deterministic)
+        # use_workspace=False (tests): the call a caller without scratch makes — the library then runs the kernels that need none
         ws, nbytes = _backward_workspace(lib, N, S, M, D, L, Lq, P, value.device,
-                                         FLAG_PROLOGUE | (FLAG_DETERMINISTIC if det else 0))
+                                         FLAG_PROLOGUE | (FLAG_DETERMINISTIC if det else 0)) if use_workspace else (None, 0)
         rc = _entry(lib, "msda_backward_prologue_bf16_gv32" if bf16 else "msda_backward_prologue_ws_f32",
                     [_VP] * 6 + [_CI] * 7 + [_LL] * 2 + [_VP] * 5 + [ctypes.c_ulonglong, ctypes.c_uint, _VP])(
             grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
@@ -650,6 +653,18 @@ def path_for(elem_bytes, M, D, L, P):
     with _ForcedPathScope(load()):
         return int(load().msda_path_for(ctypes.c_int(elem_bytes), ctypes.c_int(M), ctypes.c_int(D),
                                         ctypes.c_int(L), ctypes.c_int(P)))
+
+
+def describe_plan(N, S, M, D, L, Lq, P, row_bytes=4, grad_value_bytes=None, prologue=False, deterministic=False,
+                  has_workspace=True):
+    """msda_describe_plan (include/msda.h): which kernels / launch plan a call of this geometry takes, as text."""
+    lib = _lib or load()
+    buf = ctypes.create_string_buffer(512)
+    flags = (FLAG_PROLOGUE if prologue else 0) | (FLAG_DETERMINISTIC if deterministic else 0)
+    with _ForcedPathScope(lib):
+        lib.msda_describe_plan(row_bytes, grad_value_bytes or row_bytes, N, S, M, D, L, Lq, P, flags, 1 if has_workspace else 0,
+                               buf, len(buf))
+    return buf.value.decode()
 
 
 def force_path(path):

@@ -646,4 +646,24 @@ int msda_path_for(int elem_bytes, int M, int D, int L, int P)
 
 void msda_force_path(int path) { msda::g_force_path = path; }
 
+int msda_describe_plan(int row_bytes, int grad_value_bytes, int N, int S, int M, int D, int L, int Lq, int P, unsigned flags,
+                       int has_workspace, char *buf, int buf_len)
+{
+    if (!buf || buf_len <= 0) return 0;
+    buf[0] = 0;
+    if (N <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Lq <= 0 || P <= 0) return 0;
+    if ((row_bytes != 4 && row_bytes != 2) || msda::g_force_path == MSDA_PATH_GENERIC || !msda::use_d32(N, S, M, D, L, Lq, P)) {
+        const int k = snprintf(buf, (size_t)buf_len, "generic");
+        return k < buf_len ? k : buf_len - 1;
+    }
+    const bool prologue = (flags & MSDA_FLAG_PROLOGUE) != 0;
+    if (prologue && !msda::prologue_supported(N, S, M, D, L, Lq, P)) {
+        const int k = snprintf(buf, (size_t)buf_len, "prologue unsupported");
+        return k < buf_len ? k : buf_len - 1;
+    }
+    const int k = msda::describe_plan(row_bytes, row_bytes == 4 ? 4 : grad_value_bytes, N, S, M, L, Lq, P, prologue, has_workspace != 0,
+                                      (flags & MSDA_FLAG_DETERMINISTIC) != 0, buf, buf_len);
+    return k < buf_len ? k : buf_len - 1;
+}
+
 }  // extern "C"

@@ -19,6 +19,7 @@
 //     octets) still put ~2400 wavefronts with 16 row loads each in flight;
 //     SPLIT = 1: one octet per wavefront, no cross-wave reduction (encoder regime,
 //     large batches).
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -1122,6 +1123,41 @@ int launch_bwd_d32_bf16_gv32(const uint16_t *grad_out, const uint16_t *value, co
 
 #if MSDA_D32_HAS(0)
 int backward_passes(int Lq, int P) { return (Lq * P + kSingleMaxPoints - 1) / kSingleMaxPoints; }
+
+// What the launchers above would do for a geometry, as text (msda_describe_plan, include/msda.h): the same plan functions,
+// nothing launched.  row_bytes = 4 (fp32 rows) or 2 (bf16 rows); gv_bytes the same for grad_value.
+template <typename VT, typename GT>
+static int describe_plan_t(int N, int S, int M, int L, int Lq, int P, bool prologue, bool has_ws, bool det, char *buf, int len)
+{
+    const int items = N * Lq * M, LP = L * P;
+    int n = 0;
+    auto put = [&](const char *fmt, auto... a) { if (n < len) { const int k = snprintf(buf + n, (size_t)(len - n), fmt, a...); n += k > 0 ? k : 0; } };
+    const LdsPlan lf = plan_lds<VT>(N, S, M, L, Lq, P);
+    if (lf.use) put("fwd=lds(chunks=%d,qw=%d,stage_rows=%d,wgs=%d)", lf.chunks, lf.qw, lf.stage_rows, N * M * lf.chunks);
+    else { const int sp = pick_split(items, LP); put("fwd=tiled(split=%d,wgs=%d)", sp, (items + 32 / sp - 1) / (32 / sp)); }
+    const ValuePlan pl = plan_value<GT>(N, S, M, L, Lq, P, bwd_target_wgs(), det);
+    const long long nB = (long long)pl.W * N * M * L;
+    const char *acc = pl.acc == kAccNone ? "single" : pl.acc == kAccWide ? "wide" : pl.acc == kAccTile ? "tile" : "rmw";
+    const LdsPlan la = plan_lds<VT>(N, S, M, L, Lq, P, nB);
+    const bool lds_ok = la.use && pl.ppt == kSinglePPT && (pl.acc == kAccNone || pl.acc == kAccWide) && (!prologue || has_ws);
+    if (lds_ok)
+        put(" bwd=fused_lds(acc=%s,W=%d,tp_cap=%d,roleB=%lld,roleA=%d,qw=%d%s%s)", acc, pl.W, pl.tp_cap, nB, N * M * la.chunks, la.qw,
+            det ? ",det" : "", prologue ? ",heads_reduce" : "");
+    else if (pl.ppt == kSinglePPT && pl.acc != kAccTile) {
+        const FusedPlan fp = plan_fused(items, LP, pick_split(items, LP), nB, pl.acc, prologue ? M : 0, det);
+        put(" bwd=fused(acc=%s,W=%d,tp_cap=%d,roleB=%lld,roleA=%d,split=%d,%s%s)", acc, pl.W, pl.tp_cap, nB,
+            (items + 64 / fp.split - 1) / (64 / fp.split), fp.split, fp.fixed ? "fixed" : "prefix", det ? ",det" : "");
+    } else
+        put(" bwd=two_launches(acc=%s,W=%d,tp_cap=%d,roleB=%lld,roleA=%s%s)", acc, pl.W, pl.tp_cap, nB, la.use ? "lds" : "tiled", det ? ",det" : "");
+    return n;
+}
+int describe_plan(int row_bytes, int gv_bytes, int N, int S, int M, int L, int Lq, int P, bool prologue, bool has_ws, bool det,
+                  char *buf, int len)
+{
+    if (row_bytes == 4) return describe_plan_t<float, float>(N, S, M, L, Lq, P, prologue, has_ws, det, buf, len);
+    if (gv_bytes == 4) return describe_plan_t<bf16_t, float>(N, S, M, L, Lq, P, prologue, has_ws, det, buf, len);
+    return describe_plan_t<bf16_t, bf16_t>(N, S, M, L, Lq, P, prologue, has_ws, det, buf, len);
+}
 #endif
 
 }  // namespace msda

@@ -66,6 +66,9 @@ int launch_bwd_d32_bf16_gv32(const uint16_t *grad_out, const uint16_t *value, co
                              void *workspace = nullptr, size_t ws_bytes = 0, bool deterministic = false);
 // number of query chunks ("passes") role B of the D = 32 backward takes for Lq*P sampling points per (b, m, l)
 int backward_passes(int Lq, int P);
+// text form of the launch plan of a D = 32 geometry (msda_describe_plan); returns the length written
+int describe_plan(int row_bytes, int gv_bytes, int N, int S, int M, int L, int Lq, int P, bool prologue, bool has_ws, bool det,
+                  char *buf, int len);
 
 // ---- fused prologue (fp32, D = 32 family): softmax over L*P and loc = ref + offset/(W,H) inside the kernels.
 // ld_* = floats between consecutive (batch, query) rows of the raw offsets / logits and of their gradients

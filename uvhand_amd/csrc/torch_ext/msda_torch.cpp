@@ -57,6 +57,18 @@ void raise_if(int rc, const char *what)
     TORCH_CHECK(rc == 0, what, " failed (code ", rc, "): ", msda_last_error());
 }
 
+
+// models/ops/functions/ms_deform_attn_func.py:31 marks the backward @once_differentiable.  The nodes below end in raw-pointer
+// kernels, so a second differentiation through them would return gradients that silently ignore the graph: refuse it where
+// the reference's decorator raises (a grad_output that itself carries a graph while grad mode is on, i.e. create_graph=True).
+void once_differentiable(const torch::autograd::variable_list &grads, const char *what)
+{
+    if (!at::GradMode::is_enabled()) return;
+    for (const auto &g : grads)
+        TORCH_CHECK(!(g.defined() && g.requires_grad()), what,
+                    ": trying to differentiate twice a function that was marked with @once_differentiable");
+}
+
 at::Tensor forward(const at::Tensor &value, const at::Tensor &shapes, const at::Tensor &lsi, const at::Tensor &loc,
                    const at::Tensor &attn, int64_t im2col_step)
 {
@@ -125,6 +137,7 @@ public:
 
     static torch::autograd::variable_list backward(torch::autograd::AutogradContext *ctx, torch::autograd::variable_list grads)
     {
+        once_differentiable(grads, "MSDeformAttnFunction");
         const auto saved = ctx->get_saved_variables();
         const auto g = ::backward(saved[0].to(saved[3].scalar_type()), saved[1], saved[2], saved[3], saved[4], grads[0],
                                   ctx->saved_data["step"].toInt(), (ctx->saved_data["det"].toBool() || at::globalContext().deterministicAlgorithms()));
@@ -188,6 +201,7 @@ public:
 
     static torch::autograd::variable_list backward(torch::autograd::AutogradContext *ctx, torch::autograd::variable_list grads)
     {
+        once_differentiable(grads, "MSDeformAttnBF16Function");
         const auto saved = ctx->get_saved_variables();
         const at::Tensor &value = saved[0], &shapes = saved[1], &lsi = saved[2], &loc = saved[3], &attn = saved[4];
         const at::Tensor v16 = value.to(at::kBFloat16), l32 = loc.to(at::kFloat), a32 = attn.to(at::kFloat);
@@ -239,10 +253,19 @@ at::Tensor apply_bf16(const at::Tensor &value, const at::Tensor &shapes, const a
 // (models/ops/modules/ms_deform_attn.py:96-139 and its autograd) — queued from C++ with no Python in between: the eager
 // step at decoder sizes is bound by host time, not by the GPU (profiles/r02_notes.md section 7).  Same kernels, same
 // arithmetic, same results as the Python composition (tests/test_module_gpu.py runs both).
+inline bool aligned16(const at::Tensor &t) { return (reinterpret_cast<uintptr_t>(t.data_ptr()) & 15) == 0; }
+
 inline at::Tensor wgrad_into(const at::Tensor &dY2, const at::Tensor &X2, const at::Tensor *mask, at::Tensor &gb, bool want_bias,
                              msda_stream_t stream)
 {
     const int M = (int)dY2.size(0), N = (int)dY2.size(1), K = (int)X2.size(1);
+    // what msda_linear_wgrad_masked_f32 takes (include/msda.h): N, K multiples of 4, 16-byte aligned dense operands — else the
+    // same composition functions/linear_func.py falls back to (n_heads*n_levels*n_points == 2, an unaligned grad_output view)
+    if (N % 4 != 0 || K % 4 != 0 || M <= 0 || !dY2.is_contiguous() || !X2.is_contiguous() || !aligned16(dY2) || !aligned16(X2)) {
+        const at::Tensor dy = mask ? dY2.masked_fill(mask->view({-1, 1}), 0) : dY2;
+        if (want_bias) gb = dy.sum(0);
+        return dy.t().mm(X2);
+    }
     auto gw = at::empty({N, K}, dY2.options());
     if (want_bias) gb = at::empty({N}, dY2.options());
     const unsigned long long nbytes = msda_linear_wgrad_workspace_bytes(M, N, K);
@@ -263,7 +286,7 @@ inline at::Tensor wgrad_into(const at::Tensor &dY2, const at::Tensor &X2, const 
 static bool own_linear(const at::Tensor &a2, const at::Tensor &w)
 {
     const int64_t rows = a2.size(0), out_f = w.size(0), in_f = w.size(1);
-    return rows * out_f <= 4800LL * 256 && in_f <= 512 && out_f % 4 == 0 && in_f % 4 == 0 && w.is_contiguous() &&
+    return a2.dim() == 2 && w.dim() == 2 && rows * out_f <= 4800LL * 256 && in_f <= 512 && out_f % 4 == 0 && in_f % 4 == 0 && w.is_contiguous() &&
            a2.is_contiguous() && (reinterpret_cast<uintptr_t>(a2.data_ptr()) & 15) == 0 &&
            (reinterpret_cast<uintptr_t>(w.data_ptr()) & 15) == 0;
 }
@@ -277,6 +300,8 @@ static at::Tensor linear_rows_forward(const at::Tensor &x2, const at::Tensor &w,
                                       msda_stream_t stream)
 {
     const int64_t rows = x2.size(0);
+    TORCH_CHECK(x2.dim() == 2 && w.dim() == 2 && x2.size(1) == w.size(1) && b.numel() == w.size(0),
+                "MSDeformAttn (C++ node): a projection's input ", x2.sizes(), " does not match its weight ", w.sizes());
     if (own_linear(x2, w) && b.is_contiguous() && (reinterpret_cast<uintptr_t>(b.data_ptr()) & 15) == 0) {
         at::Tensor y = at::empty({rows, w.size(0)}, x2.options());
         raise_if(msda_linear_forward_f32(x2.data_ptr<float>(), w.data_ptr<float>(), b.data_ptr<float>(), mask_bytes(rmask), rows,
@@ -292,6 +317,8 @@ static at::Tensor linear_rows_forward(const at::Tensor &x2, const at::Tensor &w,
 static at::Tensor linear_rows_dgrad(const at::Tensor &g2, const at::Tensor &w, const at::Tensor *rmask, msda_stream_t stream)
 {
     const int64_t rows = g2.size(0);
+    TORCH_CHECK(g2.dim() == 2 && w.dim() == 2 && g2.size(1) == w.size(0),
+                "MSDeformAttn (C++ node): a projection's output gradient ", g2.sizes(), " does not match its weight ", w.sizes());
     if (own_linear(g2, w)) {
         at::Tensor gx = at::empty({rows, w.size(1)}, g2.options());
         raise_if(msda_linear_dgrad_f32(g2.data_ptr<float>(), w.data_ptr<float>(), mask_bytes(rmask), rows, (int)w.size(0),
@@ -304,15 +331,50 @@ static at::Tensor linear_rows_dgrad(const at::Tensor &g2, const at::Tensor &w, c
     return gx;
 }
 
+// Everything the kernels index with: checked here because the node passes raw pointers (the Python composition raised
+// 'inconsistent shapes' from uvhand_amd._native; models/ops/modules/ms_deform_attn.py:92-94 asserts the pixel count only).
+static void check_module_args(const at::Tensor &query, const at::Tensor &centre, const at::Tensor &input_flatten,
+                              const c10::optional<at::Tensor> &mask, const at::Tensor &shapes, const at::Tensor &lsi,
+                              const at::Tensor &w_off, const at::Tensor &b_off, const at::Tensor &w_attn, const at::Tensor &b_attn,
+                              const at::Tensor &w_val, const at::Tensor &b_val, const at::Tensor &w_out, const at::Tensor &b_out,
+                              int64_t M, int64_t L, int64_t P)
+{
+    TORCH_CHECK(M > 0 && L > 0 && P > 0, "MSDeformAttn (C++ node): n_heads, n_levels, n_points must be positive");
+    TORCH_CHECK(query.dim() == 3 && input_flatten.dim() == 3 && query.size(0) == input_flatten.size(0) &&
+                query.size(2) == input_flatten.size(2),
+                "MSDeformAttn (C++ node): expected query[N,Lq,C] and input_flatten[N,S,C], got ", query.sizes(), " and ",
+                input_flatten.sizes());
+    const int64_t N = query.size(0), Lq = query.size(1), C = query.size(2), S = input_flatten.size(1), mlp = M * L * P;
+    TORCH_CHECK(C % M == 0, "MSDeformAttn (C++ node): d_model ", C, " is not divisible by n_heads ", M);
+    TORCH_CHECK(centre.sizes() == at::IntArrayRef({N, Lq, L, 2}),
+                "MSDeformAttn (C++ node): reference points must be [N,Lq,n_levels,2] = [", N, ",", Lq, ",", L, ",2], got ", centre.sizes());
+    TORCH_CHECK(shapes.sizes() == at::IntArrayRef({L, 2}) && lsi.sizes() == at::IntArrayRef({L}),
+                "MSDeformAttn (C++ node): spatial_shapes must be [", L, ",2] and level_start_index [", L, "], got ", shapes.sizes(),
+                " and ", lsi.sizes());
+    TORCH_CHECK(shapes.is_contiguous() && lsi.is_contiguous(), "spatial_shapes / level_start_index have to be contiguous");
+    if (mask.has_value() && mask->defined())
+        TORCH_CHECK(mask->scalar_type() == at::kBool && mask->is_cuda() && mask->device() == query.device() && mask->numel() == N * S,
+                    "MSDeformAttn (C++ node): padding mask must be a bool CUDA tensor of N*S = ", N * S, " elements");
+    TORCH_CHECK(w_off.sizes() == at::IntArrayRef({2 * mlp, C}) && b_off.sizes() == at::IntArrayRef({2 * mlp}),
+                "MSDeformAttn (C++ node): sampling_offsets must be Linear(", C, ", ", 2 * mlp, "), got weight ", w_off.sizes());
+    TORCH_CHECK(w_attn.sizes() == at::IntArrayRef({mlp, C}) && b_attn.sizes() == at::IntArrayRef({mlp}),
+                "MSDeformAttn (C++ node): attention_weights must be Linear(", C, ", ", mlp, "), got weight ", w_attn.sizes());
+    TORCH_CHECK(w_val.sizes() == at::IntArrayRef({C, C}) && b_val.sizes() == at::IntArrayRef({C}) &&
+                w_out.sizes() == at::IntArrayRef({C, C}) && b_out.sizes() == at::IntArrayRef({C}),
+                "MSDeformAttn (C++ node): value_proj / output_proj must be Linear(", C, ", ", C, ")");
+    TORCH_CHECK(mlp % 2 == 0, "MSDeformAttn (C++ node): n_heads*n_levels*n_points must be even (the kernels move (x, y) pairs)");
+}
+
 class MSDAModuleFunction : public torch::autograd::Function<MSDAModuleFunction> {
 public:
-    // inputs 0..2 may need gradients (query, centre = reference point per level, input_flatten), 5..12 are the parameters
+    // inputs 0..2 may need gradients (query, centre = reference point per level, input_flatten), 6..13 are the parameters
     static at::Tensor forward(torch::autograd::AutogradContext *ctx, const at::Tensor &query, const at::Tensor &centre,
                               const at::Tensor &input_flatten, const c10::optional<at::Tensor> &mask, const at::Tensor &shapes,
                               const at::Tensor &lsi, const at::Tensor &w_off, const at::Tensor &b_off, const at::Tensor &w_attn,
                               const at::Tensor &b_attn, const at::Tensor &w_val, const at::Tensor &b_val, const at::Tensor &w_out,
                               const at::Tensor &b_out, int64_t n_heads, int64_t n_levels, int64_t n_points, int64_t im2col_step,
-                              bool deterministic)
+                              bool deterministic, const c10::optional<at::Tensor> &wm_cached,
+                              const c10::optional<at::Tensor> &bm_cached)
     {
         const int N = (int)query.size(0), Lq = (int)query.size(1), C = (int)query.size(2), S = (int)input_flatten.size(1);
         const int M = (int)n_heads, L = (int)n_levels, P = (int)n_points, D = C / M, mlp = M * L * P;
@@ -321,14 +383,23 @@ public:
         TORCH_CHECK(N == 0 || (step > 0 && N % step == 0), "batch(", N, ") must divide im2col_step(", step, ")");
         c10::hip::HIPGuardMasqueradingAsCUDA guard(query.device());
         auto stream = (msda_stream_t)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(query.device().index()).stream();
-        const at::Tensor q2 = query.contiguous(), x2 = input_flatten.contiguous(), c2 = centre.contiguous();
+        const at::Tensor q2 = query.contiguous(), x2 = input_flatten.contiguous();
+        at::Tensor c2 = centre.contiguous();
+        if (reinterpret_cast<uintptr_t>(c2.data_ptr()) & 7) c2 = c2.clone();       // the kernels read (x, y) pairs as 8 bytes
         at::Tensor rmask;
         if (mask.has_value() && mask->defined()) rmask = mask->reshape({-1}).contiguous();
         // value_proj (+ the padding mask on the masked rows only)
         const at::Tensor value = linear_rows_forward(x2.view({(int64_t)N * S, C}), w_val, b_val, rmask.defined() ? &rmask : nullptr,
                                                      stream);                                 // [N*S, C]
         // sampling_offsets and attention_weights as ONE GEMM (both read the same query); the kernels read its output in place
-        const at::Tensor wm = at::cat({w_off, w_attn}, 0), bm = at::cat({b_off, b_attn}, 0);
+        // (the caller may hand over the concatenation it keeps while the four parameters are unchanged: two launches less)
+        const bool cached = wm_cached.has_value() && wm_cached->defined() && bm_cached.has_value() && bm_cached->defined();
+        if (cached)
+            TORCH_CHECK(wm_cached->sizes() == at::IntArrayRef({3LL * mlp, (int64_t)C}) && bm_cached->sizes() == at::IntArrayRef({3LL * mlp}) &&
+                        wm_cached->scalar_type() == at::kFloat && bm_cached->scalar_type() == at::kFloat && wm_cached->is_contiguous() &&
+                        bm_cached->is_contiguous() && wm_cached->device() == query.device() && bm_cached->device() == query.device(),
+                        "MSDeformAttn (C++ node): cached merged projection has the wrong shape / dtype / device");
+        const at::Tensor wm = cached ? wm_cached->detach() : at::cat({w_off, w_attn}, 0), bm = cached ? bm_cached->detach() : at::cat({b_off, b_attn}, 0);
         const at::Tensor projected = linear_rows_forward(q2.view({(int64_t)N * Lq, C}), wm, bm, nullptr, stream);   // [N*Lq, 3*mlp]
         auto sampled = at::empty({N, Lq, C}, q2.options());
         auto loc = at::empty({N, Lq, M, L, P, 2}, q2.options()), attn = at::empty({N, Lq, M, L, P}, q2.options());
@@ -345,9 +416,15 @@ public:
 
     static torch::autograd::variable_list backward(torch::autograd::AutogradContext *ctx, torch::autograd::variable_list grads)
     {
+        once_differentiable(grads, "MSDeformAttn (C++ node)");
         const auto sv = ctx->get_saved_variables();
         const at::Tensor &q2 = sv[0], &x2 = sv[1], &rmask = sv[2], &value = sv[3], &loc = sv[4], &attn = sv[5], &sampled = sv[6],
                          &wm = sv[7], &w_val = sv[8], &w_out = sv[9], &shapes = sv[10], &lsi = sv[11];
+        // forward arguments 6..13 are the parameters (w_off, b_off, w_attn, b_attn, w_val, b_val, w_out, b_out): a frozen layer
+        // (util/settings.py:447-515 lr groups, --not_use_params) gets no weight-gradient launch
+        const bool need_m = ctx->needs_input_grad(6) || ctx->needs_input_grad(7) || ctx->needs_input_grad(8) || ctx->needs_input_grad(9);
+        const bool need_val = ctx->needs_input_grad(10) || ctx->needs_input_grad(11);
+        const bool need_out = ctx->needs_input_grad(12) || ctx->needs_input_grad(13);
         const auto dims = ctx->saved_data["dims"].toIntVector();
         const int N = (int)dims[0], S = (int)dims[1], M = (int)dims[2], D = (int)dims[3], L = (int)dims[4], Lq = (int)dims[5],
                   P = (int)dims[6], C = (int)dims[7], mlp = M * L * P;
@@ -358,7 +435,8 @@ public:
         // output_proj
         at::Tensor gb_out, gb_m, gb_val;
         const at::Tensor g_sampled = linear_rows_dgrad(go2, w_out, nullptr, stream);           // [N*Lq, C]
-        const at::Tensor gw_out = wgrad_into(go2, sampled.view({(int64_t)N * Lq, C}), nullptr, gb_out, true, stream);
+        at::Tensor gw_out, gw_m, gw_val;
+        if (need_out) gw_out = wgrad_into(go2, sampled.view({(int64_t)N * Lq, C}), nullptr, gb_out, true, stream);
         // the sampling kernels: gradients of value, of the raw offsets / logits (one tensor, the projection's layout) and of
         // the reference points
         const bool det = ctx->saved_data["det"].toBool() || at::globalContext().deterministicAlgorithms();
@@ -377,15 +455,17 @@ public:
         // merged projection
         at::Tensor g_query;
         if (ctx->needs_input_grad(0)) g_query = linear_rows_dgrad(gproj, wm, nullptr, stream).view({N, Lq, C});
-        const at::Tensor gw_m = wgrad_into(gproj, q2.view({(int64_t)N * Lq, C}), nullptr, gb_m, true, stream);
+        if (need_m) gw_m = wgrad_into(gproj, q2.view({(int64_t)N * Lq, C}), nullptr, gb_m, true, stream);
         // value_proj: masked rows of grad_value count as zero (weight gradient) and get a zero input gradient
         const at::Tensor gv2 = gv.view({(int64_t)N * S, C});
         at::Tensor g_input;
         if (ctx->needs_input_grad(2)) g_input = linear_rows_dgrad(gv2, w_val, maskp, stream).view({N, S, C});
-        const at::Tensor gw_val = wgrad_into(gv2, x2.view({(int64_t)N * S, C}), maskp, gb_val, true, stream);
-        return {g_query, gref, g_input, at::Tensor(), at::Tensor(), at::Tensor(),
-                gw_m.narrow(0, 0, 2 * mlp), gb_m.narrow(0, 0, 2 * mlp), gw_m.narrow(0, 2 * mlp, mlp), gb_m.narrow(0, 2 * mlp, mlp),
-                gw_val, gb_val, gw_out, gb_out, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+        if (need_val) gw_val = wgrad_into(gv2, x2.view({(int64_t)N * S, C}), maskp, gb_val, true, stream);
+        const at::Tensor none;
+        return {g_query, gref, g_input, none, none, none,
+                need_m ? gw_m.narrow(0, 0, 2 * mlp) : none, need_m ? gb_m.narrow(0, 0, 2 * mlp) : none,
+                need_m ? gw_m.narrow(0, 2 * mlp, mlp) : none, need_m ? gb_m.narrow(0, 2 * mlp, mlp) : none,
+                gw_val, gb_val, gw_out, gb_out, none, none, none, none, none, none, none};
     }
 };
 
@@ -418,7 +498,8 @@ public:
                               const at::Tensor &lsi, const at::Tensor &w_off, const at::Tensor &b_off, const at::Tensor &w_attn,
                               const at::Tensor &b_attn, const at::Tensor &w_val, const at::Tensor &b_val, const at::Tensor &w_out,
                               const at::Tensor &b_out, int64_t n_heads, int64_t n_levels, int64_t n_points, int64_t im2col_step,
-                              bool deterministic)
+                              bool deterministic, const c10::optional<at::Tensor> &wm_cached,
+                              const c10::optional<at::Tensor> &bm_cached)
     {
         const int N = (int)query.size(0), Lq = (int)query.size(1), C = (int)query.size(2), S = (int)input_flatten.size(1);
         const int M = (int)n_heads, L = (int)n_levels, P = (int)n_points, D = C / M, mlp = M * L * P;
@@ -429,7 +510,9 @@ public:
         auto stream = (msda_stream_t)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(query.device().index()).stream();
         // the casts are spelled out below: autocast must not re-cast the float32 query projection
         c10::impl::ExcludeDispatchKeyGuard no_autocast(c10::DispatchKeySet(c10::DispatchKey::AutocastCUDA));
-        const at::Tensor q2 = query.contiguous(), c2 = centre.contiguous();
+        const at::Tensor q2 = query.contiguous();
+        at::Tensor c2 = centre.contiguous();
+        if (reinterpret_cast<uintptr_t>(c2.data_ptr()) & 7) c2 = c2.clone();       // the kernels read (x, y) pairs as 8 bytes
         at::Tensor rmask;
         if (mask.has_value() && mask->defined()) rmask = mask->reshape({-1}).contiguous();
         // value_proj on bf16 operands, then the padding mask
@@ -437,7 +520,14 @@ public:
         at::Tensor value = at::linear(xb, wvb, b_val.to(at::kBFloat16));                // [N, S, C] bf16
         if (rmask.defined()) value = value.masked_fill(rmask.view({N, S, 1}), 0);
         // the query projection stays float32
-        const at::Tensor wm = at::cat({w_off, w_attn}, 0), bm = at::cat({b_off, b_attn}, 0);
+        // (the caller may hand over the concatenation it keeps while the four parameters are unchanged: two launches less)
+        const bool cached = wm_cached.has_value() && wm_cached->defined() && bm_cached.has_value() && bm_cached->defined();
+        if (cached)
+            TORCH_CHECK(wm_cached->sizes() == at::IntArrayRef({3LL * mlp, (int64_t)C}) && bm_cached->sizes() == at::IntArrayRef({3LL * mlp}) &&
+                        wm_cached->scalar_type() == at::kFloat && bm_cached->scalar_type() == at::kFloat && wm_cached->is_contiguous() &&
+                        bm_cached->is_contiguous() && wm_cached->device() == query.device() && bm_cached->device() == query.device(),
+                        "MSDeformAttn (C++ node): cached merged projection has the wrong shape / dtype / device");
+        const at::Tensor wm = cached ? wm_cached->detach() : at::cat({w_off, w_attn}, 0), bm = cached ? bm_cached->detach() : at::cat({b_off, b_attn}, 0);
         const at::Tensor projected = linear_rows_forward(q2.view({(int64_t)N * Lq, C}), wm, bm, nullptr, stream);
         auto sampled = at::empty({N, Lq, C}, xb.options());
         auto loc = at::empty({N, Lq, M, L, P, 2}, q2.options()), attn = at::empty({N, Lq, M, L, P}, q2.options());
@@ -457,6 +547,10 @@ public:
 
     static torch::autograd::variable_list backward(torch::autograd::AutogradContext *ctx, torch::autograd::variable_list grads)
     {
+        once_differentiable(grads, "MSDeformAttn (C++ node, bf16 rows)");
+        const bool need_m = ctx->needs_input_grad(6) || ctx->needs_input_grad(7) || ctx->needs_input_grad(8) || ctx->needs_input_grad(9);
+        const bool need_val = ctx->needs_input_grad(10) || ctx->needs_input_grad(11);
+        const bool need_out = ctx->needs_input_grad(12) || ctx->needs_input_grad(13);
         const auto sv = ctx->get_saved_variables();
         const at::Tensor &q2 = sv[0], &xb = sv[1], &rmask = sv[2], &value = sv[3], &loc = sv[4], &attn = sv[5], &sampled = sv[6],
                          &wm = sv[7], &wvb = sv[8], &wob = sv[9], &shapes = sv[10], &lsi = sv[11];
@@ -469,7 +563,8 @@ public:
         const at::Tensor go2 = grads[0].reshape({(int64_t)N * Lq, C}).to(at::kBFloat16).contiguous();
         at::Tensor gb_out, gb_m, gb_val;
         const at::Tensor g_sampled = at::mm(go2, wob);                                  // [N*Lq, C] bf16
-        const at::Tensor gw_out = wgrad_into_bf16(go2, sampled.view({(int64_t)N * Lq, C}), gb_out, stream);
+        at::Tensor gw_out, gw_m, gw_val;
+        if (need_out) gw_out = wgrad_into_bf16(go2, sampled.view({(int64_t)N * Lq, C}), gb_out, stream);
         // the sampling kernels: bf16 rows in, float32 gradients out
         const bool det = ctx->saved_data["det"].toBool() || at::globalContext().deterministicAlgorithms();
         const unsigned flags = MSDA_FLAG_PROLOGUE | (det ? MSDA_FLAG_DETERMINISTIC : 0u);
@@ -489,7 +584,7 @@ public:
         // merged projection (float32)
         at::Tensor g_query;
         if (ctx->needs_input_grad(0)) g_query = linear_rows_dgrad(gproj, wm, nullptr, stream).view({N, Lq, C});
-        const at::Tensor gw_m = wgrad_into(gproj, q2.view({(int64_t)N * Lq, C}), nullptr, gb_m, true, stream);
+        if (need_m) gw_m = wgrad_into(gproj, q2.view({(int64_t)N * Lq, C}), nullptr, gb_m, true, stream);
         // value_proj: grad_value goes back to the rows' type, the mask's rows to zero, then the two GEMMs on bf16 operands
         at::Tensor gvb = gv.to(at::kBFloat16);
         if (rmask.defined()) gvb = gvb.masked_fill(rmask.view({N, S, 1}), 0);
@@ -499,10 +594,12 @@ public:
             g_input = at::mm(gvb2, wvb).view({N, S, C});
             if (ctx->saved_data["x_float"].toBool()) g_input = g_input.to(at::kFloat);
         }
-        const at::Tensor gw_val = wgrad_into_bf16(gvb2, xb.view({(int64_t)N * S, C}), gb_val, stream);
-        return {g_query, gref, g_input, at::Tensor(), at::Tensor(), at::Tensor(),
-                gw_m.narrow(0, 0, 2 * mlp), gb_m.narrow(0, 0, 2 * mlp), gw_m.narrow(0, 2 * mlp, mlp), gb_m.narrow(0, 2 * mlp, mlp),
-                gw_val, gb_val, gw_out, gb_out, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+        if (need_val) gw_val = wgrad_into_bf16(gvb2, xb.view({(int64_t)N * S, C}), gb_val, stream);
+        const at::Tensor none;
+        return {g_query, gref, g_input, none, none, none,
+                need_m ? gw_m.narrow(0, 0, 2 * mlp) : none, need_m ? gb_m.narrow(0, 0, 2 * mlp) : none,
+                need_m ? gw_m.narrow(0, 2 * mlp, mlp) : none, need_m ? gb_m.narrow(0, 2 * mlp, mlp) : none,
+                gw_val, gb_val, gw_out, gb_out, none, none, none, none, none, none, none};
     }
 };
 
@@ -510,7 +607,8 @@ at::Tensor module_forward_bf16(const at::Tensor &query, const at::Tensor &centre
                                const c10::optional<at::Tensor> &mask, const at::Tensor &shapes, const at::Tensor &lsi,
                                const at::Tensor &w_off, const at::Tensor &b_off, const at::Tensor &w_attn, const at::Tensor &b_attn,
                                const at::Tensor &w_val, const at::Tensor &b_val, const at::Tensor &w_out, const at::Tensor &b_out,
-                               int64_t n_heads, int64_t n_levels, int64_t n_points, int64_t im2col_step, bool deterministic)
+                               int64_t n_heads, int64_t n_levels, int64_t n_points, int64_t im2col_step, bool deterministic,
+                               const c10::optional<at::Tensor> &wm_cached, const c10::optional<at::Tensor> &bm_cached)
 {
     for (const at::Tensor *t : {&query, &centre, &w_off, &b_off, &w_attn, &b_attn, &w_val, &b_val, &w_out, &b_out})
         TORCH_CHECK(t->is_cuda() && t->scalar_type() == at::kFloat && t->device() == query.device(),
@@ -519,23 +617,30 @@ at::Tensor module_forward_bf16(const at::Tensor &query, const at::Tensor &centre
                 "MSDeformAttn (C++ node, bf16 rows): float32 or bfloat16 input_flatten expected");
     TORCH_CHECK(shapes.is_cuda() && lsi.is_cuda() && shapes.scalar_type() == at::kLong && lsi.scalar_type() == at::kLong,
                 "expected scalar type Long for spatial_shapes / level_start_index (on the device)");
+    TORCH_CHECK(input_flatten.device() == query.device(), "MSDeformAttn (C++ node, bf16 rows): input_flatten on another device");
+    check_module_args(query, centre, input_flatten, mask, shapes, lsi, w_off, b_off, w_attn, b_attn, w_val, b_val, w_out, b_out,
+                      n_heads, n_levels, n_points);
     return MSDAModuleBF16Function::apply(query, centre, input_flatten, mask, shapes, lsi, w_off, b_off, w_attn, b_attn, w_val,
-                                         b_val, w_out, b_out, n_heads, n_levels, n_points, im2col_step, deterministic);
+                                         b_val, w_out, b_out, n_heads, n_levels, n_points, im2col_step, deterministic, wm_cached,
+                                         bm_cached);
 }
 
 at::Tensor module_forward(const at::Tensor &query, const at::Tensor &centre, const at::Tensor &input_flatten,
                           const c10::optional<at::Tensor> &mask, const at::Tensor &shapes, const at::Tensor &lsi,
                           const at::Tensor &w_off, const at::Tensor &b_off, const at::Tensor &w_attn, const at::Tensor &b_attn,
                           const at::Tensor &w_val, const at::Tensor &b_val, const at::Tensor &w_out, const at::Tensor &b_out,
-                          int64_t n_heads, int64_t n_levels, int64_t n_points, int64_t im2col_step, bool deterministic)
+                          int64_t n_heads, int64_t n_levels, int64_t n_points, int64_t im2col_step, bool deterministic,
+                          const c10::optional<at::Tensor> &wm_cached, const c10::optional<at::Tensor> &bm_cached)
 {
     for (const at::Tensor *t : {&query, &centre, &input_flatten, &w_off, &b_off, &w_attn, &b_attn, &w_val, &b_val, &w_out, &b_out})
         TORCH_CHECK(t->is_cuda() && t->scalar_type() == at::kFloat && t->device() == query.device(),
                     "MSDeformAttn (C++ node): float32 CUDA tensors on one device expected");
     TORCH_CHECK(shapes.is_cuda() && lsi.is_cuda() && shapes.scalar_type() == at::kLong && lsi.scalar_type() == at::kLong,
                 "expected scalar type Long for spatial_shapes / level_start_index (on the device)");
+    check_module_args(query, centre, input_flatten, mask, shapes, lsi, w_off, b_off, w_attn, b_attn, w_val, b_val, w_out, b_out,
+                      n_heads, n_levels, n_points);
     return MSDAModuleFunction::apply(query, centre, input_flatten, mask, shapes, lsi, w_off, b_off, w_attn, b_attn, w_val, b_val,
-                                     w_out, b_out, n_heads, n_levels, n_points, im2col_step, deterministic);
+                                     w_out, b_out, n_heads, n_levels, n_points, im2col_step, deterministic, wm_cached, bm_cached);
 }
 
 }  // namespace
@@ -547,9 +652,16 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("ms_deform_attn_backward", &backward, "replaces MSDA.ms_deform_attn_backward (vision.cpp:15)");
     m.def("apply", &apply, "MSDeformAttnFunction.apply as a C++ autograd node");
     m.def("apply_bf16", &apply_bf16, "MSDeformAttnBF16Function.apply as a C++ autograd node");
+#define MSDA_MODULE_ARGS                                                                                                      \
+    py::arg("query"), py::arg("centre"), py::arg("input_flatten"), py::arg("mask"), py::arg("spatial_shapes"),                \
+        py::arg("level_start_index"), py::arg("w_off"), py::arg("b_off"), py::arg("w_attn"), py::arg("b_attn"), py::arg("w_val"), \
+        py::arg("b_val"), py::arg("w_out"), py::arg("b_out"), py::arg("n_heads"), py::arg("n_levels"), py::arg("n_points"),   \
+        py::arg("im2col_step"), py::arg("deterministic"), py::arg("wm_cached") = py::none(), py::arg("bm_cached") = py::none()
     m.def("module_forward_bf16", &module_forward_bf16,
-          "MSDeformAttn.forward under autocast(bfloat16) with bf16 rows as one C++ autograd node");
-    m.def("module_forward", &module_forward, "MSDeformAttn.forward (fp32, fused prologue + merged projection) as one C++ autograd node");
+          "MSDeformAttn.forward under autocast(bfloat16) with bf16 rows as one C++ autograd node", MSDA_MODULE_ARGS);
+    m.def("module_forward", &module_forward, "MSDeformAttn.forward (fp32, fused prologue + merged projection) as one C++ autograd node",
+          MSDA_MODULE_ARGS);
+#undef MSDA_MODULE_ARGS
     // the header this file was COMPILED against (not the loaded library's msda_version(): _ext.py compares the two)
     m.def("abi_version", [] { return (int)MSDA_ABI_VERSION; });
 }

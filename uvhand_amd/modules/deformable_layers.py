@@ -1,6 +1,8 @@
 """``DeformableTransformerEncoderLayer`` / ``DeformableTransformerDecoderLayer`` — the transformer layers either side of
 the op, drop-in for UVHand ``models/arctic_transformer.py:261-300`` and ``:334-391`` (same classes,
-same lines ±6, in ``origin_deformable_transformer.py`` and ``assembly_transformer.py``).
+same lines ±6, in ``origin_deformable_transformer.py`` and ``assembly_transformer.py``) — and the two stacks that call
+them, ``DeformableTransformerEncoder`` / ``DeformableTransformerDecoder`` (``:302-330``, ``:394-460``): the layer loops with
+the reference-point hand-off between layers.
 
 Contract kept: constructor signatures and defaults; sub-module names and creation order (``self_attn, dropout1, norm1,
 linear1, dropout2, linear2, dropout3, norm2`` / ``cross_attn, dropout1, norm1, self_attn, dropout2, norm2, linear1,
@@ -14,11 +16,15 @@ What is MI355X-specific: the attention is this package's ``MSDeformAttn`` (HIP k
 the FFN's two ``nn.Linear`` layers take the split-M MFMA weight-gradient kernel (``functions/linear_func.py``) — with
 N*S = 33 440 rows per rank at the training shape the weight gradient is the GEMM the vendor BLAS runs worst.
 """
+import copy
+
+import torch
 import torch.nn.functional as F
 from torch import nn
 
 from ..functions.layernorm_func import add_layer_norm
 from ..functions.linear_func import bracket_linear
+from ..utils.transformer_inputs import decoder_reference_points, encoder_reference_points
 from .ms_deform_attn import MSDeformAttn
 
 
@@ -37,11 +43,9 @@ def _get_activation_fn(activation):
 class DeformableTransformerEncoderLayer(nn.Module):
     def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_levels=4, n_heads=8, n_points=4):
         super().__init__()
-        # self attention
         self.self_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
         self.dropout1 = nn.Dropout(dropout)
         self.norm1 = nn.LayerNorm(d_model)
-        # ffn
         self.linear1 = nn.Linear(d_model, d_ffn)
         self.activation = _get_activation_fn(activation)
         self.dropout2 = nn.Dropout(dropout)
@@ -67,22 +71,19 @@ class DeformableTransformerEncoderLayer(nn.Module):
 class DeformableTransformerDecoderLayer(nn.Module):
     def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_levels=4, n_heads=8, n_points=4):
         super().__init__()
-        # cross attention
         self.cross_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
         self.dropout1 = nn.Dropout(dropout)
         self.norm1 = nn.LayerNorm(d_model)
-        # self attention
         self.self_attn = nn.MultiheadAttention(d_model, n_heads, dropout=dropout)
         self.dropout2 = nn.Dropout(dropout)
         self.norm2 = nn.LayerNorm(d_model)
-        # ffn
         self.linear1 = nn.Linear(d_model, d_ffn)
         self.activation = _get_activation_fn(activation)
         self.dropout3 = nn.Dropout(dropout)
         self.linear2 = nn.Linear(d_ffn, d_model)
         self.dropout4 = nn.Dropout(dropout)
         self.norm3 = nn.LayerNorm(d_model)
-        # parameter-free taps the reference keeps for forward hooks (:358-359)
+        # two parameter-free modules the reference's forward calls on the reference points / attention matrix (hook points)
         self.inter_rp = nn.ReLU()
         self.attn_matrix = nn.ReLU()
 
@@ -96,13 +97,97 @@ class DeformableTransformerDecoderLayer(nn.Module):
 
     def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, level_start_index, src_padding_mask=None):
         self.inter_rp(reference_points)
-        # self attention over the queries (sequence-first, as the reference feeds nn.MultiheadAttention)
+        # the queries attend to each other first (sequence-first, as the reference feeds nn.MultiheadAttention)
         q = k = self.with_pos_embed(tgt, query_pos)
         tgt2, attn_matrix = self.self_attn(q.transpose(0, 1), k.transpose(0, 1), tgt.transpose(0, 1))
         self.attn_matrix(attn_matrix)
         tgt = add_layer_norm(tgt, self.dropout2(tgt2.transpose(0, 1)), self.norm2)
-        # cross attention into the feature pyramid
+        # then sample the feature pyramid
         tgt2 = self.cross_attn(self.with_pos_embed(tgt, query_pos), reference_points, src, src_spatial_shapes,
                                level_start_index, src_padding_mask)
         tgt = add_layer_norm(tgt, self.dropout1(tgt2), self.norm1)
         return self.forward_ffn(tgt)
+
+
+def _get_clones(module, n):
+    """n independent deep copies (models/arctic_transformer.py:459-460): every layer of a stack starts from the same values."""
+    return nn.ModuleList(copy.deepcopy(module) for _ in range(n))
+
+
+def inverse_sigmoid(x, eps=1e-5):
+    """logit of x clamped to [0, 1], with both x and 1 - x floored at eps (util/misc.py:614-618)."""
+    x = x.clamp(min=0, max=1)
+    return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
+
+
+class DeformableTransformerEncoder(nn.Module):
+    """``num_layers`` copies of an encoder layer over the flattened pyramid (models/arctic_transformer.py:302-330).  The
+    reference points — every pixel centre of every level in every level's frame, ``:310-323`` — are built once and shared
+    by all layers."""
+
+    def __init__(self, encoder_layer, num_layers):
+        super().__init__()
+        self.layers = _get_clones(encoder_layer, num_layers)
+        self.num_layers = num_layers
+
+    @staticmethod
+    def get_reference_points(spatial_shapes, valid_ratios, device):
+        return encoder_reference_points(spatial_shapes, valid_ratios, device)
+
+    def forward(self, src, spatial_shapes, level_start_index, valid_ratios, pos=None, padding_mask=None):
+        reference_points = self.get_reference_points(spatial_shapes, valid_ratios, device=src.device)
+        output = src
+        for layer in self.layers:
+            output = layer(output, pos, reference_points, spatial_shapes, level_start_index, padding_mask)
+        return output
+
+
+class DeformableTransformerDecoder(nn.Module):
+    """``num_layers`` copies of a decoder layer (models/arctic_transformer.py:394-457).  Per layer the query reference
+    points (2 numbers, or the 21 ARCTIC keypoints = 42) are scaled into every level's valid frame (``:413-419``); when the
+    model has attached its per-layer heads (``cls_embed`` / ``key_embed`` / ``obj_key_embed``, set from outside as in the
+    reference) the points are refined after each layer and handed on detached (``:423-447``): queries classified as an
+    object move by ``obj_key_embed``, queries classified as a hand (classes ``hand_classes``) by ``key_embed``, everything
+    else (class 0) stays."""
+
+    hand_classes = (12, 13)                       # left / right hand in the ARCTIC label set (:435)
+
+    def __init__(self, decoder_layer, num_layers, return_intermediate=False):
+        super().__init__()
+        self.layers = _get_clones(decoder_layer, num_layers)
+        self.num_layers = num_layers
+        self.return_intermediate = return_intermediate
+        self.cls_embed = None
+        self.key_embed = None
+        self.obj_key_embed = None
+
+    def _refine(self, lid, output, reference_points):
+        classes = self.cls_embed[lid](output).argmax(dim=-1)
+        is_hand = torch.zeros_like(classes, dtype=torch.bool)
+        for c in self.hand_classes:
+            is_hand |= classes == c
+        is_obj = ~is_hand & (classes != 0)
+        delta_hand, delta_obj = self.key_embed[lid](output), self.obj_key_embed[lid](output)
+        unsig = inverse_sigmoid(reference_points)
+        unsig = torch.where(is_obj[..., None], unsig + delta_obj, unsig)
+        unsig = torch.where(is_hand[..., None], unsig + delta_hand, unsig)
+        return (unsig.sigmoid() * 2 - 1).detach()
+
+    def forward(self, tgt, reference_points, src, src_spatial_shapes, src_level_start_index, src_valid_ratios,
+                query_pos=None, src_padding_mask=None):
+        output = tgt
+        intermediate, intermediate_reference_points = [], []
+        for lid, layer in enumerate(self.layers):
+            if reference_points.shape[-1] not in (2, 42):
+                raise AssertionError("reference_points must have 2 or 42 coordinates per query")
+            reference_points_input = decoder_reference_points(reference_points, src_valid_ratios)
+            output = layer(output, query_pos, reference_points_input, src, src_spatial_shapes, src_level_start_index,
+                           src_padding_mask)
+            if self.cls_embed is not None:
+                reference_points = self._refine(lid, output, reference_points)
+            if self.return_intermediate:
+                intermediate.append(output)
+                intermediate_reference_points.append(reference_points)
+        if self.return_intermediate:
+            return torch.stack(intermediate), torch.stack(intermediate_reference_points)
+        return output, reference_points

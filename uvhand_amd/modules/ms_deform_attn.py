@@ -93,6 +93,11 @@ class MSDeformAttn(nn.Module):
         # extension is built: the same kernels queued without Python in between (the eager step is host-bound at decoder
         # sizes); False = the Python composition below
         self.cpp_node = True
+        # the one-node path keeps [sampling_offsets ; attention_weights] concatenated while the parameters' storage and
+        # in-place version counters are unchanged (_merged_projection_weights).  Writes through `.data` are invisible to
+        # those counters: code that updates parameters that way sets this to False (or calls _reset_parameters / assigns
+        # new Parameters, which drop the cache)
+        self.cache_merged_projection = True
         self.d_model = d_model
         self.n_levels = n_levels
         self.n_heads = n_heads
@@ -106,6 +111,7 @@ class MSDeformAttn(nn.Module):
         self._reset_parameters()
 
     def _reset_parameters(self):
+        self.__dict__.pop("_merged_cache", None)                 # the initialisers below write through .data
         # sampling offsets start as the n_heads unit directions of a regular polygon, scaled to the
         # unit square's border and by the point index 1..n_points; attention logits start at zero.
         nn.init.constant_(self.sampling_offsets.weight.data, 0.0)
@@ -156,11 +162,45 @@ class MSDeformAttn(nn.Module):
         if padding_mask is not None and not (padding_mask.dtype == torch.bool and padding_mask.is_cuda
                                              and padding_mask.shape == input_flatten.shape[:-1]):
             return None
-        N, Len_q, _ = query.shape
+        # the node indexes device memory with these sizes (msda_torch.cpp: check_module_args raises on a mismatch): anything
+        # unusual — broadcastable reference points, fewer shape rows than n_levels, replaced projection layers of another
+        # width — goes to the composition below, which raises the reference's errors or broadcasts like the reference
+        if query.dim() != 3 or input_flatten.dim() != 3:
+            return None
+        N, Len_q, C = query.shape
+        mlp = self.n_heads * self.n_levels * self.n_points
+        if not (C == self.d_model and input_flatten.shape[0] == N and input_flatten.shape[2] == C
+                and tuple(reference_points.shape[:3]) == (N, Len_q, self.n_levels)
+                and tuple(spatial_shapes.shape) == (self.n_levels, 2) and tuple(level_start_index.shape) == (self.n_levels,)
+                and spatial_shapes.dtype == torch.int64 and level_start_index.dtype == torch.int64
+                and tuple(self.sampling_offsets.weight.shape) == (2 * mlp, C)
+                and tuple(self.attention_weights.weight.shape) == (mlp, C)
+                and tuple(self.value_proj.weight.shape) == (C, C) and tuple(self.output_proj.weight.shape) == (C, C)):
+            return None
         if not _native.prologue_geometry_supported(N, input_flatten.shape[1], self.n_heads, self.d_model // self.n_heads,
                                                    self.n_levels, Len_q, self.n_points):
             return None
         return ext
+
+    def _merged_projection_weights(self):
+        """[sampling_offsets ; attention_weights] weight and bias as the one-node path's single GEMM reads them, kept while
+        the four parameters are unchanged (same storage, same in-place version counter): in evaluation, and for layers an
+        optimizer does not update (util/settings.py:447-515 lr groups), the two concatenations are not launched again.
+        (None, None) — the node concatenates itself — during stream capture (a cached tensor must not live in a graph's
+        private pool) and for tensors without a version counter (inference tensors)."""
+        ps = (self.sampling_offsets.weight, self.attention_weights.weight, self.sampling_offsets.bias, self.attention_weights.bias)
+        try:
+            key = tuple((p.data_ptr(), p._version) for p in ps)
+        except RuntimeError:                                     # inference tensors do not track versions
+            return None, None
+        if not self.cache_merged_projection or torch.cuda.is_current_stream_capturing():
+            return None, None
+        cache = self.__dict__.get("_merged_cache")
+        if cache is None or cache[0] != key:
+            with torch.no_grad():
+                cache = (key, torch.cat([ps[0], ps[1]], 0), torch.cat([ps[2], ps[3]], 0))
+            self.__dict__["_merged_cache"] = cache
+        return cache[1], cache[2]
 
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
                 input_padding_mask=None):
@@ -185,12 +225,13 @@ class MSDeformAttn(nn.Module):
             centre = reference_points if reference_points.shape[-1] == 2 else torch.stack(
                 [reference_points[..., 0::2].mean(-1), reference_points[..., 1::2].mean(-1)], -1)
             node = ext.module_forward_bf16 if self.bf16_storage else ext.module_forward
+            wm, bm = self._merged_projection_weights()
             return node(
                 query, centre, input_flatten, input_padding_mask, input_spatial_shapes, input_level_start_index,
                 self.sampling_offsets.weight, self.sampling_offsets.bias, self.attention_weights.weight,
                 self.attention_weights.bias, self.value_proj.weight, self.value_proj.bias, self.output_proj.weight,
                 self.output_proj.bias, self.n_heads, self.n_levels, self.n_points, self.im2col_step,
-                _native.deterministic_requested())
+                _native.deterministic_requested(), wm, bm)
 
         # the four projections are nn.Linear (same parameters, same forward GEMM as the reference);
         # bracket_linear only swaps the weight-gradient GEMM of their backward (functions/linear_func.py)
