@@ -146,6 +146,10 @@ int msda_backward_passes(int Lq, int P);
  * grad_sampling_loc / grad_attn_weight workgroups see one head each and leave the reference-point gradient per head in
  * the scratch; without scratch the call runs the kernels that need none). */
 #define MSDA_FLAG_PROLOGUE 2u
+/* the workspace of this backward call STARTS WITH the point table a msda_forward_ws_* / msda_forward_prologue_ws_* call of
+ * the same geometry filled from the same sampling locations / attention weights (below).  Ignored where the backward's plan
+ * reads no table (msda_forward_workspace_bytes() == 0 for the geometry, the deterministic flag) or the buffer is too small. */
+#define MSDA_FLAG_FORWARD_TABLE 4u
 unsigned long long msda_backward_workspace_bytes(int N, int S, int M, int D, int L, int Lq, int P, unsigned flags);
 int msda_backward_ws_f32(const float *grad_out, const float *value, const int64_t *spatial_shapes,
                          const int64_t *level_start, const float *sampling_loc, const float *attn_weight,
@@ -167,6 +171,29 @@ int msda_backward_ws_bf16_gv32(const uint16_t *grad_out, const uint16_t *value, 
                                int N, int S, int M, int D, int L, int Lq, int P,
                                float *grad_value, float *grad_sampling_loc, float *grad_attn_weight,
                                void *workspace, unsigned long long workspace_bytes, unsigned flags, msda_stream_t stream);
+
+/* ---- Forward that leaves the backward its point table (small problems, D = 32 family) -------------------------
+ * The reference's backward re-derives every sampling point's geometry from sampling_loc / attn_weight
+ * (ms_deform_im2col_cuda.cuh:340-371, inside every one of its 32 channel threads).  Here the FORWARD already computes it once
+ * per point; msda_forward_ws_* additionally writes it to `workspace` as a level-major table — 16 bytes per sampling point,
+ * entry ((b*M + m)*L + l) * Lq*P + q*P + p = {tap validity bits << 24 | pixel index of the top-left tap + W + 1, the two bilinear
+ * fractions, the attention weight} — which the backward of the same autograd node reads, coalesced, in place of its strided scan of
+ * sampling_loc / attn_weight (pass the same buffer as `workspace` with MSDA_FLAG_FORWARD_TABLE to msda_backward_ws_*; for the
+ * fused-prologue pair: msda_forward_prologue_ws_* and msda_backward_prologue_ws_f32 / _bf16_gv32).  Results are bit-identical
+ * with and without the table.  msda_forward_workspace_bytes(): the table's size for a geometry, 0 where the backward's plan
+ * reads none (only small problems do: every workgroup of the backward launch resident at once — the 300-query decoder shape;
+ * large problems keep their scans, a table would be tens of MB of extra traffic there); flags: MSDA_FLAG_PROLOGUE for the
+ * fused-prologue pair.  workspace NULL / too small / unaligned (16 bytes): exactly msda_forward_*.  The caller owns the buffer
+ * and keeps it, unmodified, with the tensors it saves for the backward. */
+unsigned long long msda_forward_workspace_bytes(int N, int S, int M, int D, int L, int Lq, int P, unsigned flags);
+int msda_forward_ws_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                        const float *sampling_loc, const float *attn_weight,
+                        int N, int S, int M, int D, int L, int Lq, int P,
+                        float *out, void *workspace, unsigned long long workspace_bytes, msda_stream_t stream);
+int msda_forward_ws_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                         const float *sampling_loc, const float *attn_weight,
+                         int N, int S, int M, int D, int L, int Lq, int P,
+                         uint16_t *out, void *workspace, unsigned long long workspace_bytes, msda_stream_t stream);
 
 /* ---- Fused module prologue (fp32, D = 32 family) ---------------------------------
  * The module computes  attn = softmax(logits) over the L*P points of a (query, head)  and
@@ -196,7 +223,13 @@ int msda_backward_prologue_f32(const float *grad_out, const float *value, const 
                                int N, int S, int M, int D, int L, int Lq, int P, long long ld_grad_offsets,
                                long long ld_grad_logits, float *grad_value, float *grad_sampling_offsets,
                                float *grad_attn_logits, float *grad_reference_points, msda_stream_t stream);
-/* same with flags / scratch (MSDA_FLAG_DETERMINISTIC, msda_backward_workspace_bytes) */
+/* msda_forward_prologue_f32 that also leaves the point table (msda_forward_workspace_bytes(..., MSDA_FLAG_PROLOGUE)) */
+int msda_forward_prologue_ws_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                                 const float *reference_points, const float *sampling_offsets, const float *attn_logits,
+                                 int N, int S, int M, int D, int L, int Lq, int P, long long ld_offsets, long long ld_logits,
+                                 float *out, float *sampling_loc_out, float *attn_weight_out, void *workspace,
+                                 unsigned long long workspace_bytes, msda_stream_t stream);
+/* same with flags / scratch (MSDA_FLAG_DETERMINISTIC, MSDA_FLAG_FORWARD_TABLE, msda_backward_workspace_bytes) */
 int msda_backward_prologue_ws_f32(const float *grad_out, const float *value, const int64_t *spatial_shapes,
                                   const int64_t *level_start, const float *sampling_loc, const float *attn_weight,
                                   int N, int S, int M, int D, int L, int Lq, int P, long long ld_grad_offsets,
@@ -211,6 +244,11 @@ int msda_forward_prologue_bf16(const uint16_t *value, const int64_t *spatial_sha
                                const float *reference_points, const float *sampling_offsets, const float *attn_logits,
                                int N, int S, int M, int D, int L, int Lq, int P, long long ld_offsets, long long ld_logits,
                                uint16_t *out, float *sampling_loc_out, float *attn_weight_out, msda_stream_t stream);
+int msda_forward_prologue_ws_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                                  const float *reference_points, const float *sampling_offsets, const float *attn_logits,
+                                  int N, int S, int M, int D, int L, int Lq, int P, long long ld_offsets, long long ld_logits,
+                                  uint16_t *out, float *sampling_loc_out, float *attn_weight_out, void *workspace,
+                                  unsigned long long workspace_bytes, msda_stream_t stream);
 int msda_backward_prologue_bf16_gv32(const uint16_t *grad_out, const uint16_t *value, const int64_t *spatial_shapes,
                                      const int64_t *level_start, const float *sampling_loc, const float *attn_weight,
                                      int N, int S, int M, int D, int L, int Lq, int P, long long ld_grad_offsets,
@@ -300,7 +338,7 @@ const char *msda_last_error(void);
 /* Library/ABI version (major*100 + minor) and the kernel family a geometry maps to.  MSDA_ABI_VERSION is what a binding
  * compiled against THIS header expects msda_version() to return at run time (uvhand_amd/_ext.py compares the two);
  * it changes whenever a declaration in this file does. */
-#define MSDA_ABI_VERSION 114
+#define MSDA_ABI_VERSION 115
 int msda_version(void);
 int msda_path_for(int elem_bytes, int M, int D, int L, int P);
 
@@ -313,6 +351,15 @@ int msda_path_for(int elem_bytes, int M, int D, int L, int P);
  * models/ops/src/cuda/ms_deform_im2col_cuda.cuh:971-1320. */
 int msda_describe_plan(int row_bytes, int grad_value_bytes, int N, int S, int M, int D, int L, int Lq, int P, unsigned flags,
                        int has_workspace, char *buf, int buf_len);
+
+/* Measurement helper (bench.py `roofline.secondary`): gathers pseudo-random rows of `table` (row_bytes 128 = fp32 rows as 8 lanes
+ * x 16 B, or 64 = bf16 rows as 8 lanes x 8 B; the largest power-of-two row count that fits table_bytes) with the access
+ * pattern of the sampling kernels — independent 8-lane row requests, sixteen in flight per lane — and nothing else:
+ * *rows_gathered / elapsed time is the row-request rate the vector memory path of this box delivers on a table of that size,
+ * the practical ceiling of a gather kernel on cache-resident data.  `sink`: one float the kernel never writes for a finite
+ * table.  `blocks` x 256 threads, `iters` x 16 rows per 8-lane group.  No reference counterpart; no product path calls it. */
+int msda_probe_row_gather(const void *table, unsigned long long table_bytes, int row_bytes, int blocks, int iters, float *sink,
+                          unsigned long long *rows_gathered, msda_stream_t stream);
 
 /* Test hook: force the kernel family for the CALLING THREAD's subsequent calls (-1 = automatic, default; MSDA_PATH_GENERIC).
  * Thread-local, so no caller can change the kernels under another thread's launch; not meant for production callers. */

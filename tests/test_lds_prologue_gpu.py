@@ -143,10 +143,22 @@ def test_prologue_lds_stage_matches_fp64_composition(name):
     out_ref = MSDeformAttnFunction.apply(vd, sh, lsi, loc, attn, 64)
     out_ref.backward(go.double())
     assert rel_err(out.detach().cpu().numpy(), out_ref.detach().cpu().numpy()) < 2e-5
+    # A location formed in fp32 differs from the fp64 one by up to 1e-5 px; a point that close to a pixel centre sits in
+    # another bilinear cell in the two evaluations and its LOCATION gradient jumps (millions of points here: a few dozen
+    # do).  Those points — and the (query, level) cells of the reference-point gradient that contain one — are left out;
+    # value and logit gradients are continuous there and are compared everywhere.  Gradients: 1e-4 of max.
+    pix = loc.detach() * wh[None, None, None, :, None, :] - 0.5
+    near = ((pix - pix.round()).abs() < 2e-5).any(-1)                     # [N, Lq, M, L, P]
+    assert near.float().mean().item() < 1e-3
+    keep_pt = (~near).cpu().numpy()
+    keep_cell = (~near.any(dim=4).any(dim=2)).cpu().numpy()               # [N, Lq, L]
     for nm, g32, t64 in zip(("value", "ref", "offsets", "logits"), (value.grad, ref.grad, off.grad, logits.grad), (vd, rd, od, ld)):
-        e = rel_err(g32.cpu().numpy(), t64.grad.cpu().numpy())
-        # gradients 1e-4 of max: a location formed in fp32 differs from the fp64 one by up to 1e-5 px, and a point that
-        # sits that close to a pixel centre flips its bilinear cell
+        a, b = g32.cpu().numpy(), t64.grad.cpu().numpy()
+        if nm == "ref":
+            a, b = a[keep_cell], b[keep_cell]
+        elif nm == "offsets":
+            a, b = a[keep_pt], b[keep_pt]
+        e = rel_err(a, b)
         assert e < 1e-4, (nm, e)
 
 

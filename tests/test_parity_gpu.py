@@ -671,3 +671,73 @@ def test_beyond_int32_element_offsets_uses_the_generic_kernels(native):
     assert torch.all(gv[0, y * W + x] == 2.0) and gv.sum().item() == 2.0 * M * D
     del value, out, gv
     torch.cuda.empty_cache()
+
+
+# ---------------------------------------------------------------------------------------------
+# the forward's point table (msda_forward_ws_* / MSDA_FLAG_FORWARD_TABLE): small problems only
+# ---------------------------------------------------------------------------------------------
+SMALL_TABLE_CASES = {
+    "cfg2_decoder": (2, [(48, 48), (24, 24), (12, 12), (6, 6)], 8, 32, 300, 4),
+    "model_small":  ORACLE_CASES["model_small"],
+    "ragged_items": ORACLE_CASES["ragged_items"],           # items % 8 != 0, M = 5: the table's q / m split by division
+    "one_point":    ORACLE_CASES["one_point"],
+    "few_queries":  ORACLE_CASES["few_queries"],            # more rows than record slots per workgroup: the general body
+    "flat_levels":  ORACLE_CASES["flat_levels"],
+    "Lq_384":       (1, [(20, 20), (10, 10)], 8, 32, 384, 4),   # the pair's grad_out rows just fit the LDS stage (<= 399)
+    "Lq_400_p2":    (1, [(20, 20), (10, 10)], 8, 32, 400, 2),   # ... and just do not: rows gathered from global memory
+}
+
+
+@pytest.mark.parametrize("name", list(SMALL_TABLE_CASES))
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_backward_from_the_forward_table_equals_backward_from_a_scan(native, oracle, name, dtype):
+    """The forward of a small problem can leave its per-point table for the backward (include/msda.h: msda_forward_ws_*); role B
+    then reads 16-byte entries instead of re-deriving them from sampling_loc / attn_weight.  Same records either way:
+    grad_sampling_loc / grad_attn_weight bit-identical, grad_value equal up to the order of a row's sum; both against the
+    oracle.  Geometries whose backward reads no table report a size of 0 and get None."""
+    z = make_case(11, *SMALL_TABLE_CASES[name])
+    bf16 = dtype == "bf16"
+    if bf16:
+        z["value"], z["grad_out"] = _bf16_round(z["value"]), _bf16_round(z["grad_out"])
+    rows = torch.bfloat16 if bf16 else torch.float32
+    v, go = dev(z["value"]).to(rows), dev(z["grad_out"]).to(rows)
+    s, i, l, a = dev(z["shapes"]), dev(z["level_start"]), dev(z["loc"]), dev(z["attn"])
+    N, S, M, D = z["value"].shape
+    Lq, L, P = z["loc"].shape[1], z["loc"].shape[3], z["loc"].shape[4]
+    plan = native.describe_plan(N, S, M, D, L, Lq, P, row_bytes=2 if bf16 else 4)
+    out_plain = native.ms_deform_attn_forward(v, s, i, l, a, 64)
+    out, table = native.ms_deform_attn_forward(v, s, i, l, a, 64, with_table=True)
+    assert torch.equal(out, out_plain)
+    assert (table is not None) == ("fixed" in plan), plan
+    base = native.ms_deform_attn_backward(v, s, i, l, a, go, 64)
+    if table is not None:
+        assert table.numel() == N * M * L * Lq * P * 16
+        got = native.ms_deform_attn_backward(v, s, i, l, a, go, 64, table=table)
+        assert torch.equal(got[1], base[1]) and torch.equal(got[2], base[2])
+        assert rel_err(got[0].float().cpu().numpy(), base[0].float().cpu().numpy()) < (4e-3 if bf16 else 1e-6)
+    else:
+        got = base
+    r_gv, r_gl, r_ga = oracle.backward(z["grad_out"], z["value"], z["shapes"], z["level_start"], z["loc"], z["attn"])
+    assert rel_err(got[0].float().cpu().numpy(), r_gv) < (4e-3 if bf16 else 2e-5)
+    assert rel_err(got[2].cpu().numpy(), r_ga) < 2e-5
+    keep = ~near_boundary_mask(z, tol=1e-5)
+    assert rel_err(got[1].cpu().numpy()[keep], r_gl[keep]) < 2e-5
+
+
+def test_forward_table_of_a_pile_up_takes_the_general_body(native, oracle):
+    """Taps piled on a few pixels overflow the small body's fixed-capacity record slots: the workgroup starts over in the
+    general single-pass body — with the table in hand as well as without."""
+    z = make_case(12, 2, [(12, 12), (6, 6)], 8, 32, 300, 4)
+    z["loc"][..., 0] = 0.31 + 0.02 * z["loc"][..., 0]                     # every point within one or two pixels
+    z["loc"][..., 1] = 0.62 + 0.02 * z["loc"][..., 1]
+    v, go = dev(z["value"]), dev(z["grad_out"])
+    s, i, l, a = dev(z["shapes"]), dev(z["level_start"]), dev(z["loc"]), dev(z["attn"])
+    out, table = native.ms_deform_attn_forward(v, s, i, l, a, 64, with_table=True)
+    assert table is not None
+    got = native.ms_deform_attn_backward(v, s, i, l, a, go, 64, table=table)
+    base = native.ms_deform_attn_backward(v, s, i, l, a, go, 64)
+    r_gv, r_gl, r_ga = oracle.backward(z["grad_out"], z["value"], z["shapes"], z["level_start"], z["loc"], z["attn"])
+    for g in (got, base):
+        assert rel_err(g[0].cpu().numpy(), r_gv) < 2e-5
+        assert rel_err(g[2].cpu().numpy(), r_ga) < 2e-5
+    assert torch.equal(got[1], base[1])

@@ -11,6 +11,7 @@
 #include "../../uvhand_amd/csrc/msda_gemm.hip"
 #include "../../uvhand_amd/csrc/msda_layernorm.hip"
 #include "../../uvhand_amd/csrc/msda_flatten.hip"
+#include "../../uvhand_amd/csrc/msda_probe.hip"
 
 #include <algorithm>
 #include <cstdio>
@@ -46,7 +47,12 @@ int main(int argc, char **argv)
     CK(hipMemcpy(ds, hs.data(), hs.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dl, hl.data(), hl.size() * 8, hipMemcpyHostToDevice));
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    auto fwd = [&] { return msda_forward_f32(v, ds, dl, loc, at, N, S, M, D, L, Lq, P, out, st); };
+    // KB_TABLE=1: the forward leaves its point table and the backward reads it (small problems; what the autograd nodes do)
+    const bool use_table = getenv("KB_TABLE") && atoi(getenv("KB_TABLE")) != 0;
+    void *tab = nullptr; unsigned long long tab_bytes = use_table ? msda_forward_workspace_bytes(N, S, M, D, L, Lq, P, 0) : 0;
+    if (tab_bytes) CK(hipMalloc(&tab, tab_bytes));
+    printf("forward table: %.2f MB\n", tab_bytes / 1e6);
+    auto fwd = [&] { return msda_forward_ws_f32(v, ds, dl, loc, at, N, S, M, D, L, Lq, P, out, tab, tab_bytes, st); };
     // KB_DET=1: the deterministic backward (per-wavefront counters; role B and role A as two launches)
     const bool det = getenv("KB_DET") && atoi(getenv("KB_DET")) != 0;
     void *ws = nullptr; unsigned long long ws_bytes = 0;
@@ -62,7 +68,18 @@ int main(int argc, char **argv)
     }
     auto bwd = [&] { return det ? msda_backward_ws_f32(go, v, ds, dl, loc, at, N, S, M, D, L, Lq, P, gv, gl, ga, ws, ws_bytes,
                                                        MSDA_FLAG_DETERMINISTIC, st)
-                                : msda_backward_ws_f32(go, v, ds, dl, loc, at, N, S, M, D, L, Lq, P, gv, gl, ga, ws, ws_bytes, 0, st); };
+                                : tab ? msda_backward_ws_f32(go, v, ds, dl, loc, at, N, S, M, D, L, Lq, P, gv, gl, ga, tab, tab_bytes, MSDA_FLAG_FORWARD_TABLE, st)
+                                      : msda_backward_ws_f32(go, v, ds, dl, loc, at, N, S, M, D, L, Lq, P, gv, gl, ga, ws, ws_bytes, 0, st); };
+    if (getenv("KB_SKIP_ROLE")) {                     // diagnostic: 1 = role B's workgroups exit at once, 2 = role A's (results are then incomplete)
+        const int sk = atoi(getenv("KB_SKIP_ROLE"));
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(msda::msda_skip_role), &sk, sizeof(sk)));
+        printf("skipping role %s\n", sk == 1 ? "B" : sk == 2 ? "A" : "-");
+    }
+    if (getenv("KB_DIAG")) {                          // timing-only switches of the stamped build (results are then wrong): see msda_diag
+        const int dg = atoi(getenv("KB_DIAG"));
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(msda::msda_diag), &dg, sizeof(dg)));
+        printf("diag flags %d\n", dg);
+    }
     for (int which = 0; which < 2; ++which) {
         for (int i = 0; i < 5; ++i) if ((which ? bwd() : fwd()) != 0) { printf("launch failed: %s\n", msda_last_error()); return 1; }
         CK(hipStreamSynchronize(st));

@@ -32,6 +32,8 @@ _SYMBOLS = (
     "msda_zero_masked_rows_f32", "msda_linear_forward_f32", "msda_linear_dgrad_f32",
     "msda_prologue_supported", "msda_forward_prologue_f32", "msda_backward_prologue_f32",
     "msda_last_error", "msda_version", "msda_path_for", "msda_force_path", "msda_describe_plan",
+    "msda_forward_workspace_bytes", "msda_forward_ws_f32", "msda_forward_ws_bf16", "msda_forward_prologue_ws_f32",
+    "msda_forward_prologue_ws_bf16", "msda_probe_row_gather",
 )
 
 
@@ -62,6 +64,8 @@ def load():
     lib.msda_add_layernorm_workspace_bytes.argtypes = [ctypes.c_longlong, ctypes.c_int]
     lib.msda_linear_wgrad_workspace_bytes.restype = ctypes.c_ulonglong
     lib.msda_linear_wgrad_workspace_bytes.argtypes = [ctypes.c_int] * 3
+    lib.msda_forward_workspace_bytes.restype = ctypes.c_ulonglong
+    lib.msda_forward_workspace_bytes.argtypes = [ctypes.c_int] * 7 + [ctypes.c_uint]
     lib.msda_describe_plan.restype = ctypes.c_int
     lib.msda_describe_plan.argtypes = [ctypes.c_int] * 9 + [ctypes.c_uint, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
     _lib = lib
@@ -171,6 +175,7 @@ _BWD_ARGTYPES = [_VP] * 6 + [_CI] * 7 + [_VP] * 4
 _BWD_WS_ARGTYPES = [_VP] * 6 + [_CI] * 7 + [_VP] * 4 + [ctypes.c_ulonglong, ctypes.c_uint, _VP]
 FLAG_DETERMINISTIC = 1                                # MSDA_FLAG_DETERMINISTIC (include/msda.h)
 FLAG_PROLOGUE = 2                                     # MSDA_FLAG_PROLOGUE
+FLAG_FORWARD_TABLE = 4                                # MSDA_FLAG_FORWARD_TABLE
 
 
 def deterministic_requested():
@@ -221,22 +226,43 @@ class _DeviceGuard:
         return False
 
 
-def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
-    """Replaces MSDA.ms_deform_attn_forward (vision.cpp:14). Returns out[N, Lq, M*D]."""
+_FWD_WS_ARGTYPES = [_VP] * 5 + [_CI] * 7 + [_VP, _VP, ctypes.c_ulonglong, _VP]
+
+
+def _forward_table(lib, N, S, M, D, L, Lq, P, device, prologue=False):
+    """The buffer a forward of this geometry can fill with its point table for the backward of the same autograd node
+    (msda_forward_workspace_bytes, include/msda.h); None where the backward's plan reads none (all but small problems)."""
+    nbytes = int(lib.msda_forward_workspace_bytes(N, S, M, D, L, Lq, P, FLAG_PROLOGUE if prologue else 0))
+    return torch.empty((nbytes,), dtype=torch.uint8, device=device) if nbytes else None
+
+
+def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step, with_table=None):
+    """Replaces MSDA.ms_deform_attn_forward (vision.cpp:14). Returns out[N, Lq, M*D].
+    with_table=True / False (the autograd Functions): returns (out, table) — with True the forward also leaves its per-point
+    table (msda_forward_ws_*; None where the geometry's backward reads none) to be handed to ms_deform_attn_backward."""
     lib = _lib or load()
     _check_inputs((("value", value), ("spatial_shapes", spatial_shapes),
                    ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
                    ("attn_weight", attn_weight)))
     N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step)
     suf = _compute_dtypes(value, sampling_loc, attn_weight)
+    table = None
     with _DeviceGuard(value.device), _ForcedPathScope(lib):
         out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
-        rc = _entry(lib, "msda_forward_" + suf, _FWD_ARGTYPES)(
-            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
-            attn_weight.data_ptr(), N, S, M, D, L, Lq, P, out.data_ptr(), _raw_stream(value.device))
+        if with_table and suf != "f64":
+            table = _forward_table(lib, N, S, M, D, L, Lq, P, value.device)
+        if table is not None:
+            rc = _entry(lib, "msda_forward_ws_" + suf, _FWD_WS_ARGTYPES)(
+                value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
+                attn_weight.data_ptr(), N, S, M, D, L, Lq, P, out.data_ptr(), table.data_ptr(), table.numel(),
+                _raw_stream(value.device))
+        else:
+            rc = _entry(lib, "msda_forward_" + suf, _FWD_ARGTYPES)(
+                value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
+                attn_weight.data_ptr(), N, S, M, D, L, Lq, P, out.data_ptr(), _raw_stream(value.device))
     if rc != 0:
         _raise(lib, rc, "ms_deform_attn_forward")
-    return out
+    return out if with_table is None else (out, table)
 
 
 def _backward_workspace(lib, N, S, M, D, L, Lq, P, device, flags=FLAG_DETERMINISTIC):
@@ -255,7 +281,7 @@ def backward_passes(Lq, P):
 
 
 def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output,
-                            im2col_step, fp32_grad_value=False, deterministic=None):
+                            im2col_step, fp32_grad_value=False, deterministic=None, table=None):
     """Replaces MSDA.ms_deform_attn_backward (vision.cpp:15).
     Returns (grad_value, grad_sampling_loc, grad_attn_weight).  fp32_grad_value (bf16 rows only): grad_value
     comes back in float32 (msda_backward_bf16_gv32, include/msda.h; the only bf16 backward outside D = 32).  deterministic (None = deterministic_requested()):
@@ -280,6 +306,8 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
         # most shapes); the deterministic flag reaches every kernel family and dtype
         flags = FLAG_DETERMINISTIC if det else 0
         ws, nbytes = _backward_workspace(lib, N, S, M, D, L, Lq, P, value.device, flags)
+        if table is not None and ws is None:                 # the forward's point table of this very call (with_table=True)
+            ws, nbytes, flags = table, table.numel(), flags | FLAG_FORWARD_TABLE
         rc = _entry(lib, "msda_backward_ws_" + suf + ("_gv32" if fp32_grad_value else ""), _BWD_WS_ARGTYPES)(
             grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
             sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P,
@@ -445,7 +473,7 @@ def _check_prologue_dtypes(spatial_shapes, level_start_index, **floats):
 
 
 def ms_deform_attn_forward_prologue(value, spatial_shapes, level_start_index, reference_points, sampling_offsets,
-                                    attn_logits, im2col_step):
+                                    attn_logits, im2col_step, with_table=None):
     """Fused-prologue forward (include/msda.h).  Returns (out, sampling_loc, attn_weight); the last two are
     what the reference's Python would have computed and are what the backward consumes.  `sampling_offsets`
     [N,Lq,M,L,P,2] and `attn_logits` [N,Lq,M,L*P] may be column blocks of one wider projection output."""
@@ -476,17 +504,20 @@ def ms_deform_attn_forward_prologue(value, spatial_shapes, level_start_index, re
         out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
         loc = torch.empty((N, Lq, M, L, P, 2), dtype=torch.float32, device=value.device)
         attn = torch.empty((N, Lq, M, L, P), dtype=torch.float32, device=value.device)
-        rc = _entry(lib, "msda_forward_prologue_" + ("bf16" if bf16 else "f32"), [_VP] * 6 + [_CI] * 7 + [_LL] * 2 + [_VP] * 4)(
+        table = _forward_table(lib, N, S, M, D, L, Lq, P, value.device, prologue=True) if with_table else None
+        rc = _entry(lib, "msda_forward_prologue_ws_" + ("bf16" if bf16 else "f32"),
+                    [_VP] * 6 + [_CI] * 7 + [_LL] * 2 + [_VP] * 4 + [ctypes.c_ulonglong, _VP])(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), reference_points.data_ptr(),
             sampling_offsets.data_ptr(), attn_logits.data_ptr(), N, S, M, D, L, Lq, P, ld_off, ld_log, out.data_ptr(),
-            loc.data_ptr(), attn.data_ptr(), _raw_stream(value.device))
+            loc.data_ptr(), attn.data_ptr(), table.data_ptr() if table is not None else None,
+            table.numel() if table is not None else 0, _raw_stream(value.device))
     if rc != 0:
         _raise(lib, rc, "ms_deform_attn_forward_prologue")
-    return out, loc, attn
+    return (out, loc, attn) if with_table is None else (out, loc, attn, table)
 
 
 def ms_deform_attn_backward_prologue(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output,
-                                     merged=False, deterministic=None, use_workspace=True):
+                                     merged=False, deterministic=None, use_workspace=True, table=None):
     """Returns (grad_value (float32, also for bf16 rows), grad_sampling_offsets, grad_attn_logits[N,Lq,M,L*P],
     grad_reference_points[N,Lq,L,2]).
     merged=True: the two raw gradients are the column blocks [0, 2*M*L*P) and [2*M*L*P, 3*M*L*P) of ONE
@@ -520,12 +551,15 @@ def ms_deform_attn_backward_prologue(value, spatial_shapes, level_start_index, s
         # use_workspace=False (tests): the call a caller without scratch makes — the library then runs the kernels that need none
         ws, nbytes = _backward_workspace(lib, N, S, M, D, L, Lq, P, value.device,
                                          FLAG_PROLOGUE | (FLAG_DETERMINISTIC if det else 0)) if use_workspace else (None, 0)
+        flags = FLAG_DETERMINISTIC if det else 0
+        if table is not None and ws is None:                 # the forward's point table (with_table=True of the forward)
+            ws, nbytes, flags = table, table.numel(), flags | FLAG_FORWARD_TABLE
         rc = _entry(lib, "msda_backward_prologue_bf16_gv32" if bf16 else "msda_backward_prologue_ws_f32",
                     [_VP] * 6 + [_CI] * 7 + [_LL] * 2 + [_VP] * 5 + [ctypes.c_ulonglong, ctypes.c_uint, _VP])(
             grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
             sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P, ld_off, ld_log, gv.data_ptr(),
             goff.data_ptr(), glog.data_ptr(), gref.data_ptr(), ws.data_ptr() if ws is not None else None, nbytes,
-            FLAG_DETERMINISTIC if det else 0, _raw_stream(value.device))
+            flags, _raw_stream(value.device))
     if rc != 0:
         _raise(lib, rc, "ms_deform_attn_backward_prologue")
     return (gv, goff, glog, gref, both) if merged else (gv, goff, glog, gref)
@@ -665,6 +699,30 @@ def describe_plan(N, S, M, D, L, Lq, P, row_bytes=4, grad_value_bytes=None, prol
         lib.msda_describe_plan(row_bytes, grad_value_bytes or row_bytes, N, S, M, D, L, Lq, P, flags, 1 if has_workspace else 0,
                                buf, len(buf))
     return buf.value.decode()
+
+
+def probe_row_gather(table_bytes, device, row_bytes=128, blocks=4096, iters=16, repeats=5):
+    """msda_probe_row_gather (include/msda.h): row requests per second the vector memory path of `device` serves on a table
+    of `table_bytes` bytes with the sampling kernels' access pattern (measurement helper for bench.py)."""
+    lib = _lib or load()
+    table = torch.ones((max(int(table_bytes), row_bytes) // 4,), dtype=torch.float32, device=device)
+    sink = torch.zeros((1,), dtype=torch.float32, device=device)
+    rows = ctypes.c_ulonglong(0)
+    fn = _entry(lib, "msda_probe_row_gather", [_VP, ctypes.c_ulonglong, _CI, _CI, _CI, _VP, ctypes.POINTER(ctypes.c_ulonglong), _VP])
+    with _DeviceGuard(device):
+        stream = torch.cuda.current_stream(device)
+        call = lambda: fn(table.data_ptr(), table.numel() * 4, row_bytes, blocks, iters, sink.data_ptr(), ctypes.byref(rows),
+                          _raw_stream(device))
+        for _ in range(2):
+            if call() != 0:
+                _raise(lib, 1, "msda_probe_row_gather")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(repeats):
+            call()
+        e1.record(stream)
+        e1.synchronize()
+    return rows.value * repeats / (e0.elapsed_time(e1) * 1e-3)
 
 
 def force_path(path):

@@ -83,10 +83,20 @@ static bool use_d32(int N, int S, int M, int D, int L, int Lq, int P)
     return d32_supported(N, S, M, D, L, Lq, P);
 }
 
+// MSDA_FLAG_FORWARD_TABLE: `workspace` starts with the point table a msda_forward_ws_* call of the same geometry filled
+// (include/msda.h).  Used only where the backward's plan reads one and the caller's buffer holds all of it.
+static const void *table_of(const void *workspace, size_t ws_bytes, unsigned flags, int N, int S, int M, int D, int L, int Lq, int P,
+                            bool prologue)
+{
+    if (!(flags & MSDA_FLAG_FORWARD_TABLE) || !workspace || !aligned_to(workspace, 16)) return nullptr;
+    const size_t need = forward_table_bytes(N, S, M, D, L, Lq, P, prologue);
+    return (need > 0 && ws_bytes >= need) ? workspace : nullptr;
+}
+
 template <typename T>
 static int forward_impl(const T *value, const int64_t *shapes, const int64_t *level_start,
                         const T *loc, const T *attn, int N, int S, int M, int D, int L, int Lq, int P,
-                        T *out, hipStream_t stream, bool d32)
+                        T *out, hipStream_t stream, bool d32, void *table = nullptr)
 {
     const void *ptrs[] = {value, shapes, level_start, loc, attn, out};
     if (int rc = check_args(ptrs, 6, N, S, M, D, L, Lq, P)) return rc;
@@ -98,7 +108,7 @@ static int forward_impl(const T *value, const int64_t *shapes, const int64_t *le
     }
     if constexpr (sizeof(T) == 4) {
         if (d32 && aligned_to(value, 16) && aligned_to(out, 16) && aligned_to(loc, 8))
-            return launch_fwd_d32(value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, out, stream);
+            return launch_fwd_d32(value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, out, stream, table);
     }
     return launch_fwd_generic<T>(value, shapes, level_start, loc, attn, N, S, M, D, L, Lq, P, out, stream);
 }
@@ -128,7 +138,8 @@ static int backward_impl(const T *grad_out, const T *value, const int64_t *shape
             aligned_to(grad_loc, 8))
             return launch_bwd_d32(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P,
                                   grad_value, grad_loc, grad_attn, stream, workspace, ws_bytes,
-                                  (flags & MSDA_FLAG_DETERMINISTIC) != 0);
+                                  (flags & MSDA_FLAG_DETERMINISTIC) != 0,
+                                  table_of(workspace, ws_bytes, flags, N, S, M, D, L, Lq, P, false));
     }
     return launch_bwd_generic<T>(grad_out, value, shapes, level_start, loc, attn, N, S, M, D, L, Lq, P,
                                  grad_value, grad_loc, grad_attn, stream, (flags & MSDA_FLAG_DETERMINISTIC) != 0);
@@ -167,7 +178,8 @@ static int backward_bf16_impl(const uint16_t *grad_out, const uint16_t *value, c
                                                       "every other shape");
         return msda::launch_bwd_d32_bf16(grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M,
                                          L, Lq, P, grad_value, grad_sampling_loc, grad_attn_weight, (hipStream_t)stream,
-                                         workspace, ws_bytes, (flags & MSDA_FLAG_DETERMINISTIC) != 0);
+                                         workspace, ws_bytes, (flags & MSDA_FLAG_DETERMINISTIC) != 0,
+                                         msda::table_of(workspace, ws_bytes, flags, N, S, M, D, L, Lq, P, false));
     } else {
         if (!d32)                                                   // element-wise accesses: any D, any element offset
             return msda::launch_bwd_generic<float>(grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, N,
@@ -175,7 +187,8 @@ static int backward_bf16_impl(const uint16_t *grad_out, const uint16_t *value, c
                                                    (hipStream_t)stream, (flags & MSDA_FLAG_DETERMINISTIC) != 0);
         return msda::launch_bwd_d32_bf16_gv32(grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S,
                                               M, L, Lq, P, grad_value, grad_sampling_loc, grad_attn_weight,
-                                              (hipStream_t)stream, workspace, ws_bytes, (flags & MSDA_FLAG_DETERMINISTIC) != 0);
+                                              (hipStream_t)stream, workspace, ws_bytes, (flags & MSDA_FLAG_DETERMINISTIC) != 0,
+                                              msda::table_of(workspace, ws_bytes, flags, N, S, M, D, L, Lq, P, false));
     }
 }
 
@@ -220,9 +233,9 @@ int msda_backward_f64(const double *grad_out, const double *value, const int64_t
                                        grad_attn_weight, (hipStream_t)stream, false);
 }
 
-int msda_forward_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start,
-                      const float *sampling_loc, const float *attn_weight, int N, int S, int M, int D, int L,
-                      int Lq, int P, uint16_t *out, msda_stream_t stream)
+static int forward_bf16_impl(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                             const float *sampling_loc, const float *attn_weight, int N, int S, int M, int D, int L,
+                             int Lq, int P, uint16_t *out, msda_stream_t stream, void *table)
 {
     const void *ptrs[] = {value, spatial_shapes, level_start, sampling_loc, attn_weight, out};
     if (int rc = msda::check_args(ptrs, 6, N, S, M, D, L, Lq, P)) return rc;
@@ -237,7 +250,47 @@ int msda_forward_bf16(const uint16_t *value, const int64_t *spatial_shapes, cons
         return msda::launch_fwd_generic<float>(value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M, D, L, Lq,
                                                P, out, (hipStream_t)stream);
     return msda::launch_fwd_d32_bf16(value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M, L, Lq, P,
-                                     out, (hipStream_t)stream);
+                                     out, (hipStream_t)stream, table);
+}
+
+int msda_forward_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                      const float *sampling_loc, const float *attn_weight, int N, int S, int M, int D, int L,
+                      int Lq, int P, uint16_t *out, msda_stream_t stream)
+{
+    return forward_bf16_impl(value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M, D, L, Lq, P, out, stream, nullptr);
+}
+
+// ---- forward that leaves the point table for the backward of the same autograd node (include/msda.h) ----
+unsigned long long msda_forward_workspace_bytes(int N, int S, int M, int D, int L, int Lq, int P, unsigned flags)
+{
+    if (N <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Lq <= 0 || P <= 0) return 0;
+    if (msda::g_force_path == MSDA_PATH_GENERIC) return 0;
+    return (unsigned long long)msda::forward_table_bytes(N, S, M, D, L, Lq, P, (flags & MSDA_FLAG_PROLOGUE) != 0);
+}
+
+static void *fwd_table(void *workspace, unsigned long long workspace_bytes, int N, int S, int M, int D, int L, int Lq, int P, bool prologue)
+{
+    if (!workspace || !msda::aligned_to(workspace, 16) || N <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Lq <= 0 || P <= 0) return nullptr;
+    if (msda::g_force_path == MSDA_PATH_GENERIC) return nullptr;
+    const size_t need = msda::forward_table_bytes(N, S, M, D, L, Lq, P, prologue);
+    return (need > 0 && workspace_bytes >= need) ? workspace : nullptr;
+}
+
+int msda_forward_ws_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start, const float *sampling_loc,
+                        const float *attn_weight, int N, int S, int M, int D, int L, int Lq, int P, float *out, void *workspace,
+                        unsigned long long workspace_bytes, msda_stream_t stream)
+{
+    return msda::forward_impl<float>(value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M, D, L, Lq, P, out,
+                                     (hipStream_t)stream, msda::use_d32(N, S, M, D, L, Lq, P),
+                                     fwd_table(workspace, workspace_bytes, N, S, M, D, L, Lq, P, false));
+}
+
+int msda_forward_ws_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start, const float *sampling_loc,
+                         const float *attn_weight, int N, int S, int M, int D, int L, int Lq, int P, uint16_t *out, void *workspace,
+                         unsigned long long workspace_bytes, msda_stream_t stream)
+{
+    return forward_bf16_impl(value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M, D, L, Lq, P, out, stream,
+                             fwd_table(workspace, workspace_bytes, N, S, M, D, L, Lq, P, false));
 }
 
 int msda_backward_bf16(const uint16_t *grad_out, const uint16_t *value, const int64_t *spatial_shapes,
@@ -325,6 +378,16 @@ int msda_forward_prologue_f32(const float *value, const int64_t *spatial_shapes,
                               int N, int S, int M, int D, int L, int Lq, int P, long long ld_offsets, long long ld_logits,
                               float *out, float *sampling_loc_out, float *attn_weight_out, msda_stream_t stream)
 {
+    return msda_forward_prologue_ws_f32(value, spatial_shapes, level_start, reference_points, sampling_offsets, attn_logits, N, S, M,
+                                        D, L, Lq, P, ld_offsets, ld_logits, out, sampling_loc_out, attn_weight_out, nullptr, 0, stream);
+}
+
+int msda_forward_prologue_ws_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                                 const float *reference_points, const float *sampling_offsets, const float *attn_logits,
+                                 int N, int S, int M, int D, int L, int Lq, int P, long long ld_offsets, long long ld_logits,
+                                 float *out, float *sampling_loc_out, float *attn_weight_out, void *workspace,
+                                 unsigned long long workspace_bytes, msda_stream_t stream)
+{
     const void *ptrs[] = {value, spatial_shapes, level_start, reference_points, sampling_offsets, attn_logits, out,
                           sampling_loc_out, attn_weight_out};
     if (int rc = msda::check_args(ptrs, 9, N, S, M, D, L, Lq, P)) return rc;
@@ -337,7 +400,7 @@ int msda_forward_prologue_f32(const float *value, const int64_t *spatial_shapes,
     msda::begin_call();
     return msda::launch_fwd_prologue(value, spatial_shapes, level_start, reference_points, sampling_offsets, attn_logits, N,
                                      S, M, L, Lq, P, ld_offsets, ld_logits, out, sampling_loc_out, attn_weight_out,
-                                     (hipStream_t)stream);
+                                     (hipStream_t)stream, fwd_table(workspace, workspace_bytes, N, S, M, D, L, Lq, P, true));
 }
 
 int msda_backward_prologue_f32(const float *grad_out, const float *value, const int64_t *spatial_shapes,
@@ -372,13 +435,24 @@ int msda_backward_prologue_ws_f32(const float *grad_out, const float *value, con
     return msda::launch_bwd_prologue(grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M, L,
                                      Lq, P, grad_value, ld_grad_offsets, ld_grad_logits, grad_sampling_offsets,
                                      grad_attn_logits, grad_reference_points, (hipStream_t)stream, workspace,
-                                     (size_t)workspace_bytes, (flags & MSDA_FLAG_DETERMINISTIC) != 0);
+                                     (size_t)workspace_bytes, (flags & MSDA_FLAG_DETERMINISTIC) != 0,
+                                     msda::table_of(workspace, (size_t)workspace_bytes, flags, N, S, M, D, L, Lq, P, true));
 }
 
 int msda_forward_prologue_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start,
                                const float *reference_points, const float *sampling_offsets, const float *attn_logits,
                                int N, int S, int M, int D, int L, int Lq, int P, long long ld_offsets, long long ld_logits,
                                uint16_t *out, float *sampling_loc_out, float *attn_weight_out, msda_stream_t stream)
+{
+    return msda_forward_prologue_ws_bf16(value, spatial_shapes, level_start, reference_points, sampling_offsets, attn_logits, N, S, M,
+                                         D, L, Lq, P, ld_offsets, ld_logits, out, sampling_loc_out, attn_weight_out, nullptr, 0, stream);
+}
+
+int msda_forward_prologue_ws_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                                  const float *reference_points, const float *sampling_offsets, const float *attn_logits,
+                                  int N, int S, int M, int D, int L, int Lq, int P, long long ld_offsets, long long ld_logits,
+                                  uint16_t *out, float *sampling_loc_out, float *attn_weight_out, void *workspace,
+                                  unsigned long long workspace_bytes, msda_stream_t stream)
 {
     const void *ptrs[] = {value, spatial_shapes, level_start, reference_points, sampling_offsets, attn_logits, out,
                           sampling_loc_out, attn_weight_out};
@@ -392,7 +466,7 @@ int msda_forward_prologue_bf16(const uint16_t *value, const int64_t *spatial_sha
     msda::begin_call();
     return msda::launch_fwd_prologue_bf16(value, spatial_shapes, level_start, reference_points, sampling_offsets, attn_logits,
                                           N, S, M, L, Lq, P, ld_offsets, ld_logits, out, sampling_loc_out, attn_weight_out,
-                                          (hipStream_t)stream);
+                                          (hipStream_t)stream, fwd_table(workspace, workspace_bytes, N, S, M, D, L, Lq, P, true));
 }
 
 int msda_backward_prologue_bf16_gv32(const uint16_t *grad_out, const uint16_t *value, const int64_t *spatial_shapes,
@@ -416,7 +490,8 @@ int msda_backward_prologue_bf16_gv32(const uint16_t *grad_out, const uint16_t *v
     return msda::launch_bwd_prologue_bf16(grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M, L,
                                           Lq, P, grad_value, ld_grad_offsets, ld_grad_logits, grad_sampling_offsets,
                                           grad_attn_logits, grad_reference_points, (hipStream_t)stream, workspace,
-                                          (size_t)workspace_bytes, (flags & MSDA_FLAG_DETERMINISTIC) != 0);
+                                          (size_t)workspace_bytes, (flags & MSDA_FLAG_DETERMINISTIC) != 0,
+                                          msda::table_of(workspace, (size_t)workspace_bytes, flags, N, S, M, D, L, Lq, P, true));
 }
 
 unsigned long long msda_linear_wgrad_workspace_bytes(int M, int N, int K)

@@ -46,7 +46,13 @@ __device__ unsigned long long *msda_stamp_buf = nullptr;              // [blocks
              msda_stamp_buf[((size_t)(region) * 65536 + (blockIdx.x & 65535)) * 8 + (i)] =         \
                  __builtin_amdgcn_s_memrealtime(); } while (0)
 #define MSDA_STAMP(i) MSDA_STAMP_AT(0, i)
+__device__ int msda_skip_role = 0;                                    // diagnostic: 1 = role B's workgroups exit at once, 2 = role A's
+#define MSDA_SKIP_ROLE(is_b) do { if (msda_skip_role == ((is_b) ? 1 : 2)) return; } while (0)
+__device__ int msda_diag = 0;                                         // diagnostic bit flags (timing only: results are then wrong)
+#define MSDA_DIAG(bit) ((msda_diag >> (bit)) & 1)
 #else
+#define MSDA_SKIP_ROLE(is_b) do { } while (0)
+#define MSDA_DIAG(bit) 0
 #define MSDA_STAMP(i) do { } while (0)
 #define MSDA_STAMP_AT(region, i) do { } while (0)
 #endif
@@ -59,23 +65,30 @@ constexpr int kItemPad = 16;       // bytes: shifts consecutive items by one 16-
 
 struct alignas(16) LevelInfo { int H, W, start, pad; };
 
-// forward record: element offsets of the 4 taps (-1 = tap outside the map) and their
-// weights already multiplied by the attention weight.
+// forward record: byte offsets of the 4 taps' rows inside the workgroup's window of `value` (kBufOob = tap outside
+// the map: the buffer load returns zeros) and their weights already multiplied by the attention weight.
 struct alignas(16) FwdRec { int off[4]; float w[4]; };
 // backward record: same offsets, the two fractions and the attention weight.
 struct alignas(16) BwdRec { int off[4]; float lh, lw, a, pad; };
 
-__device__ __forceinline__ void tap_offsets(const PointGeom<float> &g, const LevelInfo &lv, int b,
-                                            int m, int S, int M, int off[4])
+// One sampling point as the FORWARD can leave it for the backward of the same autograd node (msda_forward_ctx_*), level-major:
+// entry ((b*M + m)*L + l) * Lq*P + q*P + p.  Role B of a small problem reads its level's entries coalesced instead of
+// re-deriving them from a strided scan of sampling_loc / attn_weight (msda_d32_value.h: bwd_value_small_body).
+struct alignas(16) PointEntry { int cell; float lh, lw, a; };   // cell: tap validity bits << 24 | (h0 * W + w0 + W + 1); 0 = no tap
+// The table entry of a point from its geometry (the same values the tap records are made of, so that the table and a scan
+// of sampling_loc / attn_weight give role B bit-identical records).
+__device__ __forceinline__ PointEntry entry_of(const PointGeom<float> &g, float a, int Wd, bool level_ok)
 {
-    const int row = M * kD;                                            // elements per pixel
-    const int base = ((b * S + lv.start) * M + m) * kD + (g.h0 * lv.W + g.w0) * row;
-    off[0] = g.ok00 ? base : -1;
-    off[1] = g.ok01 ? base + row : -1;
-    off[2] = g.ok10 ? base + lv.W * row : -1;
-    off[3] = g.ok11 ? base + lv.W * row + row : -1;
+    PointEntry e;
+    const int okb = (int)g.ok00 | ((int)g.ok01 << 1) | ((int)g.ok10 << 2) | ((int)g.ok11 << 3);
+    e.cell = (g.inside && level_ok) ? ((okb << 24) | (g.h0 * Wd + g.w0 + Wd + 1)) : 0;
+    e.lh = g.lh; e.lw = g.lw; e.a = a;
+    return e;
 }
-
+__device__ __forceinline__ PointEntry point_entry(float x, float y, float a, int H, int Wd, bool level_ok)
+{
+    return entry_of(point_geom<float>(x, y, H, Wd), a, Wd, level_ok);
+}
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
 // Storage type of the value-like tensors (value, out, grad_out, grad_value): float, or bfloat16
@@ -112,16 +125,56 @@ template <> struct Row<bf16_t> {
     }
 };
 
-// Row load of a tap that may be absent (off < 0).  The load itself is unconditional — an absent
-// tap reads row 0 of the tensor, which is always mapped — and the result is discarded by a select,
-// so the compiler can keep a whole batch of row loads in flight (per-tap branches made it wait
-// for the memory system between taps) and an Inf/NaN in an unsampled row can never leak in.
+// Row loads of `value` go through a BUFFER descriptor with a 32-bit byte offset: no 64-bit address pair per load, and a tap
+// that is absent (outside the map) carries an offset past the descriptor, for which the hardware returns zeros without
+// touching memory — so a gather lane spends ONE add per tap (its 16-byte column) and no compare / clamp / select, all sixteen
+// loads of a trip are in flight together, and an Inf / NaN in an unsampled row can never leak in.  (The first tiled kernels
+// loaded through 64-bit pointers with the result discarded by four selects per tap: ~10 vector instructions per tap of a
+// kernel that the SQ counters show to be bound by instruction issue — profiles/r04_notes.md.)
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+constexpr int kBufDword3 = 0x00020000;             // raw buffer, 32-bit data format (gfx90a / gfx94x / gfx950)
+constexpr unsigned kBufOob = 0x80000000u;          // >= any descriptor size used here (slices are checked < 2^31 bytes)
+
+template <typename VT> struct BufRow;
+template <> struct BufRow<float> {
+    static __device__ __forceinline__ float4 load(__amdgpu_buffer_rsrc_t rs, unsigned off)
+    {
+        const v4u_t u = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
+        return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+    }
+};
+template <> struct BufRow<bf16_t> {
+    static __device__ __forceinline__ float4 load(__amdgpu_buffer_rsrc_t rs, unsigned off)
+    {
+        const v2u_t u = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, 0);
+        return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                           __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+    }
+};
+
+// The tiled kernels' descriptor: the batch elements [b0, b1] a workgroup's items belong to (b0 = the first item's; a
+// workgroup rarely straddles a boundary).  d32_supported() admits only geometries whose widest such window stays below 2^31
+// bytes, so record offsets (relative to batch element b0) are plain 32-bit numbers.
 template <typename VT>
-__device__ __forceinline__ float4 ld4_tap(const VT *base, int off)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t value_window(const VT *value, int b0, int b1, int S, int M)
 {
-    const float4 v = Row<VT>::load(base + (off >= 0 ? off : 0));
-    const bool ok = off >= 0;
-    return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+    const long long slice = (long long)S * M * kD;                         // elements per batch element
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<VT *>(value) + (long long)b0 * slice, 0,
+                                             (int)((long long)(b1 - b0 + 1) * slice * (long long)sizeof(VT)), kBufDword3);
+}
+
+// byte offsets of a point's four tap rows inside that window (db = the item's batch element minus b0), kBufOob = absent
+template <typename VT>
+__device__ __forceinline__ void tap_offsets_b(const PointGeom<float> &g, const LevelInfo &lv, int db, int m, int S, int M, unsigned off[4])
+{
+    constexpr int RB = kD * (int)sizeof(VT);                               // bytes per row
+    const int row = M * RB;                                                // next pixel
+    const int base = ((db * S + lv.start) * M + m) * RB + (g.h0 * lv.W + g.w0) * row;
+    off[0] = g.ok00 ? (unsigned)base : kBufOob;
+    off[1] = g.ok01 ? (unsigned)(base + row) : kBufOob;
+    off[2] = g.ok10 ? (unsigned)(base + lv.W * row) : kBufOob;
+    off[3] = g.ok11 ? (unsigned)(base + lv.W * row + row) : kBufOob;
 }
 __device__ __forceinline__ void fma4(float4 &acc, float w, const float4 &v)
 {
@@ -212,7 +265,7 @@ __global__ __launch_bounds__(kBlock) void fwd_d32_kernel(
     const int64_t *__restrict__ level_start, const float *__restrict__ loc,
     const float *__restrict__ attn, int S, int M, int L, int Lq, int P, int items, int p_shift,
     int lp_shift, int m_shift, VT *__restrict__ out, const PrologueIn pro = PrologueIn{nullptr, nullptr, nullptr, 0, 0},
-    int xcd = 0)
+    int xcd = 0, PointEntry *__restrict__ table = nullptr)
 {
     constexpr int IPW = 32 / SPLIT;                       // items per workgroup
     constexpr int OPW = 4 / SPLIT;                        // octets per workgroup
@@ -233,7 +286,7 @@ __global__ __launch_bounds__(kBlock) void fwd_d32_kernel(
         const int il = fdiv(idx, LP, lp_shift), pt = idx - il * LP;
         const int item = item0 + il;
         FwdRec r;
-        r.off[0] = r.off[1] = r.off[2] = r.off[3] = -1;
+        r.off[0] = r.off[1] = r.off[2] = r.off[3] = (int)kBufOob;
         r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0.f;
         if (item < items) {
             const int l = fdiv(pt, P, p_shift);
@@ -254,11 +307,16 @@ __global__ __launch_bounds__(kBlock) void fwd_d32_kernel(
                 pro.attn_out[e] = a;
             }
             const PointGeom<float> g = point_geom<float>(xy.x, xy.y, li.H, li.W);
-            if (g.inside && level_fits(shapes[2 * l], shapes[2 * l + 1], level_start[l], S)) {
-                tap_offsets(g, li, b, m, S, M, r.off);
+            const bool level_ok = level_fits(shapes[2 * l], shapes[2 * l + 1], level_start[l], S);
+            if (g.inside && level_ok) {
+                tap_offsets_b<VT>(g, li, b - b0, m, S, M, reinterpret_cast<unsigned *>(r.off));
                 const float hh = 1.f - g.lh, hw = 1.f - g.lw;
                 r.w[0] = hh * hw * a; r.w[1] = hh * g.lw * a;
                 r.w[2] = g.lh * hw * a; r.w[3] = g.lh * g.lw * a;
+            }
+            if (table) {                                     // (uniform) the point, level-major, for the backward of this node
+                const int q = fdiv(r0 + il - (b - b0) * LqM, M, m_shift);
+                table[(((long long)b * M + m) * L + l) * ((long long)Lq * P) + q * P + (pt - l * P)] = entry_of(g, a, li.W, level_ok);
             }
         }
         *reinterpret_cast<FwdRec *>(recs + il * item_stride + pt * kRecBytes) = r;
@@ -270,25 +328,26 @@ __global__ __launch_bounds__(kBlock) void fwd_d32_kernel(
     const int wave = tid >> 6, lane = tid & 63, grp = lane >> 3, j = lane & 7;
     const int il = (wave / SPLIT) * 8 + grp;
     const unsigned char *rb = recs + il * item_stride;
-    const VT *vb = value + j * 4;
+    const __amdgpu_buffer_rsrc_t vbuf = value_window<VT>(value, b0, (min(item0 + IPW, items) - 1) / LqM, S, M);
+    const unsigned joff = (unsigned)(j * 4 * sizeof(VT));
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     // 4 points per trip: all records, then all 16 row loads, then the FMAs (one memory round trip
     // per trip instead of one per point).
     for (int p0 = wave % SPLIT; p0 < LP; p0 += 4 * SPLIT) {
-        int4 off[4]; float4 w[4]; float4 v[4][4];
+        uint4 off[4]; float4 w[4]; float4 v[4][4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int p = p0 + u * SPLIT;
-            off[u] = make_int4(-1, -1, -1, -1); w[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            off[u] = make_uint4(kBufOob, kBufOob, kBufOob, kBufOob); w[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (p < LP) {
-                off[u] = *reinterpret_cast<const int4 *>(rb + p * kRecBytes);
+                off[u] = *reinterpret_cast<const uint4 *>(rb + p * kRecBytes);
                 w[u] = *reinterpret_cast<const float4 *>(rb + p * kRecBytes + 16);
             }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            v[u][0] = ld4_tap(vb, off[u].x); v[u][1] = ld4_tap(vb, off[u].y);
-            v[u][2] = ld4_tap(vb, off[u].z); v[u][3] = ld4_tap(vb, off[u].w);
+            v[u][0] = BufRow<VT>::load(vbuf, off[u].x + joff); v[u][1] = BufRow<VT>::load(vbuf, off[u].y + joff);
+            v[u][2] = BufRow<VT>::load(vbuf, off[u].z + joff); v[u][3] = BufRow<VT>::load(vbuf, off[u].w + joff);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -354,7 +413,7 @@ __device__ __forceinline__ void bwd_query_body(
         const int il = fdiv(idx, LP, lp_shift), pt = idx - il * LP;
         const int item = item0 + il;
         BwdRec r;
-        r.off[0] = r.off[1] = r.off[2] = r.off[3] = -1;
+        r.off[0] = r.off[1] = r.off[2] = r.off[3] = (int)kBufOob;
         r.lh = r.lw = r.a = r.pad = 0.f;
         if (item < items) {
             const int l = fdiv(pt, P, p_shift);
@@ -366,7 +425,7 @@ __device__ __forceinline__ void bwd_query_body(
             if (g.inside && level_fits(shapes[2 * l], shapes[2 * l + 1], level_start[l], S)) {
                 int b, m;
                 item_bm(il, b0, r0, m0, LqM, M, m_shift, b, m);
-                tap_offsets(g, li, b, m, S, M, r.off);
+                tap_offsets_b<VT>(g, li, b - b0, m, S, M, reinterpret_cast<unsigned *>(r.off));
                 r.lh = g.lh; r.lw = g.lw; r.a = a;
             }
         }
@@ -376,7 +435,8 @@ __device__ __forceinline__ void bwd_query_body(
     const int wave = tid >> 6, lane = tid & 63, grp = lane >> 3, j = lane & 7;
     const int il = (wave / SPLIT) * 8 + grp;
     const unsigned char *rb = recs + il * item_stride;
-    const VT *vb = value + j * 4;
+    const __amdgpu_buffer_rsrc_t vbuf = value_window<VT>(value, b0, (min(item0 + IPW, items) - 1) / LqM, S, M);
+    const unsigned joff = (unsigned)(j * 4 * sizeof(VT));
     float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (item0 + il < items) g4 = Row<VT>::load(grad_out + (long long)(item0 + il) * kD + j * 4);
     __syncthreads();
@@ -385,20 +445,20 @@ __device__ __forceinline__ void bwd_query_body(
     // 4 points per trip: all records, then all 16 row loads, then the arithmetic — so that one
     // memory round trip covers the trip instead of one per point.
     for (int p0 = wave % SPLIT; p0 < LP; p0 += 4 * SPLIT) {
-        int4 off[4]; float4 f[4]; float4 v[4][4];
+        uint4 off[4]; float4 f[4]; float4 v[4][4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int p = p0 + u * SPLIT;
-            off[u] = make_int4(-1, -1, -1, -1); f[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            off[u] = make_uint4(kBufOob, kBufOob, kBufOob, kBufOob); f[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (p < LP) {
-                off[u] = *reinterpret_cast<const int4 *>(rb + p * kRecBytes);
+                off[u] = *reinterpret_cast<const uint4 *>(rb + p * kRecBytes);
                 f[u] = *reinterpret_cast<const float4 *>(rb + p * kRecBytes + 16);   // lh lw a -
             }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            v[u][0] = ld4_tap(vb, off[u].x); v[u][1] = ld4_tap(vb, off[u].y);
-            v[u][2] = ld4_tap(vb, off[u].z); v[u][3] = ld4_tap(vb, off[u].w);
+            v[u][0] = BufRow<VT>::load(vbuf, off[u].x + joff); v[u][1] = BufRow<VT>::load(vbuf, off[u].y + joff);
+            v[u][2] = BufRow<VT>::load(vbuf, off[u].z + joff); v[u][3] = BufRow<VT>::load(vbuf, off[u].w + joff);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -406,12 +466,13 @@ __device__ __forceinline__ void bwd_query_body(
             const float lh = f[u].x, lw = f[u].y, a = f[u].z, hh = 1.f - lh, hw = 1.f - lw;
             const float k1 = hh * hw, k2 = hh * lw, k3 = lh * hw, k4 = lh * lw;
             if constexpr (ATOMIC && sizeof(VT) == 4) {
-                float *gvb = reinterpret_cast<float *>(grad_value) + j * 4;
-                const int o4[4] = {off[u].x, off[u].y, off[u].z, off[u].w};
+                // (record offsets are bytes from the workgroup's first batch element, as for `value`)
+                unsigned char *gvb = reinterpret_cast<unsigned char *>(reinterpret_cast<float *>(grad_value) + (long long)b0 * S * M * kD + j * 4);
+                const unsigned o4[4] = {off[u].x, off[u].y, off[u].z, off[u].w};
                 const float k[4] = {k1, k2, k3, k4};
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
-                    if (o4[t] >= 0) { const float c = k[t] * a; float *d = gvb + o4[t];
+                    if (o4[t] != kBufOob) { const float c = k[t] * a; float *d = reinterpret_cast<float *>(gvb + o4[t]);
                         atomicAdd(d, c * g4.x); atomicAdd(d + 1, c * g4.y); atomicAdd(d + 2, c * g4.z); atomicAdd(d + 3, c * g4.w); }
             }
             const float d1 = dot4(g4, v[u][0]), d2 = dot4(g4, v[u][1]), d3 = dot4(g4, v[u][2]), d4 = dot4(g4, v[u][3]);
@@ -512,16 +573,21 @@ __global__ __launch_bounds__(kSBlock, 4) void bwd_fused_d32_kernel(
     const float *__restrict__ loc, const float *__restrict__ attn, int S, int M, int L, int Lq,
     int P, int items, int p_shift, int lp_shift, int m_shift, int tp_cap, int W, int nB,
     GT *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attn,
-    const PrologueOut pro = PrologueOut{nullptr, 0, 0}, int xcd = 0)
+    const PrologueOut pro = PrologueOut{nullptr, 0, 0}, int xcd = 0, const PointEntry *__restrict__ table = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int bid = (int)blockIdx.x;
+    MSDA_SKIP_ROLE(bid < nB);
     if (bid < nB) {
         if (xcd) bid = xcd_block(bid, nB);
         int pr, l, ti, Wl;
         value_block_to_range(bid, W, L, shapes, pr, l, ti, Wl, ACC != kAccWide);
-        bwd_value_body<ACC, kSinglePPT, VT, GT, FIXED, DET>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift,
-                                                          tp_cap, grad_value, ti, Wl, l, pr, smem);
+        if constexpr (FIXED)                          // small problems (plan_fused): every workgroup of the launch resident
+            bwd_value_small_body<VT, GT>(grad_out, shapes, level_start, loc, attn, table, S, M, L, Lq, P, p_shift, tp_cap, grad_value,
+                                         ti, Wl, l, pr, smem);
+        else
+            bwd_value_body<ACC, kSinglePPT, VT, GT, false, DET>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift,
+                                                                tp_cap, grad_value, ti, Wl, l, pr, smem);
     } else {
         // role A never touches grad_value unless it scatters with atomics (separate kernel, MSDA_BWD_MODE=atomic)
         bwd_query_body<SPLIT, false, kSBlock, VT, FUSED>(grad_out, value, shapes, level_start, loc, attn, S, M, L, Lq, P,
@@ -567,6 +633,13 @@ bool d32_supported(int N, int S, int M, int D, int L, int Lq, int P)
     if (items * kD >= (1LL << 31)) return false;                       // ... and of out / grad_out rows (q * M*32 in role B's gathers)
     if (items * L * P * 2 >= (1LL << 31) || items >= (1LL << 30)) return false;
     if ((long long)N * M > 65535 || S > (1 << 19)) return false;       // role-B workgroup count and S*W stay 32-bit
+    // the tiled kernels address `value` with 32-bit BYTE offsets inside the batch elements a workgroup's (at most 64) items
+    // span (value_window): that window — two elements unless a batch element has fewer than 64 items — stays below 2^31 bytes
+    // role B reads a (batch, head) pair's grad_out rows through a descriptor with 32-bit byte offsets q * M * 128 (24-bit multiplies)
+    if ((long long)Lq * M * kD * 4 >= (1LL << 31) || Lq >= (1 << 23) || (long long)M * kD * 4 >= (1 << 24)) return false;
+    if (Lq <= 0 || M <= 0) return true;                                 // (degenerate sizes never reach a kernel)
+    const long long span = min((long long)N, 2 + 63 / ((long long)Lq * M));
+    if (span * S * M * kD * 4 >= (1LL << 31)) return false;
     return true;
 }
 #endif
@@ -683,7 +756,7 @@ static int launch_query_lds(const LdsPlan &lp, const VT *grad_out, const VT *val
 template <typename VT>
 static int launch_fwd_d32_t(const VT *value, const int64_t *shapes, const int64_t *level_start,
                             const float *loc, const float *attn, int N, int S, int M, int L, int Lq, int P,
-                            VT *out, hipStream_t stream)
+                            VT *out, hipStream_t stream, PointEntry *table = nullptr)
 {
     const LdsPlan lp = plan_lds<VT>(N, S, M, L, Lq, P);
     if (lp.use)
@@ -698,7 +771,7 @@ static int launch_fwd_d32_t(const VT *value, const int64_t *shapes, const int64_
 #define MSDA_LAUNCH_FWD(SP)                                                                            \
     hipLaunchKernelGGL((fwd_d32_kernel<SP, VT>), grid, block, lds, stream, value, shapes, level_start, loc, attn, \
                        S, M, L, Lq, P, items, pow2_shift(P), pow2_shift(LP), pow2_shift(M), out,                  \
-                       PrologueIn{nullptr, nullptr, nullptr, 0, 0}, xcd)
+                       PrologueIn{nullptr, nullptr, nullptr, 0, 0}, xcd, table)
     const int xcd = xcd_remap();
     if (split == 4) MSDA_LAUNCH_FWD(4); else if (split == 2) MSDA_LAUNCH_FWD(2); else MSDA_LAUNCH_FWD(1);
 #undef MSDA_LAUNCH_FWD
@@ -790,6 +863,20 @@ static FusedPlan plan_fused(int items, int LP, int split, long long nB, int acc,
 static size_t prologue_heads_bytes(int N, int M, int L, int Lq) { return ((size_t)N * Lq * M * L * sizeof(float2) + 15) & ~(size_t)15; }
 
 #if MSDA_D32_HAS(0)
+// Bytes of the point table a forward of this geometry can leave for its backward (msda_forward_workspace_bytes): non-zero
+// exactly where the backward would take the small-problem role B (plan_fused.fixed: single pass, every workgroup resident,
+// no LDS stage) — the same plan functions the launchers run.  prologue: the fused-prologue entry points (whole queries per
+// role-A workgroup change the split).
+size_t forward_table_bytes(int N, int S, int M, int D, int L, int Lq, int P, bool prologue)
+{
+    if (!d32_supported(N, S, M, D, L, Lq, P) || (prologue && !prologue_supported(N, S, M, D, L, Lq, P))) return 0;
+    if (plan_lds<float>(N, S, M, L, Lq, P).use) return 0;
+    const ValuePlan pl = plan_value<float>(N, S, M, L, Lq, P, bwd_target_wgs(), false);
+    if (pl.acc != kAccNone || pl.ppt != kSinglePPT) return 0;
+    const FusedPlan fp = plan_fused(N * Lq * M, L * P, pick_split(N * Lq * M, L * P), (long long)pl.W * N * M * L, pl.acc, prologue ? M : 0, false);
+    return fp.fixed ? (size_t)N * M * L * Lq * P * sizeof(PointEntry) : 0;
+}
+
 size_t backward_workspace_bytes(int N, int S, int M, int D, int L, int Lq, int P, unsigned flags)
 {
     if (!d32_supported(N, S, M, D, L, Lq, P)) return 0;
@@ -806,7 +893,8 @@ template <typename VT, typename GT = VT>
 static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *shapes,
                             const int64_t *level_start, const float *loc, const float *attn, int N, int S,
                             int M, int L, int Lq, int P, GT *grad_value, float *grad_loc, float *grad_attn,
-                            hipStream_t stream, void *workspace = nullptr, size_t ws_bytes = 0, bool deterministic = false)
+                            hipStream_t stream, void *workspace = nullptr, size_t ws_bytes = 0, bool deterministic = false,
+                            const PointEntry *table = nullptr)
 {
     const int items = N * Lq * M, LP = L * P;
     const int item_stride = LP * kRecBytes + kItemPad;
@@ -864,12 +952,14 @@ static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *
             const long long nA = (items + ipw_f - 1) / ipw_f;
             if (nB + nA <= 0x7fffffffLL) {
                 const dim3 fgrid((unsigned)(nB + nA));
-                const size_t flds = pl.lds > lds_a ? pl.lds : lds_a;
+                size_t flds = pl.lds > lds_a ? pl.lds : lds_a;
+                if (fp.fixed) flds = max(flds, small_lds_bytes(pl.tp_cap));
 #define MSDA_LAUNCH_F_(SP, AC, FX, DT)                                                                 \
                 do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_fused_d32_kernel<SP, AC, VT, false, GT, FX, DT>), flds)) return rc; \
                 hipLaunchKernelGGL((bwd_fused_d32_kernel<SP, AC, VT, false, GT, FX, DT>), fgrid, dim3(kSBlock), flds, stream,  \
                                    grad_out, value, shapes, level_start, loc, attn, S, M, L, Lq, P, items, ps, lps, ms,  \
-                                   pl.tp_cap, pl.W, (int)nB, grad_value, grad_loc, grad_attn, PrologueOut{nullptr, 0, 0}, xcd); } while (0)
+                                   pl.tp_cap, pl.W, (int)nB, grad_value, grad_loc, grad_attn, PrologueOut{nullptr, 0, 0}, xcd,  \
+                                   (FX) ? table : nullptr); } while (0)
                 // (FX, the short sort, is never planned together with the deterministic flag)
 #define MSDA_LAUNCH_F(SP, AC, FX) do { if (deterministic && !(FX)) MSDA_LAUNCH_F_(SP, AC, false, true); else MSDA_LAUNCH_F_(SP, AC, FX, false); } while (0)
                 if (fp.fixed)                { if (fp.split == 4) MSDA_LAUNCH_F(4, kAccNone, true); else if (fp.split == 2) MSDA_LAUNCH_F(2, kAccNone, true); else MSDA_LAUNCH_F(1, kAccNone, true); }
@@ -946,7 +1036,7 @@ template <typename VT>
 static int launch_fwd_prologue_t(const VT *value, const int64_t *shapes, const int64_t *level_start, const float *ref,
                                  const float *offsets, const float *logits, int N, int S, int M, int L, int Lq, int P,
                                  long long ld_offsets, long long ld_logits, VT *out, float *loc_out, float *attn_out,
-                                 hipStream_t stream)
+                                 hipStream_t stream, PointEntry *table = nullptr)
 {
     const int items = N * Lq * M, LP = L * P;
     const int item_stride = LP * kRecBytes + kItemPad;
@@ -960,7 +1050,7 @@ static int launch_fwd_prologue_t(const VT *value, const int64_t *shapes, const i
     const int xcd = xcd_remap();
 #define MSDA_LAUNCH_FP(SP)                                                                             \
     hipLaunchKernelGGL((fwd_d32_kernel<SP, VT, true>), grid, block, lds, stream, value, shapes, level_start, offsets, \
-                       logits, S, M, L, Lq, P, items, pow2_shift(P), pow2_shift(LP), pow2_shift(M), out, pro, xcd)
+                       logits, S, M, L, Lq, P, items, pow2_shift(P), pow2_shift(LP), pow2_shift(M), out, pro, xcd, table)
     if (split == 4) MSDA_LAUNCH_FP(4); else if (split == 2) MSDA_LAUNCH_FP(2); else MSDA_LAUNCH_FP(1);
 #undef MSDA_LAUNCH_FP
     return check_launch("msda forward (d32, fused prologue)");
@@ -971,7 +1061,8 @@ template <typename VT>
 static int launch_bwd_prologue_t(const VT *grad_out, const VT *value, const int64_t *shapes, const int64_t *level_start,
                                  const float *loc, const float *attn, int N, int S, int M, int L, int Lq, int P, float *grad_value,
                                  long long ld_grad_offsets, long long ld_grad_logits, float *grad_offsets, float *grad_logits,
-                                 float *grad_ref, hipStream_t stream, void *workspace, size_t ws_bytes, bool deterministic)
+                                 float *grad_ref, hipStream_t stream, void *workspace, size_t ws_bytes, bool deterministic,
+                                 const PointEntry *table = nullptr)
 {
     const int items = N * Lq * M, LP = L * P;
     const int item_stride = LP * kRecBytes + kItemPad;
@@ -1012,13 +1103,14 @@ static int launch_bwd_prologue_t(const VT *grad_out, const VT *value, const int6
         return check_launch("msda backward (d32, reference-point gradient over heads)");
     }
     const dim3 fgrid((unsigned)(nB + nA));
-    const size_t flds = pl.lds > lds_a ? pl.lds : lds_a;
+    size_t flds = pl.lds > lds_a ? pl.lds : lds_a;
+    if (fp.fixed) flds = max(flds, small_lds_bytes(pl.tp_cap));
 #define MSDA_LAUNCH_BP(SP, AC, FX) do { if (deterministic && !(FX)) MSDA_LAUNCH_BP_(SP, AC, false, true); else MSDA_LAUNCH_BP_(SP, AC, FX, false); } while (0)
 #define MSDA_LAUNCH_BP_(SP, AC, FX, DT)                                                                \
     do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_fused_d32_kernel<SP, AC, VT, true, float, FX, DT>), flds)) return rc; \
     hipLaunchKernelGGL((bwd_fused_d32_kernel<SP, AC, VT, true, float, FX, DT>), fgrid, dim3(kSBlock), flds, stream, grad_out, \
                        value, shapes, level_start, loc, attn, S, M, L, Lq, P, items, ps, lps, ms, pl.tp_cap, pl.W, (int)nB,  \
-                       grad_value, grad_offsets, grad_logits, pro, xcd_remap()); } while (0)
+                       grad_value, grad_offsets, grad_logits, pro, xcd_remap(), (FX) ? table : nullptr); } while (0)
     if (fp.fixed)                { if (fp.split == 4) MSDA_LAUNCH_BP(4, kAccNone, true); else if (fp.split == 2) MSDA_LAUNCH_BP(2, kAccNone, true); else MSDA_LAUNCH_BP(1, kAccNone, true); }
     else if (pl.acc == kAccNone) { if (fp.split == 4) MSDA_LAUNCH_BP(4, kAccNone, false); else if (fp.split == 2) MSDA_LAUNCH_BP(2, kAccNone, false); else MSDA_LAUNCH_BP(1, kAccNone, false); }
     else if (pl.acc == kAccWide) { if (fp.split == 4) MSDA_LAUNCH_BP(4, kAccWide, false); else if (fp.split == 2) MSDA_LAUNCH_BP(2, kAccWide, false); else MSDA_LAUNCH_BP(1, kAccWide, false); }
@@ -1036,88 +1128,89 @@ static int launch_bwd_prologue_t(const VT *grad_out, const VT *value, const int6
 int launch_fwd_prologue(const float *value, const int64_t *shapes, const int64_t *level_start, const float *ref,
                         const float *offsets, const float *logits, int N, int S, int M, int L, int Lq, int P,
                         long long ld_offsets, long long ld_logits, float *out, float *loc_out, float *attn_out,
-                        hipStream_t stream)
+                        hipStream_t stream, void *table)
 {
     return launch_fwd_prologue_t<float>(value, shapes, level_start, ref, offsets, logits, N, S, M, L, Lq, P, ld_offsets, ld_logits,
-                                        out, loc_out, attn_out, stream);
+                                        out, loc_out, attn_out, stream, static_cast<PointEntry *>(table));
 }
 #endif
 #if MSDA_D32_HAS(1)
 int launch_fwd_prologue_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *level_start, const float *ref,
                              const float *offsets, const float *logits, int N, int S, int M, int L, int Lq, int P,
                              long long ld_offsets, long long ld_logits, uint16_t *out, float *loc_out, float *attn_out,
-                             hipStream_t stream)
+                             hipStream_t stream, void *table)
 {
     return launch_fwd_prologue_t<bf16_t>(value, shapes, level_start, ref, offsets, logits, N, S, M, L, Lq, P, ld_offsets, ld_logits,
-                                         out, loc_out, attn_out, stream);
+                                         out, loc_out, attn_out, stream, static_cast<PointEntry *>(table));
 }
 #endif
 #if MSDA_D32_HAS(0)
 int launch_bwd_prologue(const float *grad_out, const float *value, const int64_t *shapes, const int64_t *level_start,
                         const float *loc, const float *attn, int N, int S, int M, int L, int Lq, int P, float *grad_value,
                         long long ld_grad_offsets, long long ld_grad_logits, float *grad_offsets, float *grad_logits,
-                        float *grad_ref, hipStream_t stream, void *workspace, size_t ws_bytes, bool deterministic)
+                        float *grad_ref, hipStream_t stream, void *workspace, size_t ws_bytes, bool deterministic, const void *table)
 {
     return launch_bwd_prologue_t<float>(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, grad_value,
                                         ld_grad_offsets, ld_grad_logits, grad_offsets, grad_logits, grad_ref, stream, workspace,
-                                        ws_bytes, deterministic);
+                                        ws_bytes, deterministic, static_cast<const PointEntry *>(table));
 }
 #endif
 #if MSDA_D32_HAS(2)
 int launch_bwd_prologue_bf16(const uint16_t *grad_out, const uint16_t *value, const int64_t *shapes, const int64_t *level_start,
                              const float *loc, const float *attn, int N, int S, int M, int L, int Lq, int P, float *grad_value,
                              long long ld_grad_offsets, long long ld_grad_logits, float *grad_offsets, float *grad_logits,
-                             float *grad_ref, hipStream_t stream, void *workspace, size_t ws_bytes, bool deterministic)
+                             float *grad_ref, hipStream_t stream, void *workspace, size_t ws_bytes, bool deterministic,
+                             const void *table)
 {
     return launch_bwd_prologue_t<bf16_t>(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, grad_value,
                                          ld_grad_offsets, ld_grad_logits, grad_offsets, grad_logits, grad_ref, stream, workspace,
-                                         ws_bytes, deterministic);
+                                         ws_bytes, deterministic, static_cast<const PointEntry *>(table));
 }
 #endif
 
 #if MSDA_D32_HAS(0)
 int launch_fwd_d32(const float *value, const int64_t *shapes, const int64_t *level_start, const float *loc,
-                   const float *attn, int N, int S, int M, int L, int Lq, int P, float *out, hipStream_t stream)
+                   const float *attn, int N, int S, int M, int L, int Lq, int P, float *out, hipStream_t stream, void *table)
 {
-    return launch_fwd_d32_t<float>(value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, out, stream);
+    return launch_fwd_d32_t<float>(value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, out, stream, static_cast<PointEntry *>(table));
 }
 #endif
 #if MSDA_D32_HAS(0)
 int launch_bwd_d32(const float *grad_out, const float *value, const int64_t *shapes, const int64_t *level_start,
                    const float *loc, const float *attn, int N, int S, int M, int L, int Lq, int P,
                    float *grad_value, float *grad_loc, float *grad_attn, hipStream_t stream, void *workspace, size_t ws_bytes,
-                   bool deterministic)
+                   bool deterministic, const void *table)
 {
     return launch_bwd_d32_t<float>(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, grad_value,
-                                   grad_loc, grad_attn, stream, workspace, ws_bytes, deterministic);
+                                   grad_loc, grad_attn, stream, workspace, ws_bytes, deterministic, static_cast<const PointEntry *>(table));
 }
 #endif
 #if MSDA_D32_HAS(1)
 int launch_fwd_d32_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *level_start, const float *loc,
                         const float *attn, int N, int S, int M, int L, int Lq, int P, uint16_t *out,
-                        hipStream_t stream)
+                        hipStream_t stream, void *table)
 {
-    return launch_fwd_d32_t<bf16_t>(value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, out, stream);
+    return launch_fwd_d32_t<bf16_t>(value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, out, stream, static_cast<PointEntry *>(table));
 }
 #endif
 #if MSDA_D32_HAS(1)
 int launch_bwd_d32_bf16(const uint16_t *grad_out, const uint16_t *value, const int64_t *shapes,
                         const int64_t *level_start, const float *loc, const float *attn, int N, int S, int M, int L,
                         int Lq, int P, uint16_t *grad_value, float *grad_loc, float *grad_attn, hipStream_t stream,
-                        void *workspace, size_t ws_bytes, bool deterministic)
+                        void *workspace, size_t ws_bytes, bool deterministic, const void *table)
 {
     return launch_bwd_d32_t<bf16_t>(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, grad_value,
-                                    grad_loc, grad_attn, stream, workspace, ws_bytes, deterministic);
+                                    grad_loc, grad_attn, stream, workspace, ws_bytes, deterministic, static_cast<const PointEntry *>(table));
 }
 #endif
 #if MSDA_D32_HAS(2)
 int launch_bwd_d32_bf16_gv32(const uint16_t *grad_out, const uint16_t *value, const int64_t *shapes,
                              const int64_t *level_start, const float *loc, const float *attn, int N, int S, int M, int L,
                              int Lq, int P, float *grad_value, float *grad_loc, float *grad_attn, hipStream_t stream,
-                             void *workspace, size_t ws_bytes, bool deterministic)
+                             void *workspace, size_t ws_bytes, bool deterministic, const void *table)
 {
     return launch_bwd_d32_t<bf16_t, float>(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, grad_value,
-                                           grad_loc, grad_attn, stream, workspace, ws_bytes, deterministic);
+                                           grad_loc, grad_attn, stream, workspace, ws_bytes, deterministic, static_cast<const PointEntry *>(table));
 }
 #endif
 

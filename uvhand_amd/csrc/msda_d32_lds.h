@@ -95,29 +95,7 @@ __device__ __forceinline__ void lds_stage_rows(const VT *__restrict__ value, con
     }
 }
 
-// Buffer loads of `value` rows with a 32-bit byte offset through a descriptor of the batch element's slice: no 64-bit
-// address pair per load (32 VGPRs of a 16-load trip), and offsets past the descriptor return zeros without touching memory.
-typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
-typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
-constexpr int kBufDword3 = 0x00020000;             // raw buffer, 32-bit data format (gfx90a / gfx94x / gfx950)
-constexpr unsigned kBufOob = 0x80000000u;          // >= any descriptor size used here (slices are checked < 2^31 bytes)
-
-template <typename VT> struct BufRow;
-template <> struct BufRow<float> {
-    static __device__ __forceinline__ float4 load(__amdgpu_buffer_rsrc_t rs, unsigned off)
-    {
-        const v4u_t u = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
-        return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
-    }
-};
-template <> struct BufRow<bf16_t> {
-    static __device__ __forceinline__ float4 load(__amdgpu_buffer_rsrc_t rs, unsigned off)
-    {
-        const v2u_t u = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, 0);
-        return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
-                           __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
-    }
-};
+// (BufRow<>, kBufOob, kBufDword3: msda_d32.hip — the tiled kernels load through buffer descriptors too)
 
 // One sampling point -> the offsets half of its record and its geometry.  Branch-free on purpose (selects): the point
 // lanes of a wavefront belong to different levels and items.  `zero_off`: byte offset of the stage's zero row.

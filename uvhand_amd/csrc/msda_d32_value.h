@@ -163,14 +163,35 @@ __device__ __forceinline__ void add4(float4 &a, const float4 &b) { a.x += b.x; a
 // then NR*CH = 8 independent 128-B row loads, then the FMAs — one memory round trip per CH*SLOTS records of NR rows.
 // (Used by the fixed-capacity sort, the LDS-tile passes and the single-pass path's coarse levels; gather_balanced /
 // gather_split below walk contiguous segments instead.)
-template <int SLOTS, int ACC, typename VT, typename GT, int NR1 = 2>
-__device__ __forceinline__ void gather_rows(const VT *__restrict__ go_base, GT *__restrict__ gv_base,
+// Where a gather reads the grad_out row of query q of its (batch, head) pair from (lane j's 16 bytes of it): a BUFFER
+// descriptor over the pair's rows [(b, 0, m), (b, Lq-1, m)] with 32-bit byte offsets q * (M * row bytes) + j * 16 — one
+// 24-bit multiply-add per record instead of a 64-bit address pair and a slow 32-bit multiply, and a padding slot carries the
+// query index Lq, whose offset lies past the descriptor: the hardware returns zeros, no select.  (The SQ counters of round 4
+// put these kernels at ~1000 vector instructions per wavefront, most of them address arithmetic and selects.)
+template <typename VT> struct GoBuf {
+    __amdgpu_buffer_rsrc_t rs; unsigned joff; int stride_b, lq;
+    static constexpr bool kPadBySelect = false;
+    __device__ __forceinline__ int none() const { return lq; }
+    __device__ __forceinline__ float4 load(int q) const { return BufRow<VT>::load(rs, (unsigned)__mul24(q, stride_b) + joff); }
+    __device__ __forceinline__ float4 load_at(unsigned row_off) const { return BufRow<VT>::load(rs, row_off + joff); }
+};
+// (d32_supported() bounds Lq * M * 128 B below 2^31 and Lq below 2^23)
+template <typename VT>
+__device__ __forceinline__ GoBuf<VT> pair_rows(const VT *grad_out, long long item_base, int Lq, int M, int j)
+{
+    const long long bytes = (((long long)Lq - 1) * M + 1) * kD * (long long)sizeof(VT);
+    return GoBuf<VT>{__builtin_amdgcn_make_buffer_rsrc(const_cast<VT *>(grad_out) + item_base * kD, 0, (int)bytes, kBufDword3),
+                     (unsigned)(j * 4 * sizeof(VT)), M * kD * (int)sizeof(VT), Lq};
+}
+
+template <int SLOTS, int ACC, typename VT, typename GT, int NR1 = 2, typename GO = GoBuf<VT>>
+__device__ __forceinline__ void gather_rows(const GO go, GT *__restrict__ gv_base,
                                             const int *cnt, const int *start, const SRec *rec, float *tile,
-                                            int npx, int row_stride, bool first_pass, int cap_shift = -1,
+                                            int npx, int row_stride, bool first_pass, int cap = -1,
                                             const SOvf *ovf = nullptr, int novf = 0)
 {
-    // cap_shift >= 0: fixed-capacity segments (row d at d << cap_shift, at most 1 << cap_shift records there,
-    // the rest of a fuller row in ovf[0, novf)); cap_shift < 0: segments from the prefix sum (start[])
+    // cap > 0: fixed-capacity segments (row d at d * cap, at most cap records there, the rest of a fuller row in
+    // ovf[0, novf)); cap < 0: segments from the prefix sum (start[]).  (24-bit multiplies: full rate.)
     constexpr int DPW = 8 / SLOTS;
     // rows in flight per lane group x records of each per trip: 8 loads either way.  NR1 (rows in flight when ONE lane
     // group serves a row) is 4 on the fixed-capacity path: such rows hold a couple of records (cfg-2 decoder's 48x48
@@ -189,8 +210,8 @@ __device__ __forceinline__ void gather_rows(const VT *__restrict__ go_base, GT *
             const int d = d0 + r * RSTEP;
             const bool has = d < npx;
             full[r] = has ? cnt[d] : 0;
-            n[r] = cap_shift >= 0 ? min(full[r], 1 << cap_shift) : full[r];
-            rp[r] = rec + (!has ? 0 : cap_shift >= 0 ? d << cap_shift : start[d]);
+            n[r] = cap > 0 ? min(full[r], cap) : full[r];
+            rp[r] = rec + (!has ? 0 : cap > 0 ? __mul24(d, cap) : start[d]);
             acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
             nmax = max(nmax, n[r]);
         }
@@ -200,16 +221,19 @@ __device__ __forceinline__ void gather_rows(const VT *__restrict__ go_base, GT *
             for (int r = 0; r < NR; ++r)
 #pragma unroll
                 for (int u = 0; u < CH; ++u) {
-                    e[r][u].w = 0.f; e[r][u].q = -1;
+                    e[r][u].w = 0.f; e[r][u].q = go.none();
                     if (i0 + u * SLOTS < n[r]) e[r][u] = rp[r][i0 + u * SLOTS];
                 }
 #pragma unroll
             for (int r = 0; r < NR; ++r)
 #pragma unroll
                 for (int u = 0; u < CH; ++u) {
-                    const float4 t = Row<VT>::load(go_base + (long long)max(e[r][u].q, 0) * row_stride);
-                    const bool ok = e[r][u].q >= 0;
-                    g[r][u] = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
+                    const float4 t = MSDA_DIAG(2) ? make_float4(1.f, 1.f, 1.f, 1.f) : go.load(e[r][u].q);
+                    if (GO::kPadBySelect) {
+                        const bool ok = e[r][u].q >= 0;
+                        g[r][u] = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
+                    } else
+                        g[r][u] = t;
                 }
 #pragma unroll
             for (int r = 0; r < NR; ++r)
@@ -226,7 +250,7 @@ __device__ __forceinline__ void gather_rows(const VT *__restrict__ go_base, GT *
 #pragma unroll
                     for (int r = 0; r < NR; ++r)
                         if (o.row == d0 + r * RSTEP && d0 + r * RSTEP < npx)
-                            fma4(acc[r], o.w, Row<VT>::load(go_base + (long long)o.q * row_stride));
+                            fma4(acc[r], o.w, go.load(o.q));
                 }
             }
         }
@@ -258,20 +282,19 @@ __device__ __forceinline__ void gather_rows(const VT *__restrict__ go_base, GT *
 // records of the chunked / single-pass paths.  RecSoa (kAccWide): a float weight array and a 16-bit array of queries
 // relative to the chunk's first query — 6 bytes per record, so a third more records fit the same LDS and batch-heavy
 // shapes need fewer pixel ranges per level (cfg-4 encoder: 2 instead of 3, each range re-scans the level).
+// (`off`: the row's byte offset inside the pair's descriptor, GoBuf::load_at; stride_b = M * row bytes, 24-bit multiplies)
 struct RecAos {
-    const SRec *r; int stride;
-    __device__ __forceinline__ void get(int i, float &w, long long &off) const { const SRec e = r[i]; w = e.w; off = (long long)e.q * stride; }
+    const SRec *r; int stride_b;
+    __device__ __forceinline__ void get(int i, float &w, unsigned &off) const { const SRec e = r[i]; w = e.w; off = (unsigned)__mul24(e.q, stride_b); }
 };
 struct RecSoa {
-    const float *w; const uint16_t *q; int qbase, stride;
-    // 32-bit product on purpose (a 64-bit multiply per record would cost the gather an instruction pair per row load):
-    // (qbase + q) < Lq and stride = M*32, and d32_supported() admits only N*Lq*M*32 < 2^31.
-    __device__ __forceinline__ void get(int i, float &wt, long long &off) const { wt = w[i]; off = (long long)((qbase + (int)q[i]) * stride); }
+    const float *w; const uint16_t *q; int qbase, stride_b;
+    __device__ __forceinline__ void get(int i, float &wt, unsigned &off) const { wt = w[i]; off = (unsigned)__mul24(qbase + (int)q[i], stride_b); }
 };
 
 // ENDS: start[r] is the END of row r's segment (kAccWide's scatter cursor), else its beginning.
 template <typename VT, typename GT, bool ENDS, typename RV>
-__device__ __forceinline__ void gather_balanced(const VT *__restrict__ go_base, GT *__restrict__ gv_base,
+__device__ __forceinline__ void gather_balanced(const GoBuf<VT> go, GT *__restrict__ gv_base,
                                                 const int *cnt, const int *start, const RV rec, int *firsts, int npx,
                                                 int row_stride, int total, bool first_pass)
 {
@@ -310,19 +333,19 @@ __device__ __forceinline__ void gather_balanced(const VT *__restrict__ go_base, 
         next_end = r + 1 < r_stop ? endv[r + 1] : 0x7fffffff;
     };
     for (; i + CH <= i_stop; i += CH) {
-        float ew[CH]; long long eo[CH]; float4 gl[CH];
+        float ew[CH]; unsigned eo[CH]; float4 gl[CH];
 #pragma unroll
         for (int u = 0; u < CH; ++u) rec.get(i + u, ew[u], eo[u]);
 #pragma unroll
-        for (int u = 0; u < CH; ++u) gl[u] = Row<VT>::load(go_base + eo[u]);
+        for (int u = 0; u < CH; ++u) gl[u] = go.load_at(eo[u]);
 #pragma unroll
         for (int u = 0; u < CH; ++u) { while (i + u >= row_end) flush(); fma4(acc, ew[u], gl[u]); }
     }
     if (i < i_stop) {                                        // last, partial batch
-        float ew[CH]; long long eo[CH]; float4 gl[CH];
+        float ew[CH]; unsigned eo[CH]; float4 gl[CH];
 #pragma unroll
         for (int u = 0; u < CH; ++u)
-            if (i + u < i_stop) { rec.get(i + u, ew[u], eo[u]); gl[u] = Row<VT>::load(go_base + eo[u]); }
+            if (i + u < i_stop) { rec.get(i + u, ew[u], eo[u]); gl[u] = go.load_at(eo[u]); }
 #pragma unroll
         for (int u = 0; u < CH; ++u) if (i + u < i_stop) { while (i + u >= row_end) flush(); fma4(acc, ew[u], gl[u]); }
     }
@@ -338,7 +361,7 @@ __device__ __forceinline__ void gather_balanced(const VT *__restrict__ go_base, 
 // (five of eight busy, 8 slots x 4 loads in flight): gather of a workgroup of cfg-2 encoder's 6x6 level 20.2 -> 11.3 us,
 // cfg-4 encoder backward 301 -> 272 us (half its workgroups belong to coarse levels); profiles/r02_notes.md §10.
 template <typename VT, typename GT, bool ENDS, typename RV>
-__device__ __forceinline__ void gather_split(const VT *__restrict__ go_base, GT *__restrict__ gv_base, const int *cnt,
+__device__ __forceinline__ void gather_split(const GoBuf<VT> go, GT *__restrict__ gv_base, const int *cnt,
                                              const int *start, const RV rec, float4 *part, int npx, int row_stride,
                                              int total, bool first_pass)
 {
@@ -370,19 +393,19 @@ __device__ __forceinline__ void gather_split(const VT *__restrict__ go_base, GT 
         };
         int i = lo;
         for (; i + CH <= hi; i += CH) {
-            float ew[CH]; long long eo[CH]; float4 gl[CH];
+            float ew[CH]; unsigned eo[CH]; float4 gl[CH];
 #pragma unroll
             for (int u = 0; u < CH; ++u) rec.get(i + u, ew[u], eo[u]);
 #pragma unroll
-            for (int u = 0; u < CH; ++u) gl[u] = Row<VT>::load(go_base + eo[u]);
+            for (int u = 0; u < CH; ++u) gl[u] = go.load_at(eo[u]);
 #pragma unroll
             for (int u = 0; u < CH; ++u) { if (i + u >= row_end) close_row(); fma4(acc, ew[u], gl[u]); }
         }
         if (i < hi) {
-            float ew[CH]; long long eo[CH]; float4 gl[CH];
+            float ew[CH]; unsigned eo[CH]; float4 gl[CH];
 #pragma unroll
             for (int u = 0; u < CH; ++u)
-                if (i + u < hi) { rec.get(i + u, ew[u], eo[u]); gl[u] = Row<VT>::load(go_base + eo[u]); }
+                if (i + u < hi) { rec.get(i + u, ew[u], eo[u]); gl[u] = go.load_at(eo[u]); }
 #pragma unroll
             for (int u = 0; u < CH; ++u) if (i + u < hi) { if (i + u >= row_end) close_row(); fma4(acc, ew[u], gl[u]); }
         }
@@ -456,7 +479,7 @@ __device__ __forceinline__ void bwd_value_body(
     SOvf *ovf = reinterpret_cast<SOvf *>(rec + rec_cap);
     // fixed-capacity segments need a few slots per row (uniform; small maps with few queries go the prefix way)
     const int cap_shift = (FIXED && rec_cap >= 4 * npx) ? 31 - __clz(rec_cap / npx) : -1;
-    const VT *go_base = grad_out + item_base * kD + (lane & 7) * 4;
+    const GoBuf<VT> go = pair_rows<VT>(grad_out, item_base, Lq, M, lane & 7);
     GT *gv_base = grad_value + ((long long)(b * S + lstart + px0) * M + m) * kD + (lane & 7) * 4;
 
     // single-pass kernels (the host only picks them when NP <= NPC): a visible trip count of one lets the
@@ -526,10 +549,10 @@ __device__ __forceinline__ void bwd_value_body(
             if (novf <= kOvfCap) {
                 MSDA_STAMP(2); MSDA_STAMP(3); MSDA_STAMP(4);
                 const int mean2f = (2 * *total_p) / npx;
-                if (mean2f <= 8)       gather_rows<1, ACC, VT, GT, MSDA_GATHER_NR1>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first, cap_shift, ovf, novf);
-                else if (mean2f <= 16) gather_rows<2, ACC, VT, GT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first, cap_shift, ovf, novf);
-                else if (mean2f <= 32) gather_rows<4, ACC, VT, GT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first, cap_shift, ovf, novf);
-                else                   gather_rows<8, ACC, VT, GT>(go_base, gv_base, cnt, start, rec, tile, npx, row_stride, first, cap_shift, ovf, novf);
+                if (mean2f <= 8)       gather_rows<1, ACC, VT, GT, MSDA_GATHER_NR1>(go, gv_base, cnt, start, rec, tile, npx, row_stride, first, 1 << cap_shift, ovf, novf);
+                else if (mean2f <= 16) gather_rows<2, ACC, VT, GT>(go, gv_base, cnt, start, rec, tile, npx, row_stride, first, 1 << cap_shift, ovf, novf);
+                else if (mean2f <= 32) gather_rows<4, ACC, VT, GT>(go, gv_base, cnt, start, rec, tile, npx, row_stride, first, 1 << cap_shift, ovf, novf);
+                else                   gather_rows<8, ACC, VT, GT>(go, gv_base, cnt, start, rec, tile, npx, row_stride, first, 1 << cap_shift, ovf, novf);
                 if (ACC != kAccNone) __syncthreads();
                 MSDA_STAMP(5);
                 continue;
@@ -590,17 +613,17 @@ __device__ __forceinline__ void bwd_value_body(
         // ---- 4. gather; lanes per row chosen from the mean segment length (uniform) ----
         // rows of comparable length (the longest no more than one lane group's share): the balanced walk
         if (ACC != kAccTile && longest * 64 <= max(total, 1024)) {
-            gather_balanced<VT, GT, false>(go_base, gv_base, tot, start, RecAos{rec, row_stride}, reinterpret_cast<int *>(ovf), npx,
+            gather_balanced<VT, GT, false>(go, gv_base, tot, start, RecAos{rec, go.stride_b}, reinterpret_cast<int *>(ovf), npx,
                                            row_stride, total, ACC == kAccNone || first);
             if (ACC != kAccNone) __syncthreads();
             MSDA_STAMP(5);
             continue;
         }
         const int mean2 = (2 * total) / npx;                                  // 2 x mean records per row
-        if (mean2 <= 8)       gather_rows<1, ACC, VT, GT>(go_base, gv_base, tot, start, rec, tile, npx, row_stride, first);
-        else if (mean2 <= 16) gather_rows<2, ACC, VT, GT>(go_base, gv_base, tot, start, rec, tile, npx, row_stride, first);
-        else if (mean2 <= 32) gather_rows<4, ACC, VT, GT>(go_base, gv_base, tot, start, rec, tile, npx, row_stride, first);
-        else                  gather_rows<8, ACC, VT, GT>(go_base, gv_base, tot, start, rec, tile, npx, row_stride, first);
+        if (mean2 <= 8)       gather_rows<1, ACC, VT, GT>(go, gv_base, tot, start, rec, tile, npx, row_stride, first);
+        else if (mean2 <= 16) gather_rows<2, ACC, VT, GT>(go, gv_base, tot, start, rec, tile, npx, row_stride, first);
+        else if (mean2 <= 32) gather_rows<4, ACC, VT, GT>(go, gv_base, tot, start, rec, tile, npx, row_stride, first);
+        else                  gather_rows<8, ACC, VT, GT>(go, gv_base, tot, start, rec, tile, npx, row_stride, first);
         if (ACC != kAccNone) __syncthreads();                // next pass reuses the LDS arrays / re-reads rows
         MSDA_STAMP(5);
     }
@@ -615,6 +638,186 @@ __device__ __forceinline__ void bwd_value_body(
     }
 }
 
+
+// ---- small problems: every workgroup of the launch resident at once (plan_fused) -------------------------------------
+// The 300-query decoder shape: 406 workgroups on 256 CUs, ONE role-B workgroup per CU, every phase of it a latency chain, and
+// — by the SQ counters and in-kernel stamps of round 4 (profiles/r04_notes.md) — role B alone sets the launch's length.
+// bwd_value_small_body is role B for exactly that regime (one pass, Lq*P <= kSingleMaxPoints, not deterministic):
+//   * the points come from the level-major table the FORWARD of the same autograd node left in the caller's scratch
+//     (PointEntry, msda_forward_ws_*): 16 B per point, coalesced, geometry already done — instead of a strided scan of
+//     sampling_loc / attn_weight that touches one 128-B line per query for 32 useful bytes (without a table: that scan);
+//   * COMPACTION before the histogram: a workgroup owns 1/W of its level's rows, so ~3/4 of its points have no tap there,
+//     and an LDS atomic costs ~30 cycles per wavefront instruction however few lanes take part — twelve mostly-empty atomic
+//     instructions per wavefront were the longest phase.  Each wavefront lists the points that have a tap on its rows in its
+//     own LDS segment (ballot + prefix count: no atomics, no barrier — a wavefront's LDS operations execute in order) and
+//     then works through the list with dense lanes: four atomics and four record writes per 64 listed points;
+//   * fixed-capacity record slots (kSmallRecCap / rows per row; the rank from the histogram atomic is the slot), a 256-entry
+//     overflow list;
+//   * taps piled on few pixels (the list fills up), or fewer than four slots per row: the workgroup starts over in
+//     bwd_value_body's prefix-sum sort (the launch's LDS is sized for both layouts).
+// (Measured and not kept, profiles/r04_notes.md: the pair's grad_out rows staged in LDS for the gather — 1.1 us more in the
+// load phase for 1.0 us less in the gather; a flat per-lane-group walk over compacted records instead of rows in lockstep —
+// half the loads, 1.2 us slower.)
+constexpr int kSmallRecCap = 4096;                  // record slots (32 KB): 8 per row of a 48x48 level's fifth, 256+ of a 6x6 level's third
+constexpr int kSmallListCap = 96;                   // listed points per wavefront (of its 192); the rest take the sparse path
+
+__host__ __device__ inline size_t small_lds_bytes(int tp_cap)
+{
+    return ((size_t)2 * tp_cap + 32) * 4 + (size_t)kSmallRecCap * sizeof(SRec) + (size_t)kOvfCap * sizeof(SOvf) +
+           (size_t)kSWaves * kSmallListCap * (sizeof(PointEntry) + 4);
+}
+
+// The four taps of a point on this workgroup's rows [px0, px0 + npx) of a W-wide level: range-local destinations (-1 = not
+// mine), from a table entry; small_weights: their weights (bilinear x attention).
+__device__ __forceinline__ void small_dests(const PointEntry &e, int Wd, int px0, int npx, int (&dest)[4])
+{
+    const int okb = e.cell >> 24, pix = (e.cell & 0xffffff) - (Wd + 1) - px0;
+    const int p01 = pix + 1, p10 = pix + Wd, p11 = pix + Wd + 1;
+    dest[0] = ((okb & 1) && pix >= 0 && pix < npx) ? pix : -1;
+    dest[1] = ((okb & 2) && p01 >= 0 && p01 < npx) ? p01 : -1;
+    dest[2] = ((okb & 4) && p10 >= 0 && p10 < npx) ? p10 : -1;
+    dest[3] = ((okb & 8) && p11 >= 0 && p11 < npx) ? p11 : -1;
+}
+__device__ __forceinline__ void small_weights(const PointEntry &e, float (&tw)[4])
+{
+    const float hh = 1.f - e.lh, hw = 1.f - e.lw;
+    tw[0] = hh * hw * e.a; tw[1] = hh * e.lw * e.a; tw[2] = e.lh * hw * e.a; tw[3] = e.lh * e.lw * e.a;
+}
+
+template <typename VT, typename GT>
+__device__ __forceinline__ void bwd_value_small_body(
+    const VT *__restrict__ grad_out, const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
+    const float *__restrict__ loc, const float *__restrict__ attn, const PointEntry *__restrict__ table, int S, int M, int L, int Lq,
+    int P, int p_shift, int tp_cap, GT *__restrict__ grad_value, int ti, int W, int l, int pr, unsigned char *smem)
+{
+    // LDS: [cnt tp_cap] [start tp_cap] [wsum 32] [rec kSmallRecCap] [ovf kOvfCap] [listed points: 8 x kSmallListCap entries] [their queries]
+    int *cnt = reinterpret_cast<int *>(smem);
+    int *start = cnt + tp_cap;
+    int *wsum = start + tp_cap;
+    SRec *rec = reinterpret_cast<SRec *>(wsum + 32);
+    SOvf *ovf = reinterpret_cast<SOvf *>(rec + kSmallRecCap);
+    PointEntry *list = reinterpret_cast<PointEntry *>(ovf + kOvfCap);
+    int *list_q = reinterpret_cast<int *>(list + kSWaves * kSmallListCap);
+    int *novf_p = wsum + 8, *total_p = wsum + 9;
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = tid & 7;
+    MSDA_STAMP(0);
+    const int H = (int)shapes[2 * l], Wd = (int)shapes[2 * l + 1], lstart = (int)level_start[l];
+    const int HW = H * Wd;
+    const int px0 = (int)((unsigned)(ti * HW) / (unsigned)W), px1 = (int)((unsigned)((ti + 1) * HW) / (unsigned)W);
+    const int npx = px1 - px0;
+    const int b = pr / M, m = pr - b * M;
+    if (l == 0 && ti == 0) zero_uncovered_rows<GT, kSBlock>(shapes, level_start, S, M, L, grad_value, b, m);
+    const bool level_ok = level_fits(shapes[2 * l], shapes[2 * l + 1], level_start[l], S);
+    if (npx <= 0 || npx > tp_cap || !level_ok) return;
+    const int NP = Lq * P;                                                   // <= kSingleMaxPoints (the host's plan)
+    const long long item_base = (long long)b * Lq * M + m;                   // item(q) = item_base + q*M
+    const int row_stride = M * kD;
+    const GoBuf<VT> go = pair_rows<VT>(grad_out, item_base, Lq, M, j);
+    GT *gv_base = grad_value + ((long long)(b * S + lstart + px0) * M + m) * kD + j * 4;
+    const PointEntry *tab = table ? table + ((long long)pr * L + l) * NP : nullptr;       // (uniform)
+
+    // ---- this pass's points: table entries, or entries made from sampling_loc / attn_weight ----
+    constexpr int PPT = kSinglePPT;
+    PointEntry pe[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int idx = tid + k * kSBlock;
+        pe[k].cell = 0; pe[k].lh = pe[k].lw = pe[k].a = 0.f;
+        if (idx < NP) {
+            if (tab) pe[k] = tab[idx];
+            else {
+                const int q = fdiv(idx, P, p_shift), p = idx - q * P;
+                const long long pi = ((item_base + (long long)q * M) * L + l) * P + p;
+                const float2 xy = reinterpret_cast<const float2 *>(loc)[pi];
+                pe[k] = point_entry(xy.x, xy.y, attn[pi], H, Wd, true);
+            }
+        }
+    }
+    for (int i = tid; i < npx; i += kSBlock) cnt[i] = 0;
+    if (tid == 0) { *novf_p = 0; *total_p = 0; }
+    __syncthreads();
+    MSDA_STAMP(1);
+
+    const int cap = kSmallRecCap / npx;                                      // slots per row (uniform); below four: the general body
+    if (cap >= 4) {
+        // one point's taps -> ranks from the histogram atomics -> records in their slots
+        int mine_taps = 0;
+        auto sort_point = [&](const PointEntry &e, int q, const int (&dest)[4]) {
+            int rk[4]; float tw[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { rk[t] = 0; if (dest[t] >= 0) { rk[t] = MSDA_DIAG(0) ? 0 : atomicAdd(&cnt[dest[t]], 1); ++mine_taps; } }
+            if (MSDA_DIAG(1)) return;
+            small_weights(e, tw);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (dest[t] >= 0) {
+                    if (rk[t] < cap) { SRec r; r.w = tw[t]; r.q = q; rec[__mul24(dest[t], cap) + rk[t]] = r; }
+                    else {
+                        const int o = atomicAdd(novf_p, 1);
+                        if (o < kOvfCap) { SOvf r; r.w = tw[t]; r.q = q; r.row = dest[t]; ovf[o] = r; }
+                    }
+                }
+        };
+        // ---- list the points that have a tap on this workgroup's rows (wavefront-local: ballots, no atomics, no barrier) ----
+        PointEntry *mylist = list + wave * kSmallListCap;
+        int *myq = list_q + wave * kSmallListCap;
+        int listed = 0;
+        bool late[PPT];                                                      // kept points beyond the list's capacity: sparse path below
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            int dest[4];
+            small_dests(pe[k], Wd, px0, npx, dest);
+            const bool keep = (dest[0] & dest[1] & dest[2] & dest[3]) >= 0;     // some tap is mine
+            const unsigned long long mask = __ballot(keep);
+            const int pos = listed + __popcll(mask & ((1ull << lane) - 1ull));
+            late[k] = keep && pos >= kSmallListCap;
+            if (keep && pos < kSmallListCap) { mylist[pos] = pe[k]; myq[pos] = fdiv(tid + k * kSBlock, P, p_shift); }
+            listed += __popcll(mask);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int n_list = MSDA_DIAG(3) ? 0 : min(listed, kSmallListCap);
+        for (int i0 = 0; i0 < n_list; i0 += kWave) {                         // dense lanes: ~1 trip (fine levels) .. 2 (coarse)
+            const int i = i0 + lane;
+            PointEntry e; e.cell = 0; e.lh = e.lw = e.a = 0.f;
+            int q = 0;
+            if (i < n_list) { e = mylist[i]; q = myq[i]; }
+            int dest[4];
+            small_dests(e, Wd, px0, npx, dest);
+            sort_point(e, q, dest);
+        }
+        if (listed > kSmallListCap || MSDA_DIAG(3)) {                        // (uniform per wavefront; rare: more than half its points kept)
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                int dest[4];
+                small_dests(pe[k], Wd, px0, npx, dest);
+                if (!late[k] && !MSDA_DIAG(3)) dest[0] = dest[1] = dest[2] = dest[3] = -1;
+                sort_point(pe[k], fdiv(tid + k * kSBlock, P, p_shift), dest);
+            }
+        }
+        mine_taps = wave_sum(mine_taps);
+        if (lane == 0) atomicAdd(total_p, mine_taps);
+        __syncthreads();
+        MSDA_STAMP(2); MSDA_STAMP(3); MSDA_STAMP(4);
+        const int novf = *novf_p;
+        if (novf <= kOvfCap) {
+            if (MSDA_DIAG(4)) return;
+            const int mean2f = (2 * *total_p) / npx;
+            if (mean2f <= 8)       gather_rows<1, kAccNone, VT, GT, MSDA_GATHER_NR1>(go, gv_base, cnt, start, rec, nullptr, npx, row_stride, true, cap, ovf, novf);
+            else if (mean2f <= 16) gather_rows<2, kAccNone, VT, GT, 2>(go, gv_base, cnt, start, rec, nullptr, npx, row_stride, true, cap, ovf, novf);
+            else if (mean2f <= 32) gather_rows<4, kAccNone, VT, GT, 2>(go, gv_base, cnt, start, rec, nullptr, npx, row_stride, true, cap, ovf, novf);
+            else                   gather_rows<8, kAccNone, VT, GT, 2>(go, gv_base, cnt, start, rec, nullptr, npx, row_stride, true, cap, ovf, novf);
+            MSDA_STAMP(5);
+            return;
+        }
+    }
+
+    // ---- taps piled on few pixels (the overflow list filled up), or a level too fine for four slots per row: the general
+    // single-pass body (prefix-sum sort over a 4*Lq*P record array; the launch's LDS covers both layouts) from the top ----
+    __syncthreads();
+    bwd_value_body<kAccNone, kSinglePPT, VT, GT, false, false>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, tp_cap,
+                                                               grad_value, ti, W, l, pr, smem);
+}
 
 // ---- kAccWide: single pass by KEPT taps ----------------------------------------------------------------------
 // The chunked passes above size a pass by the points it SCANS (4 records per point), although a workgroup that
@@ -688,7 +891,7 @@ __device__ __forceinline__ void bwd_value_wide_body(
     const int NP = Lq * P;
     const long long item_base = (long long)b * Lq * M + m;
     const int row_stride = M * kD;
-    const VT *go_base = grad_out + item_base * kD + (lane & 7) * 4;
+    const GoBuf<VT> go = pair_rows<VT>(grad_out, item_base, Lq, M, lane & 7);
     GT *gv_base = grad_value + ((long long)(b * S + lstart + px0) * M + m) * kD + (lane & 7) * 4;
     const float2 *loc2 = reinterpret_cast<const float2 *>(loc);
     // Everything below is written for INSTRUCTION COUNT: a CU issues about one wavefront instruction per clock
@@ -875,7 +1078,7 @@ __device__ __forceinline__ void bwd_value_wide_body(
         MSDA_STAMP(4);
         // rows of comparable length (the longest no more than one lane group's share): the balanced walk
         if (longest_row() * 64 <= max(total, 1024)) {
-            gather_balanced<VT, GT, !DET>(go_base, gv_base, tot, start, RecSoa{rw, rq, qbase, row_stride}, reinterpret_cast<int *>(list), npx,
+            gather_balanced<VT, GT, !DET>(go, gv_base, tot, start, RecSoa{rw, rq, qbase, go.stride_b}, reinterpret_cast<int *>(list), npx,
                                           row_stride, total, first);
             MSDA_STAMP(5);
             return;
@@ -883,7 +1086,7 @@ __device__ __forceinline__ void bwd_value_wide_body(
         // rows of very different lengths (coarse levels): equal stretches of records, parts combined by the row's owner.
         // (Measured against it: the split gather for every row mix — same at cfg-2 / cfg-4 encoder, but on the single-pass
         // path 784 six-record rows cost 19.5 instead of 14.5 us; gather_rows here: 20.2 instead of 11.3 us per workgroup.)
-        gather_split<VT, GT, !DET>(go_base, gv_base, tot, start, RecSoa{rw, rq, qbase, row_stride}, reinterpret_cast<float4 *>(list), npx,
+        gather_split<VT, GT, !DET>(go, gv_base, tot, start, RecSoa{rw, rq, qbase, go.stride_b}, reinterpret_cast<float4 *>(list), npx,
                                    row_stride, total, first);
         MSDA_STAMP(5);
     };

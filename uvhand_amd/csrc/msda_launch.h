@@ -41,29 +41,34 @@ int launch_bwd_generic(const VT *grad_out, const VT *value, const int64_t *shape
 bool d32_supported(int N, int S, int M, int D, int L, int Lq, int P);
 int launch_fwd_d32(const float *value, const int64_t *shapes, const int64_t *level_start,
                    const float *loc, const float *attn, int N, int S, int M, int L, int Lq, int P,
-                   float *out, hipStream_t stream);
+                   float *out, hipStream_t stream, void *table = nullptr);
 int launch_bwd_d32(const float *grad_out, const float *value, const int64_t *shapes,
                    const int64_t *level_start, const float *loc, const float *attn, int N, int S,
                    int M, int L, int Lq, int P, float *grad_value, float *grad_loc, float *grad_attn,
-                   hipStream_t stream, void *workspace = nullptr, size_t ws_bytes = 0, bool deterministic = false);
+                   hipStream_t stream, void *workspace = nullptr, size_t ws_bytes = 0, bool deterministic = false,
+                   const void *table = nullptr);
+// the point table a small problem's forward can leave for its backward (bytes; 0 = the backward's plan reads none); `table`
+// arguments of the launchers below: that table (forward: written, backward: read), or null
+size_t forward_table_bytes(int N, int S, int M, int D, int L, int Lq, int P, bool prologue);
 // scratch the D = 32 backward can use to cut long levels into query chunks (0 = none needed); see msda.h
 size_t backward_workspace_bytes(int N, int S, int M, int D, int L, int Lq, int P, unsigned flags);
 
 // bf16 storage (uint16_t bits) of value / out / grad_out / grad_value; loc, attn and their gradients fp32.
 int launch_fwd_d32_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *level_start,
                         const float *loc, const float *attn, int N, int S, int M, int L, int Lq, int P,
-                        uint16_t *out, hipStream_t stream);
+                        uint16_t *out, hipStream_t stream, void *table = nullptr);
 int launch_bwd_d32_bf16(const uint16_t *grad_out, const uint16_t *value, const int64_t *shapes,
                         const int64_t *level_start, const float *loc, const float *attn, int N, int S,
                         int M, int L, int Lq, int P, uint16_t *grad_value, float *grad_loc, float *grad_attn,
-                        hipStream_t stream, void *workspace = nullptr, size_t ws_bytes = 0, bool deterministic = false);
+                        hipStream_t stream, void *workspace = nullptr, size_t ws_bytes = 0, bool deterministic = false,
+                        const void *table = nullptr);
 
 // bf16 rows in, fp32 grad_value out: nothing is rounded between the passes of a multi-pass backward (and a
 // caller whose value tensor is fp32 needs no conversion of the result)
 int launch_bwd_d32_bf16_gv32(const uint16_t *grad_out, const uint16_t *value, const int64_t *shapes,
                              const int64_t *level_start, const float *loc, const float *attn, int N, int S, int M, int L,
                              int Lq, int P, float *grad_value, float *grad_loc, float *grad_attn, hipStream_t stream,
-                             void *workspace = nullptr, size_t ws_bytes = 0, bool deterministic = false);
+                             void *workspace = nullptr, size_t ws_bytes = 0, bool deterministic = false, const void *table = nullptr);
 // number of query chunks ("passes") role B of the D = 32 backward takes for Lq*P sampling points per (b, m, l)
 int backward_passes(int Lq, int P);
 // text form of the launch plan of a D = 32 geometry (msda_describe_plan); returns the length written
@@ -77,22 +82,23 @@ bool prologue_supported(int N, int S, int M, int D, int L, int Lq, int P);
 int launch_fwd_prologue(const float *value, const int64_t *shapes, const int64_t *level_start, const float *ref,
                         const float *offsets, const float *logits, int N, int S, int M, int L, int Lq, int P,
                         long long ld_offsets, long long ld_logits, float *out, float *loc_out, float *attn_out,
-                        hipStream_t stream);
+                        hipStream_t stream, void *table = nullptr);
 int launch_bwd_prologue(const float *grad_out, const float *value, const int64_t *shapes, const int64_t *level_start,
                         const float *loc, const float *attn, int N, int S, int M, int L, int Lq, int P, float *grad_value,
                         long long ld_grad_offsets, long long ld_grad_logits, float *grad_offsets, float *grad_logits,
-                        float *grad_ref, hipStream_t stream, void *workspace = nullptr, size_t ws_bytes = 0, bool deterministic = false);
+                        float *grad_ref, hipStream_t stream, void *workspace = nullptr, size_t ws_bytes = 0, bool deterministic = false,
+                        const void *table = nullptr);
 
 // bf16 rows (value, out, grad_out); offsets / logits / reference points and every gradient fp32 (grad_value included)
 int launch_fwd_prologue_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *level_start, const float *ref,
                              const float *offsets, const float *logits, int N, int S, int M, int L, int Lq, int P,
                              long long ld_offsets, long long ld_logits, uint16_t *out, float *loc_out, float *attn_out,
-                             hipStream_t stream);
+                             hipStream_t stream, void *table = nullptr);
 int launch_bwd_prologue_bf16(const uint16_t *grad_out, const uint16_t *value, const int64_t *shapes, const int64_t *level_start,
                              const float *loc, const float *attn, int N, int S, int M, int L, int Lq, int P, float *grad_value,
                              long long ld_grad_offsets, long long ld_grad_logits, float *grad_offsets, float *grad_logits,
                              float *grad_ref, hipStream_t stream, void *workspace = nullptr, size_t ws_bytes = 0,
-                             bool deterministic = false);
+                             bool deterministic = false, const void *table = nullptr);
 
 // ---- weight / bias gradient of the bracketing nn.Linear layers (msda_linear.hip) -----------------
 size_t linear_wgrad_workspace_bytes(int M, int N, int K);

@@ -18,6 +18,10 @@ namespace {
 
 struct Dims { int N, S, M, D, L, Lq, P; };
 
+// Grad mode as the entry point saw it (inside Function::forward it is always off): a forward that will get a backward also
+// leaves its per-point table for it (msda_forward_ws_*); under no_grad / inference_mode nothing extra is written.
+thread_local bool g_grad_mode_at_entry = false;
+
 void check_inputs(std::initializer_list<std::pair<const char *, const at::Tensor *>> named)
 {
     const at::Tensor &value = *named.begin()->second;
@@ -69,8 +73,16 @@ void once_differentiable(const torch::autograd::variable_list &grads, const char
                     ": trying to differentiate twice a function that was marked with @once_differentiable");
 }
 
-at::Tensor forward(const at::Tensor &value, const at::Tensor &shapes, const at::Tensor &lsi, const at::Tensor &loc,
-                   const at::Tensor &attn, int64_t im2col_step)
+// The buffer a forward of this geometry fills with its point table for the backward of the same node (msda_forward_ws_*,
+// include/msda.h); undefined where the backward's plan reads none.
+at::Tensor forward_table(const at::Tensor &like, const Dims &d, unsigned flags)
+{
+    const unsigned long long n = msda_forward_workspace_bytes(d.N, d.S, d.M, d.D, d.L, d.Lq, d.P, flags);
+    return n ? at::empty({(int64_t)n}, like.options().dtype(at::kByte)) : at::Tensor();
+}
+
+at::Tensor forward_t(const at::Tensor &value, const at::Tensor &shapes, const at::Tensor &lsi, const at::Tensor &loc,
+                     const at::Tensor &attn, int64_t im2col_step, at::Tensor *table)
 {
     check_inputs({{"value", &value}, {"spatial_shapes", &shapes}, {"level_start_index", &lsi}, {"sampling_loc", &loc},
                   {"attn_weight", &attn}});
@@ -79,18 +91,28 @@ at::Tensor forward(const at::Tensor &value, const at::Tensor &shapes, const at::
     auto out = at::empty({d.N, d.Lq, (int64_t)d.M * d.D}, value.options());
     auto stream = (msda_stream_t)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(value.device().index()).stream();
     int rc;
-    if (value.scalar_type() == at::kFloat)
-        rc = msda_forward_f32(value.data_ptr<float>(), shapes.data_ptr<int64_t>(), lsi.data_ptr<int64_t>(), loc.data_ptr<float>(),
-                              attn.data_ptr<float>(), d.N, d.S, d.M, d.D, d.L, d.Lq, d.P, out.data_ptr<float>(), stream);
-    else
+    if (value.scalar_type() == at::kFloat) {
+        if (table) *table = forward_table(value, d, 0);
+        const bool t = table && table->defined();
+        rc = msda_forward_ws_f32(value.data_ptr<float>(), shapes.data_ptr<int64_t>(), lsi.data_ptr<int64_t>(), loc.data_ptr<float>(),
+                                 attn.data_ptr<float>(), d.N, d.S, d.M, d.D, d.L, d.Lq, d.P, out.data_ptr<float>(),
+                                 t ? table->data_ptr() : nullptr, t ? (unsigned long long)table->numel() : 0, stream);
+    } else
         rc = msda_forward_f64(value.data_ptr<double>(), shapes.data_ptr<int64_t>(), lsi.data_ptr<int64_t>(), loc.data_ptr<double>(),
                               attn.data_ptr<double>(), d.N, d.S, d.M, d.D, d.L, d.Lq, d.P, out.data_ptr<double>(), stream);
     raise_if(rc, "ms_deform_attn_forward");
     return out;
 }
 
-std::vector<at::Tensor> backward(const at::Tensor &value, const at::Tensor &shapes, const at::Tensor &lsi, const at::Tensor &loc,
-                                 const at::Tensor &attn, const at::Tensor &grad_out_in, int64_t im2col_step, bool deterministic)
+at::Tensor forward(const at::Tensor &value, const at::Tensor &shapes, const at::Tensor &lsi, const at::Tensor &loc,
+                   const at::Tensor &attn, int64_t im2col_step)
+{
+    return forward_t(value, shapes, lsi, loc, attn, im2col_step, nullptr);
+}
+
+std::vector<at::Tensor> backward_t(const at::Tensor &value, const at::Tensor &shapes, const at::Tensor &lsi, const at::Tensor &loc,
+                                   const at::Tensor &attn, const at::Tensor &grad_out_in, int64_t im2col_step, bool deterministic,
+                                   const at::Tensor &table)
 {
     const at::Tensor grad_out = grad_out_in.contiguous();       // the reference asserts it (ms_deform_attn_cuda.cu:98)
     check_inputs({{"value", &value}, {"spatial_shapes", &shapes}, {"level_start_index", &lsi}, {"sampling_loc", &loc},
@@ -102,11 +124,12 @@ std::vector<at::Tensor> backward(const at::Tensor &value, const at::Tensor &shap
     auto gv = at::empty_like(value), gl = at::empty_like(loc), ga = at::empty_like(attn);
     auto stream = (msda_stream_t)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(value.device().index()).stream();
     int rc;
-    const unsigned flags = deterministic ? MSDA_FLAG_DETERMINISTIC : 0u;
+    unsigned flags = deterministic ? MSDA_FLAG_DETERMINISTIC : 0u;
     at::Tensor ws;
     // (also without flags: the library says how much scratch a call of this geometry can use, mostly none)
-    const unsigned long long nbytes = msda_backward_workspace_bytes(d.N, d.S, d.M, d.D, d.L, d.Lq, d.P, flags);
+    unsigned long long nbytes = msda_backward_workspace_bytes(d.N, d.S, d.M, d.D, d.L, d.Lq, d.P, flags);
     if (nbytes) ws = at::empty({(int64_t)nbytes}, value.options().dtype(at::kByte));
+    else if (table.defined()) { ws = table; nbytes = (unsigned long long)table.numel(); flags |= MSDA_FLAG_FORWARD_TABLE; }   // the forward's point table
     if (value.scalar_type() == at::kFloat)
         rc = msda_backward_ws_f32(grad_out.data_ptr<float>(), value.data_ptr<float>(), shapes.data_ptr<int64_t>(),
                                   lsi.data_ptr<int64_t>(), loc.data_ptr<float>(), attn.data_ptr<float>(), d.N, d.S, d.M, d.D, d.L,
@@ -121,6 +144,12 @@ std::vector<at::Tensor> backward(const at::Tensor &value, const at::Tensor &shap
     return {gv, gl, ga};
 }
 
+std::vector<at::Tensor> backward(const at::Tensor &value, const at::Tensor &shapes, const at::Tensor &lsi, const at::Tensor &loc,
+                                 const at::Tensor &attn, const at::Tensor &grad_out_in, int64_t im2col_step, bool deterministic)
+{
+    return backward_t(value, shapes, lsi, loc, attn, grad_out_in, im2col_step, deterministic, at::Tensor());
+}
+
 // models/ops/functions/ms_deform_attn_func.py:21-39 as a C++ autograd node (value cast to the compute dtype in both
 // directions, the un-cast inputs saved, gradients for value / sampling_locations / attention_weights only).
 class MSDAFunction : public torch::autograd::Function<MSDAFunction> {
@@ -131,16 +160,20 @@ public:
     {
         ctx->saved_data["step"] = im2col_step;
         ctx->saved_data["det"] = deterministic;
-        ctx->save_for_backward({value, shapes, lsi, loc, attn});
-        return ::forward(value.to(loc.scalar_type()), shapes, lsi, loc, attn, im2col_step);
+        at::Tensor table;                                   // the forward's per-point table, if the backward of this geometry reads one
+        const bool want = g_grad_mode_at_entry && (value.requires_grad() || loc.requires_grad() || attn.requires_grad());
+        at::Tensor out = forward_t(value.to(loc.scalar_type()), shapes, lsi, loc, attn, im2col_step, want ? &table : nullptr);
+        ctx->save_for_backward({value, shapes, lsi, loc, attn, table});
+        return out;
     }
 
     static torch::autograd::variable_list backward(torch::autograd::AutogradContext *ctx, torch::autograd::variable_list grads)
     {
         once_differentiable(grads, "MSDeformAttnFunction");
         const auto saved = ctx->get_saved_variables();
-        const auto g = ::backward(saved[0].to(saved[3].scalar_type()), saved[1], saved[2], saved[3], saved[4], grads[0],
-                                  ctx->saved_data["step"].toInt(), (ctx->saved_data["det"].toBool() || at::globalContext().deterministicAlgorithms()));
+        const auto g = backward_t(saved[0].to(saved[3].scalar_type()), saved[1], saved[2], saved[3], saved[4], grads[0],
+                                  ctx->saved_data["step"].toInt(), (ctx->saved_data["det"].toBool() || at::globalContext().deterministicAlgorithms()),
+                                  saved[5]);
         return {g[0], at::Tensor(), at::Tensor(), g[1], g[2], at::Tensor(), at::Tensor()};
     }
 };
@@ -148,6 +181,7 @@ public:
 at::Tensor apply(const at::Tensor &value, const at::Tensor &shapes, const at::Tensor &lsi, const at::Tensor &loc,
                  const at::Tensor &attn, int64_t im2col_step, bool deterministic)
 {
+    g_grad_mode_at_entry = at::GradMode::is_enabled();
     return MSDAFunction::apply(value, shapes, lsi, loc, attn, im2col_step, deterministic);
 }
 
@@ -185,7 +219,6 @@ public:
     {
         ctx->saved_data["step"] = im2col_step;
         ctx->saved_data["det"] = deterministic;
-        ctx->save_for_backward({value, shapes, lsi, loc, attn});
         const at::Tensor v16 = value.to(at::kBFloat16), l32 = loc.to(at::kFloat), a32 = attn.to(at::kFloat);
         check_inputs({{"value", &v16}, {"spatial_shapes", &shapes}, {"level_start_index", &lsi}, {"sampling_loc", &l32},
                       {"attn_weight", &a32}});
@@ -193,9 +226,14 @@ public:
         c10::hip::HIPGuardMasqueradingAsCUDA guard(v16.device());
         auto out = at::empty({d.N, d.Lq, (int64_t)d.M * d.D}, v16.options());
         auto stream = (msda_stream_t)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(v16.device().index()).stream();
-        raise_if(msda_forward_bf16(bf16_ptr(v16), shapes.data_ptr<int64_t>(), lsi.data_ptr<int64_t>(), l32.data_ptr<float>(),
-                                   a32.data_ptr<float>(), d.N, d.S, d.M, d.D, d.L, d.Lq, d.P, bf16_mut(out), stream),
+        at::Tensor table;
+        if (g_grad_mode_at_entry && (value.requires_grad() || loc.requires_grad() || attn.requires_grad())) table = forward_table(v16, d, 0);
+        raise_if(msda_forward_ws_bf16(bf16_ptr(v16), shapes.data_ptr<int64_t>(), lsi.data_ptr<int64_t>(), l32.data_ptr<float>(),
+                                      a32.data_ptr<float>(), d.N, d.S, d.M, d.D, d.L, d.Lq, d.P, bf16_mut(out),
+                                      table.defined() ? table.data_ptr() : nullptr,
+                                      table.defined() ? (unsigned long long)table.numel() : 0, stream),
                  "ms_deform_attn_forward (bf16 rows)");
+        ctx->save_for_backward({value, shapes, lsi, loc, attn, table});
         return out;
     }
 
@@ -215,13 +253,14 @@ public:
         const bool gv32 = value.scalar_type() == at::kFloat || msda_backward_passes(d.Lq, d.P) > 1 ||
                           msda_path_for(2, d.M, d.D, d.L, d.P) != MSDA_PATH_D32 ||
                           (((uintptr_t)go.data_ptr() | (uintptr_t)v16.data_ptr() | (uintptr_t)l32.data_ptr()) & 7) != 0;
-        const unsigned flags = (ctx->saved_data["det"].toBool() || at::globalContext().deterministicAlgorithms()) ? MSDA_FLAG_DETERMINISTIC : 0u;
+        unsigned flags = (ctx->saved_data["det"].toBool() || at::globalContext().deterministicAlgorithms()) ? MSDA_FLAG_DETERMINISTIC : 0u;
         c10::hip::HIPGuardMasqueradingAsCUDA guard(v16.device());
         auto gv = at::empty_like(v16, v16.options().dtype(gv32 ? at::kFloat : at::kBFloat16));
         auto gl = at::empty_like(l32), ga = at::empty_like(a32);
         at::Tensor ws;
-        const unsigned long long nbytes = msda_backward_workspace_bytes(d.N, d.S, d.M, d.D, d.L, d.Lq, d.P, flags);
+        unsigned long long nbytes = msda_backward_workspace_bytes(d.N, d.S, d.M, d.D, d.L, d.Lq, d.P, flags);
         if (nbytes) ws = at::empty({(int64_t)nbytes}, v16.options().dtype(at::kByte));
+        else if (saved[5].defined()) { ws = saved[5]; nbytes = (unsigned long long)ws.numel(); flags |= MSDA_FLAG_FORWARD_TABLE; }
         auto stream = (msda_stream_t)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(v16.device().index()).stream();
         int rc;
         if (gv32)
@@ -243,6 +282,7 @@ public:
 at::Tensor apply_bf16(const at::Tensor &value, const at::Tensor &shapes, const at::Tensor &lsi, const at::Tensor &loc,
                       const at::Tensor &attn, int64_t im2col_step, bool deterministic)
 {
+    g_grad_mode_at_entry = at::GradMode::is_enabled();
     return MSDABF16Function::apply(value, shapes, lsi, loc, attn, im2col_step, deterministic);
 }
 
@@ -403,12 +443,16 @@ public:
         const at::Tensor projected = linear_rows_forward(q2.view({(int64_t)N * Lq, C}), wm, bm, nullptr, stream);   // [N*Lq, 3*mlp]
         auto sampled = at::empty({N, Lq, C}, q2.options());
         auto loc = at::empty({N, Lq, M, L, P, 2}, q2.options()), attn = at::empty({N, Lq, M, L, P}, q2.options());
-        raise_if(msda_forward_prologue_f32(value.data_ptr<float>(), shapes.data_ptr<int64_t>(), lsi.data_ptr<int64_t>(),
-                                           c2.data_ptr<float>(), projected.data_ptr<float>(), projected.data_ptr<float>() + 2 * mlp,
-                                           N, S, M, D, L, Lq, P, 3LL * mlp, 3LL * mlp, sampled.data_ptr<float>(),
-                                           loc.data_ptr<float>(), attn.data_ptr<float>(), stream),
+        at::Tensor table;                                   // per-point table for the backward of this node (small problems)
+        if (g_grad_mode_at_entry)
+            table = forward_table(q2, Dims{N, S, M, D, L, Lq, P}, MSDA_FLAG_PROLOGUE);
+        raise_if(msda_forward_prologue_ws_f32(value.data_ptr<float>(), shapes.data_ptr<int64_t>(), lsi.data_ptr<int64_t>(),
+                                              c2.data_ptr<float>(), projected.data_ptr<float>(), projected.data_ptr<float>() + 2 * mlp,
+                                              N, S, M, D, L, Lq, P, 3LL * mlp, 3LL * mlp, sampled.data_ptr<float>(),
+                                              loc.data_ptr<float>(), attn.data_ptr<float>(), table.defined() ? table.data_ptr() : nullptr,
+                                              table.defined() ? (unsigned long long)table.numel() : 0, stream),
                  "ms_deform_attn_forward_prologue");
-        ctx->save_for_backward({q2, x2, rmask.defined() ? rmask : at::Tensor(), value, loc, attn, sampled, wm, w_val, w_out, shapes, lsi});
+        ctx->save_for_backward({q2, x2, rmask.defined() ? rmask : at::Tensor(), value, loc, attn, sampled, wm, w_val, w_out, shapes, lsi, table});
         ctx->saved_data["dims"] = std::vector<int64_t>{N, S, M, D, L, Lq, P, C};
         ctx->saved_data["det"] = deterministic;
         return linear_rows_forward(sampled.view({(int64_t)N * Lq, C}), w_out, b_out, nullptr, stream).view({N, Lq, C});
@@ -441,16 +485,18 @@ public:
         // the reference points
         const bool det = ctx->saved_data["det"].toBool() || at::globalContext().deterministicAlgorithms();
         const unsigned flags = MSDA_FLAG_PROLOGUE | (det ? MSDA_FLAG_DETERMINISTIC : 0u);
-        const unsigned long long nbytes = msda_backward_workspace_bytes(N, S, M, D, L, Lq, P, flags);
+        unsigned long long nbytes = msda_backward_workspace_bytes(N, S, M, D, L, Lq, P, flags);
         at::Tensor ws;
+        unsigned table_flag = 0;
         if (nbytes) ws = at::empty({(int64_t)nbytes}, q2.options().dtype(at::kByte));
+        else if (sv[12].defined()) { ws = sv[12]; nbytes = (unsigned long long)ws.numel(); table_flag = MSDA_FLAG_FORWARD_TABLE; }
         auto gv = at::empty_like(value), gproj = at::empty({(int64_t)N * Lq, 3LL * mlp}, q2.options());
         auto gref = at::empty({N, Lq, L, 2}, q2.options());
         raise_if(msda_backward_prologue_ws_f32(g_sampled.data_ptr<float>(), value.data_ptr<float>(), shapes.data_ptr<int64_t>(),
                                                lsi.data_ptr<int64_t>(), loc.data_ptr<float>(), attn.data_ptr<float>(), N, S, M, D, L,
                                                Lq, P, 3LL * mlp, 3LL * mlp, gv.data_ptr<float>(), gproj.data_ptr<float>(),
                                                gproj.data_ptr<float>() + 2 * mlp, gref.data_ptr<float>(),
-                                               nbytes ? ws.data_ptr() : nullptr, nbytes, det ? MSDA_FLAG_DETERMINISTIC : 0u, stream),
+                                               nbytes ? ws.data_ptr() : nullptr, nbytes, (det ? MSDA_FLAG_DETERMINISTIC : 0u) | table_flag, stream),
                  "ms_deform_attn_backward_prologue");
         // merged projection
         at::Tensor g_query;
@@ -531,14 +577,18 @@ public:
         const at::Tensor projected = linear_rows_forward(q2.view({(int64_t)N * Lq, C}), wm, bm, nullptr, stream);
         auto sampled = at::empty({N, Lq, C}, xb.options());
         auto loc = at::empty({N, Lq, M, L, P, 2}, q2.options()), attn = at::empty({N, Lq, M, L, P}, q2.options());
-        raise_if(msda_forward_prologue_bf16(reinterpret_cast<const uint16_t *>(value.data_ptr<at::BFloat16>()),
-                                            shapes.data_ptr<int64_t>(), lsi.data_ptr<int64_t>(), c2.data_ptr<float>(),
-                                            projected.data_ptr<float>(), projected.data_ptr<float>() + 2 * mlp, N, S, M, D, L, Lq,
-                                            P, 3LL * mlp, 3LL * mlp, reinterpret_cast<uint16_t *>(sampled.data_ptr<at::BFloat16>()),
-                                            loc.data_ptr<float>(), attn.data_ptr<float>(), stream),
+        at::Tensor table;
+        if (g_grad_mode_at_entry)
+            table = forward_table(q2, Dims{N, S, M, D, L, Lq, P}, MSDA_FLAG_PROLOGUE);
+        raise_if(msda_forward_prologue_ws_bf16(reinterpret_cast<const uint16_t *>(value.data_ptr<at::BFloat16>()),
+                                               shapes.data_ptr<int64_t>(), lsi.data_ptr<int64_t>(), c2.data_ptr<float>(),
+                                               projected.data_ptr<float>(), projected.data_ptr<float>() + 2 * mlp, N, S, M, D, L, Lq,
+                                               P, 3LL * mlp, 3LL * mlp, reinterpret_cast<uint16_t *>(sampled.data_ptr<at::BFloat16>()),
+                                               loc.data_ptr<float>(), attn.data_ptr<float>(), table.defined() ? table.data_ptr() : nullptr,
+                                               table.defined() ? (unsigned long long)table.numel() : 0, stream),
                  "ms_deform_attn_forward_prologue (bf16 rows)");
         const at::Tensor wob = w_out.to(at::kBFloat16);
-        ctx->save_for_backward({q2, xb, rmask.defined() ? rmask : at::Tensor(), value, loc, attn, sampled, wm, wvb, wob, shapes, lsi});
+        ctx->save_for_backward({q2, xb, rmask.defined() ? rmask : at::Tensor(), value, loc, attn, sampled, wm, wvb, wob, shapes, lsi, table});
         ctx->saved_data["dims"] = std::vector<int64_t>{N, S, M, D, L, Lq, P, C};
         ctx->saved_data["det"] = deterministic;
         ctx->saved_data["x_float"] = input_flatten.scalar_type() == at::kFloat;
@@ -568,9 +618,11 @@ public:
         // the sampling kernels: bf16 rows in, float32 gradients out
         const bool det = ctx->saved_data["det"].toBool() || at::globalContext().deterministicAlgorithms();
         const unsigned flags = MSDA_FLAG_PROLOGUE | (det ? MSDA_FLAG_DETERMINISTIC : 0u);
-        const unsigned long long nbytes = msda_backward_workspace_bytes(N, S, M, D, L, Lq, P, flags);
+        unsigned long long nbytes = msda_backward_workspace_bytes(N, S, M, D, L, Lq, P, flags);
         at::Tensor ws;
+        unsigned table_flag = 0;
         if (nbytes) ws = at::empty({(int64_t)nbytes}, q2.options().dtype(at::kByte));
+        else if (sv[12].defined()) { ws = sv[12]; nbytes = (unsigned long long)ws.numel(); table_flag = MSDA_FLAG_FORWARD_TABLE; }
         auto gv = at::empty({N, S, C}, q2.options()), gproj = at::empty({(int64_t)N * Lq, 3LL * mlp}, q2.options());
         auto gref = at::empty({N, Lq, L, 2}, q2.options());
         raise_if(msda_backward_prologue_bf16_gv32(reinterpret_cast<const uint16_t *>(g_sampled.data_ptr<at::BFloat16>()),
@@ -579,7 +631,7 @@ public:
                                                   attn.data_ptr<float>(), N, S, M, D, L, Lq, P, 3LL * mlp, 3LL * mlp,
                                                   gv.data_ptr<float>(), gproj.data_ptr<float>(), gproj.data_ptr<float>() + 2 * mlp,
                                                   gref.data_ptr<float>(), nbytes ? ws.data_ptr() : nullptr, nbytes,
-                                                  det ? MSDA_FLAG_DETERMINISTIC : 0u, stream),
+                                                  (det ? MSDA_FLAG_DETERMINISTIC : 0u) | table_flag, stream),
                  "ms_deform_attn_backward_prologue (bf16 rows)");
         // merged projection (float32)
         at::Tensor g_query;
@@ -620,6 +672,7 @@ at::Tensor module_forward_bf16(const at::Tensor &query, const at::Tensor &centre
     TORCH_CHECK(input_flatten.device() == query.device(), "MSDeformAttn (C++ node, bf16 rows): input_flatten on another device");
     check_module_args(query, centre, input_flatten, mask, shapes, lsi, w_off, b_off, w_attn, b_attn, w_val, b_val, w_out, b_out,
                       n_heads, n_levels, n_points);
+    g_grad_mode_at_entry = at::GradMode::is_enabled();
     return MSDAModuleBF16Function::apply(query, centre, input_flatten, mask, shapes, lsi, w_off, b_off, w_attn, b_attn, w_val,
                                          b_val, w_out, b_out, n_heads, n_levels, n_points, im2col_step, deterministic, wm_cached,
                                          bm_cached);
@@ -639,6 +692,7 @@ at::Tensor module_forward(const at::Tensor &query, const at::Tensor &centre, con
                 "expected scalar type Long for spatial_shapes / level_start_index (on the device)");
     check_module_args(query, centre, input_flatten, mask, shapes, lsi, w_off, b_off, w_attn, b_attn, w_val, b_val, w_out, b_out,
                       n_heads, n_levels, n_points);
+    g_grad_mode_at_entry = at::GradMode::is_enabled();
     return MSDAModuleFunction::apply(query, centre, input_flatten, mask, shapes, lsi, w_off, b_off, w_attn, b_attn, w_val, b_val,
                                      w_out, b_out, n_heads, n_levels, n_points, im2col_step, deterministic, wm_cached, bm_cached);
 }

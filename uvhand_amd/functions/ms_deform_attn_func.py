@@ -50,23 +50,27 @@ class MSDeformAttnFunction(Function):
                 attention_weights, im2col_step):
         ctx.im2col_step = im2col_step
         cdt, loc, attn = _compute_dtype(sampling_locations, attention_weights)
-        output = MSDA.ms_deform_attn_forward(
-            value.to(cdt), value_spatial_shapes, value_level_start_index, loc, attn, ctx.im2col_step)
+        # a forward whose backward will run also leaves its per-point table for it (small problems; None otherwise)
+        output, table = MSDA.ms_deform_attn_forward(
+            value.to(cdt), value_spatial_shapes, value_level_start_index, loc, attn, ctx.im2col_step,
+            with_table=any(ctx.needs_input_grad))
+        ctx.has_table = table is not None
         ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index,
-                              sampling_locations, attention_weights)
+                              sampling_locations, attention_weights, *([table] if table is not None else []))
         return output
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_output):
         value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights = \
-            ctx.saved_tensors
+            ctx.saved_tensors[:5]
+        table = ctx.saved_tensors[5] if ctx.has_table else None
         cdt, loc, attn = _compute_dtype(sampling_locations, attention_weights)
         # the reference asserts contiguity of grad_output (ms_deform_attn_cuda.cu:98) and would
         # raise on e.g. an expanded gradient; making it contiguous is the superset behaviour.
         grad_value, grad_sampling_loc, grad_attn_weight = MSDA.ms_deform_attn_backward(
             value.to(cdt), value_spatial_shapes, value_level_start_index, loc, attn,
-            grad_output.to(cdt).contiguous(), ctx.im2col_step)
+            grad_output.to(cdt).contiguous(), ctx.im2col_step, table=table)
         if loc is not sampling_locations:                                           # half inputs: gradients in their dtypes
             grad_sampling_loc = grad_sampling_loc.to(sampling_locations.dtype)
             grad_attn_weight = grad_attn_weight.to(attention_weights.dtype)
@@ -112,18 +116,20 @@ class MSDeformAttnBF16Function(Function):
     def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations,
                 attention_weights, im2col_step):
         ctx.im2col_step = im2col_step
-        output = MSDA.ms_deform_attn_forward(
+        output, table = MSDA.ms_deform_attn_forward(
             value.to(torch.bfloat16), value_spatial_shapes, value_level_start_index,
-            sampling_locations.float(), attention_weights.float(), ctx.im2col_step)
+            sampling_locations.float(), attention_weights.float(), ctx.im2col_step, with_table=any(ctx.needs_input_grad))
+        ctx.has_table = table is not None
         ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index,
-                              sampling_locations, attention_weights)
+                              sampling_locations, attention_weights, *([table] if table is not None else []))
         return output
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_output):
         value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights = \
-            ctx.saved_tensors
+            ctx.saved_tensors[:5]
+        table = ctx.saved_tensors[5] if ctx.has_table else None
         # grad_value in float32 straight from the kernel when that is what `value` needs anyway, and for long
         # backwards (several query chunks accumulate: fp32 in place, one rounding at the end)
         # — and wherever the generic kernels serve the call (D != 32: fp32 atomics are their only accumulation)
@@ -133,7 +139,7 @@ class MSDeformAttnBF16Function(Function):
         grad_value, grad_sampling_loc, grad_attn_weight = MSDA.ms_deform_attn_backward(
             value.to(torch.bfloat16), value_spatial_shapes, value_level_start_index,
             sampling_locations.float(), attention_weights.float(),
-            grad_output.to(torch.bfloat16).contiguous(), ctx.im2col_step, fp32_grad_value=fp32_gv)
+            grad_output.to(torch.bfloat16).contiguous(), ctx.im2col_step, fp32_grad_value=fp32_gv, table=table)
         return (grad_value.to(value.dtype), None, None, grad_sampling_loc.to(sampling_locations.dtype),
                 grad_attn_weight.to(attention_weights.dtype), None)
 
@@ -154,19 +160,23 @@ class MSDeformAttnPrologueFunction(Function):
     def forward(ctx, value, value_spatial_shapes, value_level_start_index, reference_points, sampling_offsets,
                 attn_logits, im2col_step):
         N, Lq, M, L, P, _ = sampling_offsets.shape
-        out, loc, attn = MSDA.ms_deform_attn_forward_prologue(
+        out, loc, attn, table = MSDA.ms_deform_attn_forward_prologue(
             value, value_spatial_shapes, value_level_start_index, reference_points.contiguous(),
-            sampling_offsets.contiguous(), attn_logits.contiguous().view(N, Lq, M, L * P), im2col_step)
-        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, loc, attn)
+            sampling_offsets.contiguous(), attn_logits.contiguous().view(N, Lq, M, L * P), im2col_step,
+            with_table=any(ctx.needs_input_grad))
+        ctx.has_table = table is not None
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, loc, attn,
+                              *([table] if table is not None else []))
         ctx.logits_shape = attn_logits.shape
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_output):
-        value, value_spatial_shapes, value_level_start_index, loc, attn = ctx.saved_tensors
+        value, value_spatial_shapes, value_level_start_index, loc, attn = ctx.saved_tensors[:5]
         gv, goff, glog, gref = MSDA.ms_deform_attn_backward_prologue(
-            value, value_spatial_shapes, value_level_start_index, loc, attn, grad_output.contiguous())
+            value, value_spatial_shapes, value_level_start_index, loc, attn, grad_output.contiguous(),
+            table=ctx.saved_tensors[5] if ctx.has_table else None)
         return gv, None, None, gref, goff, glog.view(ctx.logits_shape), None
 
 
@@ -198,18 +208,22 @@ class MSDeformAttnMergedPrologueFunction(Function):
                                "expected %d)" % (width, 3 * mlp))
         projected = projected.contiguous()
         rows = value.to(torch.bfloat16) if bf16_rows else value
-        out, loc, attn = MSDA.ms_deform_attn_forward_prologue(
+        out, loc, attn, table = MSDA.ms_deform_attn_forward_prologue(
             rows, value_spatial_shapes, value_level_start_index, reference_points.contiguous(),
             projected[..., :2 * mlp].view(N, Lq, n_heads, n_levels, n_points, 2),
-            projected[..., 2 * mlp:].view(N, Lq, n_heads, n_levels * n_points), im2col_step)
-        ctx.save_for_backward(rows, value_spatial_shapes, value_level_start_index, loc, attn)
+            projected[..., 2 * mlp:].view(N, Lq, n_heads, n_levels * n_points), im2col_step,
+            with_table=any(ctx.needs_input_grad))
+        ctx.has_table = table is not None
+        ctx.save_for_backward(rows, value_spatial_shapes, value_level_start_index, loc, attn,
+                              *([table] if table is not None else []))
         ctx.value_dtype = value.dtype
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_output):
-        rows, value_spatial_shapes, value_level_start_index, loc, attn = ctx.saved_tensors
+        rows, value_spatial_shapes, value_level_start_index, loc, attn = ctx.saved_tensors[:5]
         gv, _, _, gref, gproj = MSDA.ms_deform_attn_backward_prologue(
-            rows, value_spatial_shapes, value_level_start_index, loc, attn, grad_output.to(rows.dtype).contiguous(), merged=True)
+            rows, value_spatial_shapes, value_level_start_index, loc, attn, grad_output.to(rows.dtype).contiguous(), merged=True,
+            table=ctx.saved_tensors[5] if ctx.has_table else None)
         return gv.to(ctx.value_dtype), None, None, gref, gproj, None, None, None, None, None
