@@ -40,8 +40,8 @@
  * them on the host side, ms_deform_attn_cuda.cu:54,121-123).
  *
  * Ownership: the library allocates nothing and frees nothing, reads no environment
- * variable, and keeps no process-wide mutable state: the error string and the test
- * hook msda_force_path() are per thread.  It never synchronises the
+ * variable, and keeps no process-wide mutable state that any computation depends on: the error string and
+ * the test hook msda_force_path() are per thread (msda_launch_count() is a diagnostic counter).  It never synchronises the
  * device: all work (including the zero-fill of grad_value where a kernel needs
  * it) is enqueued on `stream` (a hipStream_t; NULL = the default stream).
  * Re-entrant: forward and backward may be called concurrently from different
@@ -139,7 +139,10 @@ int msda_backward_passes(int Lq, int P);
  * Shapes that are inconsistent with S (a level whose pixels do not lie in [0, S)) never cause an
  * out-of-range access on this path: such a level contributes nothing and pixels no level covers get zeros.
  * Outside the D = 32 family (any D, fp64, element-aligned views) the flag selects a destination-major kernel that
- * adds a pixel's contributions in (query, point) order — no atomics, no scratch, rows x Lq*P point tests of work.
+ * adds a pixel's contributions in (query, point) order — no atomics, no scratch, rows x Lq*P point tests of work; a call
+ * with N*S*M x Lq*P > 2^36 is refused (MSDA_ERR_ARGUMENT) rather than run for seconds.  A pixel that several levels cover
+ * (overlapping level_start ranges: not something the reference's callers produce) is credited to the first such level there,
+ * to every level by the default kernels: overlapping levels are unsupported in every deterministic path.
  * Cost on the D = 32 family: 3-15 % over the default backward (profiles/r03_notes.md section 4).  Replaces the same reference functions as msda_backward_*. */
 #define MSDA_FLAG_DETERMINISTIC 1u
 /* msda_backward_workspace_bytes only: the size is asked for a msda_backward_prologue_* call (on large problems its
@@ -360,6 +363,11 @@ int msda_describe_plan(int row_bytes, int grad_value_bytes, int N, int S, int M,
  * table.  `blocks` x 256 threads, `iters` x 16 rows per 8-lane group.  No reference counterpart; no product path calls it. */
 int msda_probe_row_gather(const void *table, unsigned long long table_bytes, int row_bytes, int blocks, int iters, float *sink,
                           unsigned long long *rows_gathered, msda_stream_t stream);
+
+/* Diagnostic: kernel launches this process has enqueued through the library so far (one count per launcher call that reached
+ * the device; a monotonically increasing relaxed atomic — the only process-wide state the library keeps, never read by a
+ * kernel path).  Tests use the difference around a call, e.g. "a frozen projection costs no weight-gradient launch". */
+unsigned long long msda_launch_count(void);
 
 /* Test hook: force the kernel family for the CALLING THREAD's subsequent calls (-1 = automatic, default; MSDA_PATH_GENERIC).
  * Thread-local, so no caller can change the kernels under another thread's launch; not meant for production callers. */

@@ -76,11 +76,15 @@ def test_two_ranks_on_one_device_are_a_launch_error_under_rccl_only():
     """harness.duplicate_devices / check_one_rank_per_device: under backend "nccl" (RCCL) two ranks on one physical GPU must
     fail the job; the gloo rehearsal shares a card on purpose."""
     from uvhand_amd import harness
-    a = {"device": "cuda:0", "index": 0, "name": "x", "pci_bus_id": "0000:05:00", "uuid": "GPU-1"}
+    a = {"host": "node0", "device": "cuda:0", "index": 0, "name": "x", "pci_bus_id": "0000:05:00", "uuid": "GPU-1"}
     b = dict(a, device="cuda:1", index=1, pci_bus_id="0000:15:00", uuid="GPU-2")
     assert harness.duplicate_devices([a, b]) == []
-    assert harness.duplicate_devices([a, dict(a)]) == [(0, 1, "GPU-1")]
-    assert harness.duplicate_devices([dict(a, uuid=None), dict(a, uuid=None, device="cuda:0")]) == [(0, 1, "0000:05:00")]
+    assert harness.duplicate_devices([a, dict(a)]) == [(0, 1, "GPU-1 on node0")]
+    assert harness.duplicate_devices([dict(a, uuid=None), dict(a, uuid=None, device="cuda:0")]) == [(0, 1, "0000:05:00 on node0")]
+    # two NODES: the same bus id / index / a constant uuid on another host is another GPU
+    assert harness.duplicate_devices([a, dict(a, host="node1")]) == []
+    assert harness.duplicate_devices([dict(a, uuid=None, pci_bus_id=None), dict(a, uuid=None, pci_bus_id=None, host="node1")]) == []
+    assert "host" in harness.device_identity(None)
     cpu = harness.device_identity(None)
     assert harness.duplicate_devices([cpu, cpu]) == []                  # nothing to tell apart on the CPU
     assert harness.check_one_rank_per_device("nccl", None) == [cpu]     # one process: nothing to check

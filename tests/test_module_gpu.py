@@ -566,3 +566,134 @@ def test_module_at_encoder_geometry_above_the_lds_stage_threshold(cpp):
     assert rel_err(refp.grad.cpu().numpy(), gold["grad_refp"]) < 2e-4
     for name, p in mod.named_parameters():
         assert rel_err(p.grad.cpu().numpy(), gold["pgrad." + name]) < 3e-4, name
+
+
+def _node_inputs(z):
+    return (torch.from_numpy(z["query"]).cuda().requires_grad_(True), torch.from_numpy(z["refp"]).cuda().requires_grad_(True),
+            torch.from_numpy(z["src"]).cuda().requires_grad_(True), torch.from_numpy(z["shapes"]).cuda(),
+            torch.from_numpy(z["level_start"]).cuda(), torch.from_numpy(z["mask"]).cuda())
+
+
+def test_frozen_projections_cost_no_weight_gradient_launch():
+    """The one-node path skips the weight / bias gradient of every projection whose parameters do not require grad (the lr groups
+    and --not_use_params of util/settings.py:447-515 freeze layers): fewer launches through the library (msda_launch_count),
+    no .grad on the frozen parameters, everything else unchanged."""
+    from uvhand_amd import _ext, _native
+    if _ext.get() is None or not hasattr(_ext.get(), "module_forward"):
+        pytest.skip("torch extension not built")
+    z = load_golden("module_2d")
+    results, launches = {}, {}
+    for frozen in (False, True):
+        mod = _module()
+        if frozen:
+            for p in list(mod.value_proj.parameters()) + list(mod.output_proj.parameters()):
+                p.requires_grad_(False)
+        q, r, s_, sh, lsi, mask = _node_inputs(z)
+        for _ in range(2):                                   # second round: the cached merged projection is in use as well
+            mod.zero_grad(set_to_none=True)
+            q.grad = r.grad = s_.grad = None
+            before = _native.launch_count()
+            out = mod(q, r, s_, sh, lsi, mask)
+            assert "MSDAModuleFunction" in out.grad_fn.name()
+            out.backward(torch.from_numpy(z["gout"]).cuda())
+            torch.cuda.synchronize()
+            launches[frozen] = _native.launch_count() - before
+        results[frozen] = (out.detach(), q.grad, s_.grad, r.grad, {n: p.grad for n, p in mod.named_parameters()})
+    assert launches[True] < launches[False], launches
+    for a, b in zip(results[True][:4], results[False][:4]):
+        assert torch.equal(a, b)
+    for n, g in results[True][4].items():
+        if n.startswith(("value_proj", "output_proj")):
+            assert g is None, n
+        else:
+            assert torch.equal(g, results[False][4][n]), n
+
+
+def test_merged_projection_cache_follows_parameter_updates():
+    """The cached [sampling_offsets ; attention_weights] concatenation is keyed on the parameters' storage and in-place version
+    counters: an optimizer-style in-place update, load_state_dict and _reset_parameters all show in the next forward."""
+    z = load_golden("module_2d")
+    mod = _module()
+    q, r, s_, sh, lsi, mask = _node_inputs(z)
+    out0 = mod(q, r, s_, sh, lsi, mask).detach().clone()
+    assert mod.__dict__.get("_merged_cache") is not None or not mod.cpp_node
+    with torch.no_grad():
+        mod.attention_weights.bias.add_(torch.linspace(-1, 1, mod.attention_weights.bias.numel(), device="cuda"))
+    out1 = mod(q, r, s_, sh, lsi, mask).detach().clone()
+    assert not torch.equal(out0, out1)
+    ref = _module()                                          # a fresh module with the same update and no cache history
+    with torch.no_grad():
+        ref.attention_weights.bias.add_(torch.linspace(-1, 1, ref.attention_weights.bias.numel(), device="cuda"))
+    assert torch.equal(out1, ref(q, r, s_, sh, lsi, mask).detach())
+    mod.load_state_dict(_module().state_dict())
+    assert torch.equal(mod(q, r, s_, sh, lsi, mask).detach(), out0)
+    torch.manual_seed(5)                                     # (xavier_uniform_ draws the value / output projections)
+    mod._reset_parameters()                                  # (re-creates the offsets' bias on the CPU, as the reference's does)
+    mod.cuda()
+    fresh = _module()
+    torch.manual_seed(5)
+    fresh._reset_parameters()
+    fresh.cuda()
+    assert torch.equal(mod(q, r, s_, sh, lsi, mask).detach(), fresh(q, r, s_, sh, lsi, mask).detach())
+
+
+def test_cpp_node_checks_its_arguments_and_falls_back_in_python():
+    """the one-node path validated dtype / device only.  Reference points that merely broadcast ([N, Lq, 1, 2]) and
+    a spatial_shapes with fewer rows than n_levels now take the Python composition (which broadcasts like the reference, or
+    raises); handed to the node directly they raise instead of reading out of bounds; a create_graph=True backward raises
+    like the reference's @once_differentiable."""
+    from uvhand_amd import _ext
+    ext = _ext.get()
+    if ext is None or not hasattr(ext, "module_forward"):
+        pytest.skip("torch extension not built")
+    z = load_golden("module_2d")
+    mod = _module()
+    q, r, s_, sh, lsi, mask = _node_inputs(z)
+    full = mod(q, r, s_, sh, lsi, mask)
+    assert "MSDAModuleFunction" in full.grad_fn.name()
+    # broadcastable reference points: same result through the composition
+    r1 = r.detach()[:, :, :1].clone()
+    out = mod(q, r1.expand(-1, -1, 4, -1), s_, sh, lsi, mask)              # an expanded view is a full-size tensor: the node takes it
+    out_b = mod(q, r1, s_, sh, lsi, mask)                                  # [N, Lq, 1, 2]: the module expands it like the reference's broadcast
+    assert torch.equal(out_b, out)
+    mod.fused_prologue = False                                             # ... and so does the reference's own arithmetic
+    out_c = mod(q, r1, s_, sh, lsi, mask)
+    mod.fused_prologue = True
+    assert rel_err(out_c.detach().cpu().numpy(), out.detach().cpu().numpy()) < 2e-5
+    args = (q, r1, s_, mask, sh, lsi, mod.sampling_offsets.weight, mod.sampling_offsets.bias, mod.attention_weights.weight,
+            mod.attention_weights.bias, mod.value_proj.weight, mod.value_proj.bias, mod.output_proj.weight, mod.output_proj.bias,
+            8, 4, 4, 64, False)
+    with pytest.raises(RuntimeError, match="reference points must be"):
+        ext.module_forward(*args)
+    bad = list(args); bad[1] = r.detach(); bad[4] = sh[:3].contiguous()
+    with pytest.raises(RuntimeError, match="spatial_shapes must be"):
+        ext.module_forward(*bad)
+    # @once_differentiable
+    g, = torch.autograd.grad(full.sum(), q, create_graph=True)
+    (full * 2).sum().backward(retain_graph=True)                           # a plain second backward of the same graph is fine
+    go = torch.ones_like(full).requires_grad_(True)
+    with pytest.raises(RuntimeError, match="once_differentiable"):
+        torch.autograd.grad(full, q, grad_outputs=go, create_graph=True)
+
+
+def test_cpp_node_with_two_projection_outputs_falls_back_to_torch_weight_gradients():
+    """n_heads * n_levels * n_points == 2 gives the merged projection 6 output rows (2 offsets x 2 + 2 logits), not a
+    multiple of 4: the node's weight gradient then takes the torch composition instead of msda_linear_wgrad (which refuses)."""
+    from uvhand_amd.modules import MSDeformAttn
+    torch.manual_seed(3)
+    mod = MSDeformAttn(32, 1, 1, 2).cuda()
+    sh = torch.tensor([[6, 5]], dtype=torch.long).cuda()
+    lsi = torch.zeros(1, dtype=torch.long).cuda()
+    q = torch.randn(2, 7, 32).cuda().requires_grad_(True)
+    src = torch.randn(2, 30, 32).cuda().requires_grad_(True)
+    ref = torch.rand(2, 7, 1, 2).cuda()
+    res = {}
+    for cpp in (True, False):
+        mod.cpp_node = cpp
+        mod.zero_grad(set_to_none=True)
+        q.grad = src.grad = None
+        out = mod(q, ref, src, sh, lsi)
+        out.sum().backward()
+        res[cpp] = [out.detach(), q.grad, src.grad] + [p.grad for p in mod.parameters()]
+    for a, b in zip(res[True], res[False]):
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5

@@ -741,3 +741,48 @@ def test_forward_table_of_a_pile_up_takes_the_general_body(native, oracle):
         assert rel_err(g[0].cpu().numpy(), r_gv) < 2e-5
         assert rel_err(g[2].cpu().numpy(), r_ga) < 2e-5
     assert torch.equal(got[1], base[1])
+
+
+# ---------------------------------------------------------------------------------------------
+# either side of every dispatcher threshold (msda_d32.hip: plan_lds, pick_split, plan_value, plan_fused)
+# ---------------------------------------------------------------------------------------------
+_S2 = [(8, 8), (4, 4)]
+_S5 = [(8, 8), (4, 4), (2, 2), (2, 2), (1, 1)]                # L*P = 20 > 16: never the LDS stage, so pick_split decides
+_C2 = [(48, 48), (24, 24), (12, 12), (6, 6)]
+STRADDLE = {
+    # name: ((N, shapes, M, D, Lq, P), substrings the launch plan must contain)
+    "items_32760":   ((1, _S2, 8, 32, 4095, 4), ["fwd=tiled(", "bwd=fused("]),           # below plan_lds' 32 768 items
+    "items_32776":   ((1, _S2, 8, 32, 4097, 4), ["fwd=lds(", "bwd=fused_lds("]),         # above
+    "octets_2048":   ((1, _S2, 8, 32, 2048, 4), ["fwd=tiled(split=4"]),                  # pick_split: 4 wavefronts per octet ...
+    "octets_2049":   ((1, _S2, 8, 32, 2049, 4), ["fwd=tiled(split=2"]),                  # ... 2
+    "octets_8192":   ((1, _S5, 8, 32, 8192, 4), ["fwd=tiled(split=2"]),
+    "octets_8193":   ((1, _S5, 8, 32, 8193, 4), ["fwd=tiled(split=1"]),                  # ... 1
+    "points_1536":   ((1, _S2, 8, 32, 384, 4), ["acc=single", "fixed"]),                 # Lq*P = kSingleMaxPoints: one pass, short sort
+    "points_1540":   ((1, _S2, 8, 32, 385, 4), ["acc=wide", "prefix"]),                  # beyond: the kept-taps pass
+    "points_65536":  ((1, _S2, 1, 32, 16384, 4), ["acc=wide"]),                          # Lq*P = kWideMaxStep: one attempt covers all points
+    "points_65540":  ((1, _S2, 1, 32, 16385, 4), ["acc=wide"]),                          # two attempts (16-bit list entries)
+    "roleB_384":     ((2, _C2, 8, 32, 3060, 4), ["bwd=fused_lds(", "roleB=384", "roleA=128"]),   # role A in the slots role B leaves
+    "roleB_448":     ((2, _C2, 8, 32, 3300, 4), ["bwd=fused_lds(", "roleB=448", "roleA=512"]),   # ... behind several rounds of role B
+}
+
+
+@pytest.mark.parametrize("name", list(STRADDLE))
+def test_either_side_of_every_dispatcher_threshold(native, oracle, name):
+    """Each geometry sits just below or just above one of the launch-plan thresholds; the plan the library reports
+    (msda_describe_plan) must be the branch named here, and forward + backward must match the C oracle on it."""
+    case, must = STRADDLE[name]
+    N, shapes, M, D, Lq, P = case
+    S = sum(h * w for h, w in shapes)
+    plan = native.describe_plan(N, S, M, D, len(shapes), Lq, P)
+    for sub in must:
+        assert sub in plan, (sub, plan)
+    z = make_case(21, *case)
+    out, gv, gl, ga = run_hip(z, torch.float32)
+    args = [z["value"], z["shapes"], z["level_start"], z["loc"], z["attn"]]
+    r_gv, r_gl, r_ga = oracle.backward(z["grad_out"], *args)
+    assert rel_err(out, oracle.forward(*args)) < 5e-6
+    # (thousands of taps per pixel on these tiny maps: fp32 summation order shows at 5e-5 of max)
+    assert rel_err(gv, r_gv) < 5e-5
+    assert rel_err(ga, r_ga) < 2e-5
+    keep = ~near_boundary_mask(z, tol=1e-5)
+    assert rel_err(gl[keep], r_gl[keep]) < 2e-5

@@ -125,6 +125,10 @@ def main():
                          "the clip + optimizer phase, where nothing is queued behind them (profiles/r03_notes.md §8)")
     ap.add_argument("--plain-layers", action="store_true",
                     help="A/B: stock add + LayerNorm and stock FFN weight gradients inside the layers")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture forward + loss + backward of the whole stack into ONE HIP graph (after the warm-up, gradients left "
+                         "in static buffers) and replay it per step; clip_grad_norm_ + AdamW stay outside.  One rank only (the "
+                         "gradient all-reduce is not captured), none of the host-side f4 flags")
     ap.add_argument("--amp", default="", choices=["", "bf16"],
                     help="bf16: torch.autocast(bfloat16) around the forward + bf16 row storage in the op (BASELINE config 3)")
     args = ap.parse_args()
@@ -197,6 +201,33 @@ def main():
 
     for _ in range(args.warmup):
         loss = step()
+    if args.graph:
+        if distributed or args.vote or args.reduce_dict or args.host_matcher:
+            sys.exit("ddp_step.py --graph: one rank, without --vote / --reduce-dict / --host-matcher (host work cannot be captured)")
+        # whole-network capture (forward, loss, backward); the gradients the capture allocates stay where they are and every
+        # replay refreshes them, so the optimizer reads them as usual.  Nothing in the modules or the library synchronises,
+        # allocates outside the capture pool or reads spatial_shapes back (tests/test_module_gpu.py captures one module).
+        side = torch.cuda.Stream(device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            opt.zero_grad(set_to_none=True)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                if args.amp == "bf16":
+                    with torch.autocast("cuda", dtype=torch.bfloat16):
+                        static_loss = model(src, pos, enc_ref, shapes, lsi)
+                else:
+                    static_loss = model(src, pos, enc_ref, shapes, lsi)
+                static_loss.backward()
+        torch.cuda.current_stream(device).wait_stream(side)
+
+        def step():                                         # noqa: F811 (replaces the eager step for the timed loop)
+            graph.replay()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 0.1)
+            opt.step()
+            return static_loss
+        for _ in range(2):
+            loss = step()
     if not args.no_gc_freeze:
         gc.collect()
         gc.freeze()
@@ -225,6 +256,7 @@ def main():
                                        "dec": args.dec, "ballast_mb": args.ballast_mb, "amp": args.amp or None,
                                        "dropout": args.dropout, "layers": "plain" if args.plain_layers else "fused",
                                        "attention_modules": "python" if args.no_cpp_node else "cpp_node",
+                                       "launch": "hip graph of forward + backward" if args.graph else "eager",
                                        "gc_frozen": not args.no_gc_freeze,
                                        "vote": args.vote, "find_unused_parameters": args.find_unused,
                                        "reduce_dict": args.reduce_dict, "host_matcher": args.host_matcher},

@@ -53,7 +53,7 @@ def sweep(out_path):
                         fwd = lambda: _native.ms_deform_attn_forward(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], 64,
                                                                      with_table=True if table is not None else None)
                         bwd = lambda: _native.ms_deform_attn_backward(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], d["go"], 64, table=table)
-                        tf, tb = time_call(fwd, st), time_call(bwd, st)
+                        tf, tb = min(time_call(fwd, st), time_call(fwd, st)), min(time_call(bwd, st), time_call(bwd, st))   # (one-off hiccups of 20-300 us were seen on single measurements)
                         row = {"pyramid": pname, "regime": regime, "locations": locs, "N": N, "Lq": Lq, "S": S, "fwd_us": tf, "bwd_us": tb,
                                "samples_per_s": N / ((tf + tb) * 1e-6), "fwd_frac": fb / tf / 1e3 / 8000.0, "bwd_frac": bb / tb / 1e3 / 8000.0,
                                "plan": _native.describe_plan(N, S, 8, 32, len(shapes), Lq, 4), "table": table is not None}

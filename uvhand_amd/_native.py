@@ -33,7 +33,7 @@ _SYMBOLS = (
     "msda_prologue_supported", "msda_forward_prologue_f32", "msda_backward_prologue_f32",
     "msda_last_error", "msda_version", "msda_path_for", "msda_force_path", "msda_describe_plan",
     "msda_forward_workspace_bytes", "msda_forward_ws_f32", "msda_forward_ws_bf16", "msda_forward_prologue_ws_f32",
-    "msda_forward_prologue_ws_bf16", "msda_probe_row_gather",
+    "msda_forward_prologue_ws_bf16", "msda_probe_row_gather", "msda_launch_count",
 )
 
 
@@ -66,6 +66,7 @@ def load():
     lib.msda_linear_wgrad_workspace_bytes.argtypes = [ctypes.c_int] * 3
     lib.msda_forward_workspace_bytes.restype = ctypes.c_ulonglong
     lib.msda_forward_workspace_bytes.argtypes = [ctypes.c_int] * 7 + [ctypes.c_uint]
+    lib.msda_launch_count.restype = ctypes.c_ulonglong
     lib.msda_describe_plan.restype = ctypes.c_int
     lib.msda_describe_plan.argtypes = [ctypes.c_int] * 9 + [ctypes.c_uint, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
     _lib = lib
@@ -723,6 +724,11 @@ def probe_row_gather(table_bytes, device, row_bytes=128, blocks=4096, iters=16, 
         e1.record(stream)
         e1.synchronize()
     return rows.value * repeats / (e0.elapsed_time(e1) * 1e-3)
+
+
+def launch_count():
+    """msda_launch_count (include/msda.h): launches enqueued through the library by this process so far."""
+    return int((_lib or load()).msda_launch_count())
 
 
 def force_path(path):

@@ -4,6 +4,8 @@
 #include <cstring>
 #include <string>
 
+#include <atomic>
+
 #include "msda_launch.h"
 
 namespace msda {
@@ -25,8 +27,14 @@ static void begin_call()
     (void)hipGetLastError();
 }
 
+// Launches enqueued by this process through the library (every launcher ends in check_launch, once per kernel it queued or
+// per pair of dependent kernels): a diagnostic for tests ("a frozen projection costs no weight-gradient launch"), relaxed atomic.
+static std::atomic<unsigned long long> g_launch_checks{0};
+unsigned long long launch_checks() { return g_launch_checks.load(std::memory_order_relaxed); }
+
 int check_launch(const char *what)
 {
+    g_launch_checks.fetch_add(1, std::memory_order_relaxed);
     const hipError_t e = hipGetLastError();
     if (e == hipSuccess) return MSDA_OK;
     char buf[400];
@@ -720,6 +728,8 @@ int msda_path_for(int elem_bytes, int M, int D, int L, int P)
 }
 
 void msda_force_path(int path) { msda::g_force_path = path; }
+
+unsigned long long msda_launch_count(void) { return msda::launch_checks(); }
 
 int msda_describe_plan(int row_bytes, int grad_value_bytes, int N, int S, int M, int D, int L, int Lq, int P, unsigned flags,
                        int has_workspace, char *buf, int buf_len)

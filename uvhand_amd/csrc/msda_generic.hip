@@ -241,6 +241,12 @@ int launch_bwd_generic(const VT *grad_out, const VT *value, const int64_t *shape
     if (blocks * kGenericBlock > 0xffffffffLL) return set_error(MSDA_ERR_ARGUMENT, "N*Lq*M too large for one launch");
     if (deterministic) {
         const long long rows = (long long)N * S * M;
+        // brute force (rows x Lq*P point tests): bounded, so that a flag set for the whole program (torch.use_deterministic_
+        // algorithms) cannot silently turn an encoder-sized fp64 / odd-D call into seconds of work — refuse it like a framework
+        // refuses an op that has no deterministic form (include/msda.h, MSDA_FLAG_DETERMINISTIC)
+        if ((double)rows * (double)Lq * (double)P > 68719476736.0)       // 2^36 point tests, ~50 ms
+            return set_error(MSDA_ERR_ARGUMENT, "msda backward: MSDA_FLAG_DETERMINISTIC outside the D = 32 family tests every sampling point "
+                                                "against every pixel row (N*S*M x Lq*P > 2^36 here): use D = 32 fp32 / bf16 tensors or clear the flag");
         long long rblocks = (rows + kGenericItemsPerBlock - 1) / kGenericItemsPerBlock;
         if (rblocks > (1LL << 22)) rblocks = 1LL << 22;                  // the kernel strides over the rows
         hipLaunchKernelGGL((bwd_generic_kernel<T, VT, false>), dim3((unsigned)blocks), dim3(kGenericBlock), 0, stream,

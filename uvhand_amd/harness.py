@@ -11,6 +11,8 @@ the CPU tests) and contain no compute.
 """
 import os
 
+import socket
+
 import torch
 import torch.distributed as dist
 
@@ -92,25 +94,29 @@ def gather_objects(obj):
 
 def device_identity(device):
     """What tells two ranks' GPUs apart: index, name, PCI bus id and uuid where this torch exposes them."""
+    host = socket.gethostname()
     if device is None or device.type != "cuda":
-        return {"device": str(device), "index": None, "name": None, "pci_bus_id": None, "uuid": None}
+        return {"host": host, "device": str(device), "index": None, "name": None, "pci_bus_id": None, "uuid": None}
     props = torch.cuda.get_device_properties(device)
     bus = getattr(props, "pci_bus_id", None)
-    return {"device": str(device), "index": device.index, "name": props.name,
+    return {"host": host, "device": str(device), "index": device.index, "name": props.name,
             "pci_bus_id": None if bus is None else "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), bus,
                                                                        getattr(props, "pci_device_id", 0)),
             "uuid": str(getattr(props, "uuid", "")) or None}
 
 
 def duplicate_devices(identities):
-    """Pairs of ranks that sit on the same physical GPU (same uuid / PCI bus id, or — lacking both — same index)."""
+    """Pairs of ranks that sit on the same physical GPU: same HOST and same uuid / PCI bus id, or — lacking both — same
+    index.  (Bus ids and indices repeat from node to node, and some builds report a constant uuid: without the host a
+    multi-node job would see every node's GPU 0 as one device.)"""
     seen, dup = {}, []
     for rank, ident in enumerate(identities):
-        key = ident.get("uuid") or ident.get("pci_bus_id") or ident.get("index")
-        if key is None:
+        dev = ident.get("uuid") or ident.get("pci_bus_id") or ident.get("index")
+        if dev is None:
             continue
+        key = (ident.get("host"), dev)
         if key in seen:
-            dup.append((seen[key], rank, key))
+            dup.append((seen[key], rank, "%s on %s" % (dev, ident.get("host"))))
         else:
             seen[key] = rank
     return dup

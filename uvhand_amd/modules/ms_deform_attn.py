@@ -218,6 +218,10 @@ class MSDeformAttn(nn.Module):
         N, Len_q, _ = query.shape
         N, Len_in, _ = input_flatten.shape
         _check_shapes_sum(input_spatial_shapes, Len_in)
+        # reference points given once for all levels ([N, Len_q, 1, .]): the reference's arithmetic broadcasts them (:110-128);
+        # the fused paths index a row per level, so make the broadcast explicit (a view)
+        if reference_points.dim() == 4 and reference_points.shape[2] == 1 and self.n_levels > 1:
+            reference_points = reference_points.expand(-1, -1, self.n_levels, -1)
 
         ext = self._cpp_node(query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
                              input_padding_mask)
