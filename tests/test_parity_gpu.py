@@ -711,7 +711,7 @@ def test_backward_from_the_forward_table_equals_backward_from_a_scan(native, ora
     assert (table is not None) == ("fixed" in plan), plan
     base = native.ms_deform_attn_backward(v, s, i, l, a, go, 64)
     if table is not None:
-        assert table.numel() == N * M * L * Lq * P * 16
+        assert table.numel() >= N * M * L * Lq * P * 16                      # (+ the range header behind the point entries)
         got = native.ms_deform_attn_backward(v, s, i, l, a, go, 64, table=table)
         assert torch.equal(got[1], base[1]) and torch.equal(got[2], base[2])
         assert rel_err(got[0].float().cpu().numpy(), base[0].float().cpu().numpy()) < (4e-3 if bf16 else 1e-6)

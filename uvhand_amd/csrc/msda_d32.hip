@@ -75,6 +75,17 @@ struct alignas(16) BwdRec { int off[4]; float lh, lw, a, pad; };
 // entry ((b*M + m)*L + l) * Lq*P + q*P + p.  Role B of a small problem reads its level's entries coalesced instead of
 // re-deriving them from a strided scan of sampling_loc / attn_weight (msda_d32_value.h: bwd_value_small_body).
 struct alignas(16) PointEntry { int cell; float lh, lw, a; };   // cell: tap validity bits << 24 | (h0 * W + w0 + W + 1); 0 = no tap
+// Behind the point entries the table carries a small HEADER, written by one workgroup of the forward: for every role-B
+// workgroup slot s of a (batch, head) pair (s = level-and-range, value_block_to_range) the level geometry and pixel range that
+// workgroup would otherwise derive from spatial_shapes / level_start_index itself — ~550 scalar instructions per wavefront
+// (64-bit products, six integer divisions, the level walk) at the head of every role-B wavefront's life, a serial chain of
+// more than a microsecond (SQ counters with role B alone and its phases switched off, profiles/r04_notes.md).
+struct alignas(32) RangeEntry { int l, H, Wd, lstart, px0, npx, cap, pad; };   // npx = 0: nothing to do (the level does not fit, or an empty range)
+constexpr int kMaxRangeEntries = 254;                                          // W * L of a small problem's plan (else: no header)
+struct alignas(32) RangeHeader { int magic, W, L, tiled, tp_cap, pad[3]; };    // entries follow
+constexpr int kRangeMagic = 0x4d534441;
+__host__ __device__ inline size_t range_header_bytes() { return sizeof(RangeHeader) + (size_t)kMaxRangeEntries * sizeof(RangeEntry); }
+
 // The table entry of a point from its geometry (the same values the tap records are made of, so that the table and a scan
 // of sampling_loc / attn_weight give role B bit-identical records).
 __device__ __forceinline__ PointEntry entry_of(const PointGeom<float> &g, float a, int Wd, bool level_ok)
@@ -156,12 +167,24 @@ template <> struct BufRow<bf16_t> {
 // The tiled kernels' descriptor: the batch elements [b0, b1] a workgroup's items belong to (b0 = the first item's; a
 // workgroup rarely straddles a boundary).  d32_supported() admits only geometries whose widest such window stays below 2^31
 // bytes, so record offsets (relative to batch element b0) are plain 32-bit numbers.
+// A descriptor lives in scalar registers.  Its base and size here are uniform by construction (functions of the workgroup id
+// and kernel arguments) but reach the compiler through integer divisions and 64-bit multiplies it evaluates on the vector
+// unit — and a descriptor it cannot PROVE uniform makes every buffer load a "waterfall" loop (v_readfirstlane x4, v_cmp_eq_u64 x2,
+// s_and_saveexec, the load, s_cbranch: twelve instructions around each of sixteen loads — found in the ISA of round 4's first
+// buffer-load kernels, where it ate the whole gain).  uniform_rsrc() says so explicitly.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void *base, long long bytes)
+{
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    const int n = __builtin_amdgcn_readfirstlane((int)bytes);
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo), 0, n, kBufDword3);
+}
+
 template <typename VT>
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t value_window(const VT *value, int b0, int b1, int S, int M)
 {
     const long long slice = (long long)S * M * kD;                         // elements per batch element
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<VT *>(value) + (long long)b0 * slice, 0,
-                                             (int)((long long)(b1 - b0 + 1) * slice * (long long)sizeof(VT)), kBufDword3);
+    return uniform_rsrc(value + (long long)b0 * slice, (long long)(b1 - b0 + 1) * slice * (long long)sizeof(VT));
 }
 
 // byte offsets of a point's four tap rows inside that window (db = the item's batch element minus b0), kBufOob = absent
@@ -255,6 +278,46 @@ __device__ __forceinline__ float group_sum(float x, int width)
     for (int m = 1; m < width; m <<= 1) x += __shfl_xor(x, m, kWave);
     return x;
 }
+// (defined in msda_d32_value.h, role B's workgroup id -> level / range dealing)
+__device__ __forceinline__ void value_block_to_range(int bid, int W, int L, const int64_t *__restrict__ shapes, int &pr, int &l, int &ti,
+                                                     int &Wl, bool may_skew);
+
+// The header behind the point table: thread s < W*L works out slot s (one thread per slot: the level walk runs once per
+// launch, in parallel, instead of once per role-B wavefront).
+__device__ __forceinline__ void write_range_header(PointEntry *table, long long points, const int64_t *__restrict__ shapes,
+                                                   const int64_t *__restrict__ level_start, int S, int L, int W, int tp_cap, int rec_cap)
+{
+    RangeHeader *hdr = reinterpret_cast<RangeHeader *>(table + points);
+    RangeEntry *ent = reinterpret_cast<RangeEntry *>(hdr + 1);
+    const int s = threadIdx.x, T = W * L;
+    if (s == 0) {
+        long long run = 0;
+        bool tiled = true;                                   // every level fits and starts where the previous one ends, up to S
+        for (int k = 0; k < L; ++k) {
+            tiled = tiled && level_start[k] == run && level_fits(shapes[2 * k], shapes[2 * k + 1], level_start[k], S);
+            run += shapes[2 * k] * shapes[2 * k + 1];
+        }
+        RangeHeader h;
+        h.magic = kRangeMagic; h.W = W; h.L = L; h.tiled = (tiled && run == S) ? 1 : 0; h.tp_cap = tp_cap;
+        h.pad[0] = h.pad[1] = h.pad[2] = 0;
+        *hdr = h;
+    }
+    if (s < T && T <= kMaxRangeEntries) {
+        int pr, l, ti, Wl;
+        value_block_to_range(s, W, L, shapes, pr, l, ti, Wl, true);
+        RangeEntry e;
+        e.l = l; e.H = e.Wd = e.lstart = e.px0 = e.npx = e.cap = e.pad = 0;
+        if (level_fits(shapes[2 * l], shapes[2 * l + 1], level_start[l], S)) {
+            const int H = (int)shapes[2 * l], Wd = (int)shapes[2 * l + 1], HW = H * Wd;
+            const int px0 = (int)((unsigned)(ti * HW) / (unsigned)Wl), px1 = (int)((unsigned)((ti + 1) * HW) / (unsigned)Wl);
+            e.H = H; e.Wd = Wd; e.lstart = (int)level_start[l]; e.px0 = px0;
+            e.npx = (px1 - px0 > 0 && px1 - px0 <= tp_cap) ? px1 - px0 : 0;
+            e.cap = e.npx > 0 ? rec_cap / e.npx : 0;
+        }
+        ent[s] = e;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
@@ -265,16 +328,23 @@ __global__ __launch_bounds__(kBlock) void fwd_d32_kernel(
     const int64_t *__restrict__ level_start, const float *__restrict__ loc,
     const float *__restrict__ attn, int S, int M, int L, int Lq, int P, int items, int p_shift,
     int lp_shift, int m_shift, VT *__restrict__ out, const PrologueIn pro = PrologueIn{nullptr, nullptr, nullptr, 0, 0},
-    int xcd = 0, PointEntry *__restrict__ table = nullptr)
+    int xcd = 0, PointEntry *__restrict__ table = nullptr, int hdr_W = 0, int hdr_tp_cap = 0, int hdr_rec_cap = 0)
 {
     constexpr int IPW = 32 / SPLIT;                       // items per workgroup
+    // with a header to write the launch has ONE EXTRA workgroup that does only that: beside the others (it is done long before
+    // they are), not in front of one of them — as a prefix of workgroup 0 it made that workgroup, and with it the launch, 0.9 us longer
+    const int n_blocks = (int)gridDim.x - (hdr_W > 0 ? 1 : 0);
+    if (hdr_W > 0 && (int)blockIdx.x == n_blocks) {
+        write_range_header(table, (long long)items * L * P, shapes, level_start, S, L, hdr_W, hdr_tp_cap, hdr_rec_cap);
+        return;
+    }
     constexpr int OPW = 4 / SPLIT;                        // octets per workgroup
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *recs = smem;
     const int LP = L * P;
     const int item_stride = LP * kRecBytes + kItemPad;
     const int tid = threadIdx.x;
-    const int item0 = (xcd ? xcd_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x) * IPW;
+    const int item0 = (xcd ? xcd_block((int)blockIdx.x, n_blocks) : (int)blockIdx.x) * IPW;
     MSDA_STAMP_AT(2, 0);
     const int LqM = Lq * M;
     const int b0 = item0 / LqM, r0 = item0 - b0 * LqM, m0 = item0 % M;      // uniform (scalar unit)
@@ -573,21 +643,23 @@ __global__ __launch_bounds__(kSBlock, 4) void bwd_fused_d32_kernel(
     const float *__restrict__ loc, const float *__restrict__ attn, int S, int M, int L, int Lq,
     int P, int items, int p_shift, int lp_shift, int m_shift, int tp_cap, int W, int nB,
     GT *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attn,
-    const PrologueOut pro = PrologueOut{nullptr, 0, 0}, int xcd = 0, const PointEntry *__restrict__ table = nullptr)
+    const PrologueOut pro = PrologueOut{nullptr, 0, 0}, int xcd = 0, const PointEntry *__restrict__ table = nullptr,
+    const RangeHeader *__restrict__ header = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int bid = (int)blockIdx.x;
     MSDA_SKIP_ROLE(bid < nB);
     if (bid < nB) {
         if (xcd) bid = xcd_block(bid, nB);
-        int pr, l, ti, Wl;
-        value_block_to_range(bid, W, L, shapes, pr, l, ti, Wl, ACC != kAccWide);
-        if constexpr (FIXED)                          // small problems (plan_fused): every workgroup of the launch resident
-            bwd_value_small_body<VT, GT>(grad_out, shapes, level_start, loc, attn, table, S, M, L, Lq, P, p_shift, tp_cap, grad_value,
-                                         ti, Wl, l, pr, smem);
-        else
+        if constexpr (FIXED) {                        // small problems (plan_fused): every workgroup of the launch resident
+            bwd_value_small_body<VT, GT>(grad_out, shapes, level_start, loc, attn, table, header, S, M, L, Lq, P, p_shift, tp_cap,
+                                         grad_value, bid, W, smem);
+        } else {
+            int pr, l, ti, Wl;
+            value_block_to_range(bid, W, L, shapes, pr, l, ti, Wl, ACC != kAccWide);
             bwd_value_body<ACC, kSinglePPT, VT, GT, false, DET>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift,
                                                                 tp_cap, grad_value, ti, Wl, l, pr, smem);
+        }
     } else {
         // role A never touches grad_value unless it scatters with atomics (separate kernel, MSDA_BWD_MODE=atomic)
         bwd_query_body<SPLIT, false, kSBlock, VT, FUSED>(grad_out, value, shapes, level_start, loc, attn, S, M, L, Lq, P,
@@ -753,6 +825,16 @@ static int launch_query_lds(const LdsPlan &lp, const VT *grad_out, const VT *val
     return check_launch("msda backward (d32, query-major, LDS stage)");
 }
 
+// ranges per level / rows per range of the backward's role-B plan, for the header the forward writes behind the point table
+// (0: no header — the plan has more slots than the header holds)
+static void table_header_plan(int N, int S, int M, int L, int Lq, int P, int &W, int &tp_cap);
+// the header behind the point entries of a table (null: no table, or a plan with more slots than the header holds)
+static const RangeHeader *table_header_of(const PointEntry *table, int N, int M, int L, int Lq, int P, int W)
+{
+    if (!table || W * L > kMaxRangeEntries) return nullptr;
+    return reinterpret_cast<const RangeHeader *>(table + (long long)N * M * L * Lq * P);
+}
+
 template <typename VT>
 static int launch_fwd_d32_t(const VT *value, const int64_t *shapes, const int64_t *level_start,
                             const float *loc, const float *attn, int N, int S, int M, int L, int Lq, int P,
@@ -767,11 +849,13 @@ static int launch_fwd_d32_t(const VT *value, const int64_t *shapes, const int64_
     const int split = pick_split(items, LP);
     const int ipw = 32 / split;
     const size_t lds = (size_t)ipw * item_stride + (split > 1 ? 4096 : 0);
-    const dim3 grid((items + ipw - 1) / ipw), block(kBlock);
+    int hdr_W = 0, hdr_tp_cap = 0;
+    if (table) table_header_plan(N, S, M, L, Lq, P, hdr_W, hdr_tp_cap);
+    const dim3 grid((items + ipw - 1) / ipw + (hdr_W > 0 ? 1 : 0)), block(kBlock);      // (+ the header's workgroup)
 #define MSDA_LAUNCH_FWD(SP)                                                                            \
     hipLaunchKernelGGL((fwd_d32_kernel<SP, VT>), grid, block, lds, stream, value, shapes, level_start, loc, attn, \
                        S, M, L, Lq, P, items, pow2_shift(P), pow2_shift(LP), pow2_shift(M), out,                  \
-                       PrologueIn{nullptr, nullptr, nullptr, 0, 0}, xcd, table)
+                       PrologueIn{nullptr, nullptr, nullptr, 0, 0}, xcd, table, hdr_W, hdr_tp_cap, kSmallRecCap)
     const int xcd = xcd_remap();
     if (split == 4) MSDA_LAUNCH_FWD(4); else if (split == 2) MSDA_LAUNCH_FWD(2); else MSDA_LAUNCH_FWD(1);
 #undef MSDA_LAUNCH_FWD
@@ -862,6 +946,13 @@ static FusedPlan plan_fused(int items, int LP, int split, long long nB, int acc,
 // per-head reference-point gradients of the fused-prologue backward on large problems, padded to 16 bytes
 static size_t prologue_heads_bytes(int N, int M, int L, int Lq) { return ((size_t)N * Lq * M * L * sizeof(float2) + 15) & ~(size_t)15; }
 
+static void table_header_plan(int N, int S, int M, int L, int Lq, int P, int &W, int &tp_cap)
+{
+    const ValuePlan pl = plan_value<float>(N, S, M, L, Lq, P, bwd_target_wgs(), false);
+    W = pl.W * L <= kMaxRangeEntries ? pl.W : 0;
+    tp_cap = pl.tp_cap;
+}
+
 #if MSDA_D32_HAS(0)
 // Bytes of the point table a forward of this geometry can leave for its backward (msda_forward_workspace_bytes): non-zero
 // exactly where the backward would take the small-problem role B (plan_fused.fixed: single pass, every workgroup resident,
@@ -874,8 +965,9 @@ size_t forward_table_bytes(int N, int S, int M, int D, int L, int Lq, int P, boo
     const ValuePlan pl = plan_value<float>(N, S, M, L, Lq, P, bwd_target_wgs(), false);
     if (pl.acc != kAccNone || pl.ppt != kSinglePPT) return 0;
     const FusedPlan fp = plan_fused(N * Lq * M, L * P, pick_split(N * Lq * M, L * P), (long long)pl.W * N * M * L, pl.acc, prologue ? M : 0, false);
-    return fp.fixed ? (size_t)N * M * L * Lq * P * sizeof(PointEntry) : 0;
+    return fp.fixed ? (size_t)N * M * L * Lq * P * sizeof(PointEntry) + range_header_bytes() : 0;
 }
+
 
 size_t backward_workspace_bytes(int N, int S, int M, int D, int L, int Lq, int P, unsigned flags)
 {
@@ -959,7 +1051,7 @@ static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *
                 hipLaunchKernelGGL((bwd_fused_d32_kernel<SP, AC, VT, false, GT, FX, DT>), fgrid, dim3(kSBlock), flds, stream,  \
                                    grad_out, value, shapes, level_start, loc, attn, S, M, L, Lq, P, items, ps, lps, ms,  \
                                    pl.tp_cap, pl.W, (int)nB, grad_value, grad_loc, grad_attn, PrologueOut{nullptr, 0, 0}, xcd,  \
-                                   (FX) ? table : nullptr); } while (0)
+                                   (FX) ? table : nullptr, (FX) ? table_header_of(table, N, M, L, Lq, P, pl.W) : nullptr); } while (0)
                 // (FX, the short sort, is never planned together with the deterministic flag)
 #define MSDA_LAUNCH_F(SP, AC, FX) do { if (deterministic && !(FX)) MSDA_LAUNCH_F_(SP, AC, false, true); else MSDA_LAUNCH_F_(SP, AC, FX, false); } while (0)
                 if (fp.fixed)                { if (fp.split == 4) MSDA_LAUNCH_F(4, kAccNone, true); else if (fp.split == 2) MSDA_LAUNCH_F(2, kAccNone, true); else MSDA_LAUNCH_F(1, kAccNone, true); }
@@ -1043,14 +1135,17 @@ static int launch_fwd_prologue_t(const VT *value, const int64_t *shapes, const i
     const int split = pick_split(items, LP);
     const int ipw = 32 / split;
     const size_t lds = (size_t)ipw * item_stride + (split > 1 ? 4096 : 0);
-    const dim3 grid((items + ipw - 1) / ipw), block(kBlock);
+    int hdr_W = 0, hdr_tp_cap = 0;
+    if (table) table_header_plan(N, S, M, L, Lq, P, hdr_W, hdr_tp_cap);
+    const dim3 grid((items + ipw - 1) / ipw + (hdr_W > 0 ? 1 : 0)), block(kBlock);      // (+ the header's workgroup)
     const PrologueIn pro{ref, loc_out, attn_out, (int)((ld_offsets - 2LL * M * LP) / 2), (int)(ld_logits - (long long)M * LP)};
     const LdsPlan lp = plan_lds<VT>(N, S, M, L, Lq, P);
     if (lp.use) return launch_fwd_lds<VT, true>(lp, value, shapes, level_start, offsets, logits, N, S, M, L, Lq, P, out, pro, stream);
     const int xcd = xcd_remap();
 #define MSDA_LAUNCH_FP(SP)                                                                             \
     hipLaunchKernelGGL((fwd_d32_kernel<SP, VT, true>), grid, block, lds, stream, value, shapes, level_start, offsets, \
-                       logits, S, M, L, Lq, P, items, pow2_shift(P), pow2_shift(LP), pow2_shift(M), out, pro, xcd, table)
+                       logits, S, M, L, Lq, P, items, pow2_shift(P), pow2_shift(LP), pow2_shift(M), out, pro, xcd, table,   \
+                       hdr_W, hdr_tp_cap, kSmallRecCap)
     if (split == 4) MSDA_LAUNCH_FP(4); else if (split == 2) MSDA_LAUNCH_FP(2); else MSDA_LAUNCH_FP(1);
 #undef MSDA_LAUNCH_FP
     return check_launch("msda forward (d32, fused prologue)");
@@ -1110,7 +1205,8 @@ static int launch_bwd_prologue_t(const VT *grad_out, const VT *value, const int6
     do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_fused_d32_kernel<SP, AC, VT, true, float, FX, DT>), flds)) return rc; \
     hipLaunchKernelGGL((bwd_fused_d32_kernel<SP, AC, VT, true, float, FX, DT>), fgrid, dim3(kSBlock), flds, stream, grad_out, \
                        value, shapes, level_start, loc, attn, S, M, L, Lq, P, items, ps, lps, ms, pl.tp_cap, pl.W, (int)nB,  \
-                       grad_value, grad_offsets, grad_logits, pro, xcd_remap(), (FX) ? table : nullptr); } while (0)
+                       grad_value, grad_offsets, grad_logits, pro, xcd_remap(), (FX) ? table : nullptr,                          \
+                       (FX) ? table_header_of(table, N, M, L, Lq, P, pl.W) : nullptr); } while (0)
     if (fp.fixed)                { if (fp.split == 4) MSDA_LAUNCH_BP(4, kAccNone, true); else if (fp.split == 2) MSDA_LAUNCH_BP(2, kAccNone, true); else MSDA_LAUNCH_BP(1, kAccNone, true); }
     else if (pl.acc == kAccNone) { if (fp.split == 4) MSDA_LAUNCH_BP(4, kAccNone, false); else if (fp.split == 2) MSDA_LAUNCH_BP(2, kAccNone, false); else MSDA_LAUNCH_BP(1, kAccNone, false); }
     else if (pl.acc == kAccWide) { if (fp.split == 4) MSDA_LAUNCH_BP(4, kAccWide, false); else if (fp.split == 2) MSDA_LAUNCH_BP(2, kAccWide, false); else MSDA_LAUNCH_BP(1, kAccWide, false); }

@@ -187,8 +187,7 @@ __global__ __launch_bounds__(kLBlock, 4) void fwd_d32_lds_kernel(
     __syncthreads();
     lds_stage_rows<VT>(value, tab, L, S, M, b, m, stage);
     if (tid < 8) Row<VT>::store(stage + stage_rows * kD + tid * 4, make_float4(0.f, 0.f, 0.f, 0.f));
-    const __amdgpu_buffer_rsrc_t vbuf = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<VT *>(value) + (long long)b * S * M * kD, 0, (int)((long long)S * M * kD * sizeof(VT)), kBufDword3);
+    const __amdgpu_buffer_rsrc_t vbuf = uniform_rsrc(value + (long long)b * S * M * kD, (long long)S * M * kD * (long long)sizeof(VT));
     const float2 *loc2 = reinterpret_cast<const float2 *>(loc);
     const unsigned char *rb = recs + grp * item_stride;
     const unsigned char *stage_b = reinterpret_cast<const unsigned char *>(stage);
@@ -297,8 +296,7 @@ __device__ __forceinline__ void bwd_query_lds_body(
     __syncthreads();
     lds_stage_rows<VT>(value, tab, L, S, M, b, m, stage);
     if (tid < 8) Row<VT>::store(stage + stage_rows * kD + tid * 4, make_float4(0.f, 0.f, 0.f, 0.f));
-    const __amdgpu_buffer_rsrc_t vbuf = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<VT *>(value) + (long long)b * S * M * kD, 0, (int)((long long)S * M * kD * sizeof(VT)), kBufDword3);
+    const __amdgpu_buffer_rsrc_t vbuf = uniform_rsrc(value + (long long)b * S * M * kD, (long long)S * M * kD * (long long)sizeof(VT));
     const float2 *loc2 = reinterpret_cast<const float2 *>(loc);
     unsigned char *rb = recs + grp * item_stride;
     const unsigned char *stage_b = reinterpret_cast<const unsigned char *>(stage);

@@ -180,8 +180,7 @@ template <typename VT>
 __device__ __forceinline__ GoBuf<VT> pair_rows(const VT *grad_out, long long item_base, int Lq, int M, int j)
 {
     const long long bytes = (((long long)Lq - 1) * M + 1) * kD * (long long)sizeof(VT);
-    return GoBuf<VT>{__builtin_amdgcn_make_buffer_rsrc(const_cast<VT *>(grad_out) + item_base * kD, 0, (int)bytes, kBufDword3),
-                     (unsigned)(j * 4 * sizeof(VT)), M * kD * (int)sizeof(VT), Lq};
+    return GoBuf<VT>{uniform_rsrc(grad_out + item_base * kD, bytes), (unsigned)(j * 4 * sizeof(VT)), M * kD * (int)sizeof(VT), Lq};
 }
 
 template <int SLOTS, int ACC, typename VT, typename GT, int NR1 = 2, typename GO = GoBuf<VT>>
@@ -221,8 +220,11 @@ __device__ __forceinline__ void gather_rows(const GO go, GT *__restrict__ gv_bas
             for (int r = 0; r < NR; ++r)
 #pragma unroll
                 for (int u = 0; u < CH; ++u) {
-                    e[r][u].w = 0.f; e[r][u].q = go.none();
-                    if (i0 + u * SLOTS < n[r]) e[r][u] = rp[r][i0 + u * SLOTS];
+                    // unconditional read + two selects (a slot past the row's records still lies inside the LDS arrays: the
+                    // record array is followed by the overflow list); a guarded read costs an exec-mask round trip per slot
+                    const SRec t = rp[r][i0 + u * SLOTS];
+                    const bool ok = i0 + u * SLOTS < n[r];
+                    e[r][u].w = ok ? t.w : 0.f; e[r][u].q = ok ? t.q : go.none();
                 }
 #pragma unroll
             for (int r = 0; r < NR; ++r)
@@ -269,7 +271,7 @@ __device__ __forceinline__ void gather_rows(const GO go, GT *__restrict__ gv_bas
                     float4 *t = reinterpret_cast<float4 *>(tile) + d * 8 + j;
                     if (first_pass) *t = acc[r]; else { float4 o = *t; add4(o, acc[r]); *t = o; }
                 } else {
-                    GT *pr = gv_base + (long long)d * row_stride;
+                    GT *pr = gv_base + (long long)__mul24(d, row_stride);      // (rows per workgroup and M*32 are both far below 2^23)
                     if (ACC == kAccRmw && !first_pass) add4(acc[r], Row<GT>::load(pr));
                     Row<GT>::store(pr, acc[r]);
                 }
@@ -687,8 +689,9 @@ __device__ __forceinline__ void small_weights(const PointEntry &e, float (&tw)[4
 template <typename VT, typename GT>
 __device__ __forceinline__ void bwd_value_small_body(
     const VT *__restrict__ grad_out, const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
-    const float *__restrict__ loc, const float *__restrict__ attn, const PointEntry *__restrict__ table, int S, int M, int L, int Lq,
-    int P, int p_shift, int tp_cap, GT *__restrict__ grad_value, int ti, int W, int l, int pr, unsigned char *smem)
+    const float *__restrict__ loc, const float *__restrict__ attn, const PointEntry *__restrict__ table,
+    const RangeHeader *__restrict__ header, int S, int M, int L, int Lq, int P, int p_shift, int tp_cap, GT *__restrict__ grad_value,
+    int bid, int W_plan, unsigned char *smem)
 {
     // LDS: [cnt tp_cap] [start tp_cap] [wsum 32] [rec kSmallRecCap] [ovf kOvfCap] [listed points: 8 x kSmallListCap entries] [their queries]
     int *cnt = reinterpret_cast<int *>(smem);
@@ -702,15 +705,31 @@ __device__ __forceinline__ void bwd_value_small_body(
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = tid & 7;
     MSDA_STAMP(0);
-    const int H = (int)shapes[2 * l], Wd = (int)shapes[2 * l + 1], lstart = (int)level_start[l];
-    const int HW = H * Wd;
-    const int px0 = (int)((unsigned)(ti * HW) / (unsigned)W), px1 = (int)((unsigned)((ti + 1) * HW) / (unsigned)W);
-    const int npx = px1 - px0;
-    const int b = pr / M, m = pr - b * M;
-    if (l == 0 && ti == 0) zero_uncovered_rows<GT, kSBlock>(shapes, level_start, S, M, L, grad_value, b, m);
-    const bool level_ok = level_fits(shapes[2 * l], shapes[2 * l + 1], level_start[l], S);
-    if (npx <= 0 || npx > tp_cap || !level_ok) return;
     const int NP = Lq * P;                                                   // <= kSingleMaxPoints (the host's plan)
+    // ---- which rows are mine: from the header the forward left behind the point table (one 32-byte entry), or worked out here ----
+    int l, H, Wd, lstart, px0, npx, cap;
+    const int T = W_plan * L;
+    // slot decode without an integer division: bid < 2^16 and T <= 254 on this path, so floor((bid + 0.5) / T) is exact in float
+    const int pr = __builtin_amdgcn_readfirstlane((int)(((float)bid + 0.5f) * __builtin_amdgcn_rcpf((float)T)));
+    const int slot = bid - pr * T;
+    const int b = __builtin_amdgcn_readfirstlane((int)(((float)pr + 0.5f) * __builtin_amdgcn_rcpf((float)M))), m = pr - b * M;
+    if (header && header->magic == kRangeMagic && header->W == W_plan && header->L == L && header->tp_cap == tp_cap) {
+        const RangeEntry e = reinterpret_cast<const RangeEntry *>(header + 1)[slot];
+        l = e.l; H = e.H; Wd = e.Wd; lstart = e.lstart; px0 = e.px0; npx = e.npx; cap = e.cap;
+        if (slot == 0 && !header->tiled) zero_uncovered_rows<GT, kSBlock>(shapes, level_start, S, M, L, grad_value, b, m);
+        if (npx <= 0) return;
+    } else {
+        int pr2, ti, Wl;
+        value_block_to_range(bid, W_plan, L, shapes, pr2, l, ti, Wl, true);
+        H = (int)shapes[2 * l]; Wd = (int)shapes[2 * l + 1]; lstart = (int)level_start[l];
+        const int HW = H * Wd;
+        px0 = (int)((unsigned)(ti * HW) / (unsigned)Wl);
+        npx = (int)((unsigned)((ti + 1) * HW) / (unsigned)Wl) - px0;
+        if (l == 0 && ti == 0) zero_uncovered_rows<GT, kSBlock>(shapes, level_start, S, M, L, grad_value, b, m);
+        const bool level_ok = level_fits(shapes[2 * l], shapes[2 * l + 1], level_start[l], S);
+        if (npx <= 0 || npx > tp_cap || !level_ok) return;
+        cap = kSmallRecCap / npx;
+    }
     const long long item_base = (long long)b * Lq * M + m;                   // item(q) = item_base + q*M
     const int row_stride = M * kD;
     const GoBuf<VT> go = pair_rows<VT>(grad_out, item_base, Lq, M, j);
@@ -739,8 +758,7 @@ __device__ __forceinline__ void bwd_value_small_body(
     __syncthreads();
     MSDA_STAMP(1);
 
-    const int cap = kSmallRecCap / npx;                                      // slots per row (uniform); below four: the general body
-    if (cap >= 4) {
+    if (cap >= 4) {                                                          // slots per row (uniform); below four: the general body
         // one point's taps -> ranks from the histogram atomics -> records in their slots
         int mine_taps = 0;
         auto sort_point = [&](const PointEntry &e, int q, const int (&dest)[4]) {
@@ -802,10 +820,10 @@ __device__ __forceinline__ void bwd_value_small_body(
         const int novf = *novf_p;
         if (novf <= kOvfCap) {
             if (MSDA_DIAG(4)) return;
-            const int mean2f = (2 * *total_p) / npx;
-            if (mean2f <= 8)       gather_rows<1, kAccNone, VT, GT, MSDA_GATHER_NR1>(go, gv_base, cnt, start, rec, nullptr, npx, row_stride, true, cap, ovf, novf);
-            else if (mean2f <= 16) gather_rows<2, kAccNone, VT, GT, 2>(go, gv_base, cnt, start, rec, nullptr, npx, row_stride, true, cap, ovf, novf);
-            else if (mean2f <= 32) gather_rows<4, kAccNone, VT, GT, 2>(go, gv_base, cnt, start, rec, nullptr, npx, row_stride, true, cap, ovf, novf);
+            const int taps = *total_p;                       // lanes per row from the mean records per row (no division: 2*taps/npx <= k)
+            if (taps <= 4 * npx)       gather_rows<1, kAccNone, VT, GT, MSDA_GATHER_NR1>(go, gv_base, cnt, start, rec, nullptr, npx, row_stride, true, cap, ovf, novf);
+            else if (taps <= 8 * npx)  gather_rows<2, kAccNone, VT, GT, 2>(go, gv_base, cnt, start, rec, nullptr, npx, row_stride, true, cap, ovf, novf);
+            else if (taps <= 16 * npx) gather_rows<4, kAccNone, VT, GT, 2>(go, gv_base, cnt, start, rec, nullptr, npx, row_stride, true, cap, ovf, novf);
             else                   gather_rows<8, kAccNone, VT, GT, 2>(go, gv_base, cnt, start, rec, nullptr, npx, row_stride, true, cap, ovf, novf);
             MSDA_STAMP(5);
             return;
@@ -815,8 +833,12 @@ __device__ __forceinline__ void bwd_value_small_body(
     // ---- taps piled on few pixels (the overflow list filled up), or a level too fine for four slots per row: the general
     // single-pass body (prefix-sum sort over a 4*Lq*P record array; the launch's LDS covers both layouts) from the top ----
     __syncthreads();
-    bwd_value_body<kAccNone, kSinglePPT, VT, GT, false, false>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, tp_cap,
-                                                               grad_value, ti, W, l, pr, smem);
+    {
+        int pr2, l2, ti2, Wl2;
+        value_block_to_range(bid, W_plan, L, shapes, pr2, l2, ti2, Wl2, true);
+        bwd_value_body<kAccNone, kSinglePPT, VT, GT, false, false>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, tp_cap,
+                                                                   grad_value, ti2, Wl2, l2, pr2, smem);
+    }
 }
 
 // ---- kAccWide: single pass by KEPT taps ----------------------------------------------------------------------
