@@ -261,8 +261,10 @@ def measure_op(workload, dtype, device, stream, seed, locations="uniform", budge
 
     vd, ld, ad = value.detach(), loc.detach(), attn.detach()
     gv32 = bf16 and _native.backward_passes(Lq, P) > 1
-    fwd = lambda: _native.ms_deform_attn_forward(vd, d["shapes"], d["lsi"], ld, ad, 64)
-    bwd = lambda: _native.ms_deform_attn_backward(vd, d["shapes"], d["lsi"], ld, ad, go, 64, fp32_grad_value=gv32)
+    # the two kernels as the autograd step runs them: the forward leaves its point table where the backward's plan reads one
+    table = _native.ms_deform_attn_forward(vd, d["shapes"], d["lsi"], ld, ad, 64, with_table=True)[1]
+    fwd = lambda: _native.ms_deform_attn_forward(vd, d["shapes"], d["lsi"], ld, ad, 64, with_table=True if table is not None else None)
+    bwd = lambda: _native.ms_deform_attn_backward(vd, d["shapes"], d["lsi"], ld, ad, go, 64, fp32_grad_value=gv32, table=table)
     row = {"workload": workload, "dtype": dtype, "locations": locations, "N": N, "Lq": Lq, "S": S}
     with torch.cuda.stream(stream):
         for name, fn in (("step", step), ("fwd", fwd), ("bwd", bwd)):
@@ -466,11 +468,13 @@ def main():
         vd, ld, ad = value.detach(), loc.detach(), attn.detach()
         if bf16:
             ld, ad = ld.float(), ad.float()
-        fwd = lambda: _native.ms_deform_attn_forward(vd, shapes, lsi, ld, ad, 64)
+        # (as the autograd step runs them: the forward leaves its point table where the backward's plan reads one)
+        table = _native.ms_deform_attn_forward(vd, shapes, lsi, ld, ad, 64, with_table=True)[1]
+        fwd = lambda: _native.ms_deform_attn_forward(vd, shapes, lsi, ld, ad, 64, with_table=True if table is not None else None)
         # bf16 rows: the kernel variant MSDeformAttnBF16Function picks for a bf16 `value` (fp32 grad_value
         # when the backward takes several passes)
         gv32 = bf16 and _native.backward_passes(Lq, P) > 1
-        bwd = lambda: _native.ms_deform_attn_backward(vd, shapes, lsi, ld, ad, go, 64, fp32_grad_value=gv32)
+        bwd = lambda: _native.ms_deform_attn_backward(vd, shapes, lsi, ld, ad, go, 64, fp32_grad_value=gv32, table=table)
         kt = {}
         for name, fn in (("fwd", fwd), ("bwd", bwd)):
             g2 = None
@@ -541,6 +545,7 @@ def main():
         # (fwd + bwd tensors, ~23 MB at cfg-2) sits in the 8 L2s / the 256 MB Infinity Cache (BASELINE.md says to state this).
         working_set = fwd_b + bwd_b - esize * (N * S * M * D + N * Lq * M * D) - 4 * 3 * N * Lq * M * L * P   # inputs counted once
         result["roofline"]["cache_resident"] = True
+        result["roofline"]["forward_table_bytes"] = int(table.numel()) if table is not None else 0   # extra (not algorithmic) traffic: written by the forward, read by the backward
         result["roofline"]["working_set_bytes"] = working_set
         if world == 1:
             result["roofline"]["copy_GBps_measured"] = copy_bandwidth_gbs(device)
