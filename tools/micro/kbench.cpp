@@ -117,7 +117,7 @@ int main(int argc, char **argv)
             double gs[16][5] = {{0}}, gm[16] = {0}; int gn[16] = {0};
             for (int b = 0; b < nBb && b < 65536; ++b) {
                 const unsigned long long *t = &hsb[b * 8];
-                if (!t[0] || !t[5]) continue;
+                if (!t[0] || !t[1] || !t[2] || !t[3] || !t[4] || !t[5]) continue;   // (a workgroup that had nothing to do stamps only its ends)
                 const int x = b & 7, idx = b >> 3, q = nBb >> 3, r = nBb & 7, logical = x * q + (x < r ? x : r) + idx;
                 // same dealing as value_block_to_range (msda_d32.hip) for a pyramid whose level 0 is the largest
                 const int sl = logical % (W * L); int lvl = 0, base = 0;

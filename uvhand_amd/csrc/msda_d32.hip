@@ -612,6 +612,7 @@ __global__ __launch_bounds__(kBlock) void bwd_query_d32_kernel(
 }  // namespace msda
 #include "msda_d32_lds.h"        // large problems: forward and role A with the coarse levels served from LDS
 #include "msda_d32_value.h"      // role B, per-tap records: gathers, bwd_value_body, bwd_value_wide_body, value_block_to_range
+#include "msda_d32_dense.h"      // role B, coarse levels: [pixels x queries] weights x grad_out on the matrix cores
 namespace msda {
 
 template <int ACC, int PPT, typename VT, typename GT = VT, bool DET = false>
@@ -675,15 +676,23 @@ __global__ __launch_bounds__(kSBlock, 4) void bwd_fused_lds_d32_kernel(
     const VT *__restrict__ grad_out, const VT *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ level_start, const float *__restrict__ loc, const float *__restrict__ attn, int S, int M, int L,
     int Lq, int P, int p_shift, int lp_shift, int tp_cap, int W, int nB, int chunks, int qw, int stage_rows,
-    GT *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attn, const PrologueOut pro, int xcd)
+    GT *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attn, const PrologueOut pro, int xcd,
+    int lds_bytes)
 {
     static_assert(kSBlock == kLBlock, "both roles run in 512-thread workgroups");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int bid = (int)blockIdx.x;
+    MSDA_SKIP_ROLE(bid < nB);
     if (bid < nB) {
         if (xcd) bid = xcd_block(bid, nB);
         int pr, l, ti, Wl;
         value_block_to_range(bid, W, L, shapes, pr, l, ti, Wl, ACC != kAccWide);
+        // a level of a few dozen pixels: its taps are a dense [pixels x queries] matrix — matrix cores (msda_d32_dense.h)
+        if (!MSDA_DIAG(7) && dense_level(shapes[2 * l], shapes[2 * l + 1], level_start[l], S, Wl, lds_bytes)) {
+            if (l == 0 && ti == 0) zero_uncovered_rows<GT, kSBlock>(shapes, level_start, S, M, L, grad_value, pr / M, pr % M);
+            bwd_value_dense_body<VT, GT>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, grad_value, ti, Wl, l, pr, smem);
+            return;
+        }
         bwd_value_body<ACC, kSinglePPT, VT, GT, false, DET>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift,
                                                             tp_cap, grad_value, ti, Wl, l, pr, smem);
     } else {
@@ -723,6 +732,13 @@ static int env_int(const char *name, int dflt) { return tuning_int(name, dflt); 
 static int bwd_target_wgs()
 {
     static const int v = [] { int t = env_int("MSDA_BWD_WGS", 256); return t < 1 ? 1 : t; }();
+    return v;
+}
+
+// coarse levels on the matrix cores (msda_d32_dense.h); MSDA_DENSE=0: every level through the sort + gather bodies (A/B knob)
+static int dense_on()
+{
+    static const int v = env_int("MSDA_DENSE", 1) != 0;
     return v;
 }
 
@@ -1021,13 +1037,14 @@ static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *
         if (bwd_mode == 0 && lds_a.use && pl.ppt == kSinglePPT && (pl.acc == kAccNone || pl.acc == kAccWide) &&
             nB + (long long)N * M * lds_a.chunks <= 0x7fffffffLL) {
             const dim3 fgrid((unsigned)(nB + (long long)N * M * lds_a.chunks));
-            const size_t flds = pl.lds > lds_a.lds ? pl.lds : lds_a.lds;
+            // (at least what the dense coarse-level body needs: two such workgroups still share a CU)
+            const size_t flds = max(max(pl.lds, lds_a.lds), (size_t)dense_lds_bytes());
 #define MSDA_LAUNCH_FLD_(AC, NS_, DT)                                                                  \
             do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_fused_lds_d32_kernel<AC, VT, false, GT, NS_, DT>), flds)) return rc; \
             hipLaunchKernelGGL((bwd_fused_lds_d32_kernel<AC, VT, false, GT, NS_, DT>), fgrid, dim3(kSBlock), flds, stream, grad_out,  \
                                value, shapes, level_start, loc, attn, S, M, L, Lq, P, ps, lps, pl.tp_cap, pl.W, (int)nB,          \
                                lds_a.chunks, lds_a.qw, lds_a.stage_rows, grad_value, grad_loc, grad_attn,                        \
-                               PrologueOut{nullptr, 0, 0}, xcd); } while (0)
+                               PrologueOut{nullptr, 0, 0}, xcd, dense_on() ? (int)flds : 0); } while (0)
 #define MSDA_LAUNCH_FLD(AC, NS_) do { if (deterministic) MSDA_LAUNCH_FLD_(AC, NS_, true); else MSDA_LAUNCH_FLD_(AC, NS_, false); } while (0)
             const bool one_slot = 8 * LP <= kWave;
             if (pl.acc == kAccNone) { if (one_slot) MSDA_LAUNCH_FLD(kAccNone, 1); else MSDA_LAUNCH_FLD(kAccNone, 2); }
@@ -1179,13 +1196,13 @@ static int launch_bwd_prologue_t(const VT *grad_out, const VT *value, const int6
         (pl.acc == kAccNone || pl.acc == kAccWide) && nB + (long long)N * M * lq.chunks <= 0x7fffffffLL) {
         const PrologueOut pro_h{static_cast<float *>(workspace), pro.off_pad, pro.log_pad};
         const dim3 lgrid((unsigned)(nB + (long long)N * M * lq.chunks));
-        const size_t llds = pl.lds > lq.lds ? pl.lds : lq.lds;
+        const size_t llds = max(max(pl.lds, lq.lds), (size_t)dense_lds_bytes());
 #define MSDA_LAUNCH_BPL(AC, NS_) do { if (deterministic) MSDA_LAUNCH_BPL_(AC, NS_, true); else MSDA_LAUNCH_BPL_(AC, NS_, false); } while (0)
 #define MSDA_LAUNCH_BPL_(AC, NS_, DT)                                                                  \
         do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_fused_lds_d32_kernel<AC, VT, true, float, NS_, DT>), llds)) return rc; \
         hipLaunchKernelGGL((bwd_fused_lds_d32_kernel<AC, VT, true, float, NS_, DT>), lgrid, dim3(kSBlock), llds, stream, grad_out,   \
                            value, shapes, level_start, loc, attn, S, M, L, Lq, P, ps, lps, pl.tp_cap, pl.W, (int)nB, lq.chunks,   \
-                           lq.qw, lq.stage_rows, grad_value, grad_offsets, grad_logits, pro_h, xcd_remap()); } while (0)
+                           lq.qw, lq.stage_rows, grad_value, grad_offsets, grad_logits, pro_h, xcd_remap(), dense_on() ? (int)llds : 0); } while (0)
         const bool one_slot = 8 * LP <= kWave;
         if (pl.acc == kAccNone) { if (one_slot) MSDA_LAUNCH_BPL(kAccNone, 1); else MSDA_LAUNCH_BPL(kAccNone, 2); }
         else                    { if (one_slot) MSDA_LAUNCH_BPL(kAccWide, 1); else MSDA_LAUNCH_BPL(kAccWide, 2); }
@@ -1330,8 +1347,9 @@ static int describe_plan_t(int N, int S, int M, int L, int Lq, int P, bool prolo
     const LdsPlan la = plan_lds<VT>(N, S, M, L, Lq, P, nB);
     const bool lds_ok = la.use && pl.ppt == kSinglePPT && (pl.acc == kAccNone || pl.acc == kAccWide) && (!prologue || has_ws);
     if (lds_ok)
-        put(" bwd=fused_lds(acc=%s,W=%d,tp_cap=%d,roleB=%lld,roleA=%d,qw=%d%s%s)", acc, pl.W, pl.tp_cap, nB, N * M * la.chunks, la.qw,
-            det ? ",det" : "", prologue ? ",heads_reduce" : "");
+        // dense_px: a level of at most this many pixels (that the launch deals W workgroups) goes to the matrix cores
+        put(" bwd=fused_lds(acc=%s,W=%d,tp_cap=%d,roleB=%lld,roleA=%d,qw=%d,dense_px=%d%s%s)", acc, pl.W, pl.tp_cap, nB, N * M * la.chunks, la.qw,
+            !dense_on() || pl.W > 2 ? 0 : pl.W == 2 ? kDenseMaxRows : kDensePassRows, det ? ",det" : "", prologue ? ",heads_reduce" : "");
     else if (pl.ppt == kSinglePPT && pl.acc != kAccTile) {
         const FusedPlan fp = plan_fused(items, LP, pick_split(items, LP), nB, pl.acc, prologue ? M : 0, det);
         put(" bwd=fused(acc=%s,W=%d,tp_cap=%d,roleB=%lld,roleA=%d,split=%d,%s%s)", acc, pl.W, pl.tp_cap, nB,

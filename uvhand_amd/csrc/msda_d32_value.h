@@ -298,7 +298,7 @@ struct RecSoa {
 template <typename VT, typename GT, bool ENDS, typename RV>
 __device__ __forceinline__ void gather_balanced(const GoBuf<VT> go, GT *__restrict__ gv_base,
                                                 const int *cnt, const int *start, const RV rec, int *firsts, int npx,
-                                                int row_stride, int total, bool first_pass)
+                                                int row_stride, int total, int first_pass)
 {
     constexpr int G = kSBlock / 8, CH = 8;
     const int tid = threadIdx.x, g = tid >> 3;
@@ -320,28 +320,30 @@ __device__ __forceinline__ void gather_balanced(const GoBuf<VT> go, GT *__restri
     if (r >= r_stop) return;                                 // (no barrier below)
     int i = r ? endv[r - 1] : 0;
     const int i_stop = endv[r_stop - 1];
-    // the end of the row after the current one is read one flush ahead, so a flush waits for nothing (lane groups of a
-    // wavefront flush at different records: each flush runs on its own under the execution mask)
-    int row_end = endv[r], next_end = r + 1 < r_stop ? endv[r + 1] : 0x7fffffff;
+    // A flush is issued under the execution mask of the lane groups whose row just ended — 8 groups at different records, so
+    // some group flushes at almost every other record and the flush's instructions weigh like the loop's own (round 4: ~25
+    // of them, with a prefetched "end of the row after next" and a 64-bit row counter; now the store, the pointer, the
+    // accumulator and ONE LDS read of the next row's end — endv[r_stop] is always a readable LDS word, and unused).
+    const int fp = __builtin_amdgcn_readfirstlane(first_pass);      // a scalar, not a lane mask: one s_cmp per flush
+    int row_end = endv[r];
     GT *prow = gv_base + (long long)r * row_stride;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     auto flush = [&]() {                                     // row r is complete (possibly empty)
-        if (!first_pass) add4(acc, Row<GT>::load(prow));
+        if (!fp) add4(acc, Row<GT>::load(prow));
         Row<GT>::store(prow, acc);
         acc = make_float4(0.f, 0.f, 0.f, 0.f);
         prow += row_stride;
         ++r;
-        row_end = next_end;
-        next_end = r + 1 < r_stop ? endv[r + 1] : 0x7fffffff;
+        row_end = endv[r];
     };
     for (; i + CH <= i_stop; i += CH) {
         float ew[CH]; unsigned eo[CH]; float4 gl[CH];
 #pragma unroll
         for (int u = 0; u < CH; ++u) rec.get(i + u, ew[u], eo[u]);
 #pragma unroll
-        for (int u = 0; u < CH; ++u) gl[u] = go.load_at(eo[u]);
+        for (int u = 0; u < CH; ++u) gl[u] = MSDA_DIAG(2) ? make_float4(1.f, 1.f, 1.f, 1.f) : go.load_at(eo[u]);
 #pragma unroll
-        for (int u = 0; u < CH; ++u) { while (i + u >= row_end) flush(); fma4(acc, ew[u], gl[u]); }
+        for (int u = 0; u < CH; ++u) { while (i + u >= row_end) flush(); fma4(acc, ew[u], gl[u]); }   // (i + u < i_stop: r stays below r_stop)
     }
     if (i < i_stop) {                                        // last, partial batch
         float ew[CH]; unsigned eo[CH]; float4 gl[CH];
@@ -350,6 +352,55 @@ __device__ __forceinline__ void gather_balanced(const GoBuf<VT> go, GT *__restri
             if (i + u < i_stop) { rec.get(i + u, ew[u], eo[u]); gl[u] = go.load_at(eo[u]); }
 #pragma unroll
         for (int u = 0; u < CH; ++u) if (i + u < i_stop) { while (i + u >= row_end) flush(); fma4(acc, ew[u], gl[u]); }
+    }
+    while (r < r_stop) flush();                              // the row in progress and the empty rows after it
+}
+
+// gather_balanced for a record array whose rows are padded to multiples of 8 records (zero weight, a query past the
+// descriptor; bwd_value_wide_body): a batch of 8 never straddles two rows, so a row's end is looked for once per batch
+// instead of once per record — the per-record test and its execution-mask round trip were a quarter of the walk's
+// instructions (~17 per record step, 8 lanes groups at a time).  ends[r] = end of row r's (padded) segment.
+template <typename VT, typename GT, typename RV>
+__device__ __forceinline__ void gather_pad8(const GoBuf<VT> go, GT *__restrict__ gv_base, const int *ends, const RV rec, int *firsts,
+                                            int npx, int row_stride, int total, int first_pass)
+{
+    constexpr int G = kSBlock / 8, CH = 8;
+    const int tid = threadIdx.x, g = tid >> 3;
+    const int lo = (g * (total + 2 * npx)) / G;              // rows dealt by weight = slots + 2, as gather_balanced does
+    int a = 0, b = npx;
+    while (a < b) {
+        const int mid = (a + b) >> 1;
+        if ((mid ? ends[mid - 1] : 0) + 2 * mid >= lo) b = mid; else a = mid + 1;
+    }
+    if ((tid & 7) == 0) firsts[g] = a;
+    if (tid == 0) firsts[G] = npx;
+    __syncthreads();
+    int r = a;
+    const int r_stop = firsts[g + 1];
+    if (r >= r_stop) return;                                 // (no barrier below)
+    int i = r ? ends[r - 1] : 0;
+    const int i_stop = ends[r_stop - 1];
+    const int fp = __builtin_amdgcn_readfirstlane(first_pass);
+    int row_end = ends[r];
+    GT *prow = gv_base + (long long)r * row_stride;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto flush = [&]() {                                     // row r is complete (possibly empty); ends[r_stop] is a readable word
+        if (!fp) add4(acc, Row<GT>::load(prow));
+        Row<GT>::store(prow, acc);
+        acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        prow += row_stride;
+        ++r;
+        row_end = ends[r];
+    };
+    for (; i < i_stop; i += CH) {                            // (i, row ends and i_stop are multiples of 8)
+        float ew[CH]; unsigned eo[CH]; float4 gl[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) rec.get(i + u, ew[u], eo[u]);
+#pragma unroll
+        for (int u = 0; u < CH; ++u) gl[u] = MSDA_DIAG(2) ? make_float4(1.f, 1.f, 1.f, 1.f) : go.load_at(eo[u]);
+        while (i >= row_end) flush();                        // the rows that ended before this batch (i < i_stop: r stays below r_stop)
+#pragma unroll
+        for (int u = 0; u < CH; ++u) fma4(acc, ew[u], gl[u]);
     }
     while (r < r_stop) flush();                              // the row in progress and the empty rows after it
 }
@@ -365,7 +416,7 @@ __device__ __forceinline__ void gather_balanced(const GoBuf<VT> go, GT *__restri
 template <typename VT, typename GT, bool ENDS, typename RV>
 __device__ __forceinline__ void gather_split(const GoBuf<VT> go, GT *__restrict__ gv_base, const int *cnt,
                                              const int *start, const RV rec, float4 *part, int npx, int row_stride,
-                                             int total, bool first_pass)
+                                             int total, int first_pass)
 {
     constexpr int G = kSBlock / 8, CH = 8;
     const int tid = threadIdx.x, g = tid >> 3, j = tid & 7;
@@ -854,7 +905,8 @@ __device__ __forceinline__ void bwd_value_small_body(
 //   4. gathers as before and stores every row once.
 // If the kept taps exceed the record array or the list (locations piled on this workgroup's rows), it starts
 // over in chunks whose taps always fit, accumulating like kAccRmw.
-constexpr int kWideMaxStep = 65536;                 // points per attempt (what a 16-bit list entry / relative query can address)
+constexpr int kWideMaxStep = 65528;                 // points per attempt (what a 16-bit list entry / relative query can address; 0xffff = no query)
+constexpr bool kWidePad8 = true;                    // rows padded to 8 records when the record array has room (gather_pad8)
 constexpr int kWideLdsBudget = 80 * 1024;           // two workgroups per CU
 // Capacities of a kAccWide workgroup, the same on the host (plan_value) and on the device: what is left of the LDS budget
 // after the row arrays goes to the list (16-bit entries, one per listed point; at least the 8 KB the gathers use as
@@ -913,7 +965,6 @@ __device__ __forceinline__ void bwd_value_wide_body(
     const int NP = Lq * P;
     const long long item_base = (long long)b * Lq * M + m;
     const int row_stride = M * kD;
-    const GoBuf<VT> go = pair_rows<VT>(grad_out, item_base, Lq, M, lane & 7);
     GT *gv_base = grad_value + ((long long)(b * S + lstart + px0) * M + m) * kD + (lane & 7) * 4;
     const float2 *loc2 = reinterpret_cast<const float2 *>(loc);
     // Everything below is written for INSTRUCTION COUNT: a CU issues about one wavefront instruction per clock
@@ -940,7 +991,8 @@ __device__ __forceinline__ void bwd_value_wide_body(
         return off0 + (unsigned)(q * MLP + (idx - q * P));
     };
 
-    // steps 1-2 for the points [p0, p1); returns the number of kept taps
+    bool pad8 = false;                                       // layout of the record array for the current attempt (count_points)
+    // steps 1-2 for the points [p0, p1); returns the number of record slots they take
     auto count_points = [&](int p0, int p1) -> int {
         for (int i = tid; i < npx * CW; i += kSBlock) cnt[i] = 0;
         if (tid == 0) *kept_p = 0;
@@ -999,6 +1051,7 @@ __device__ __forceinline__ void bwd_value_wide_body(
         }
         __syncthreads();
         MSDA_STAMP(1);
+        if (MSDA_DIAG(6)) return 0;
         // 1b. histogram of the listed points' taps (dense lanes: ~4 atomics per 64 listed points)
         {
             // DET: the wavefront walks its own list segment (64 entries per step); else all threads share one list
@@ -1032,11 +1085,15 @@ __device__ __forceinline__ void bwd_value_wide_body(
         // exclusive prefix sum over the rows (512 threads x CH consecutive rows)
         const int CH = (npx + kSBlock - 1) / kSBlock;
         const int r0 = tid * CH;
+        // One scan for two layouts of the record array: rows back to back (low 16 bits), or every row rounded up to a multiple
+        // of 8 records (high 16 bits; totals stay below 2^14) — the padded layout if it fits: gather_pad8 then walks a row's
+        // records 8 at a time without a boundary test per record (kWidePad8).
+        auto padded = [](int c) { return c + (((c + 7) & ~7) << 16); };
         int mine = 0, big = 0;
         if (DET) {                                           // row totals; the packed counts become within-row prefixes (cursors)
-            for (int k = 0; k < CH; ++k) if (r0 + k < npx) { const int t = det_row_prefix(cnt, r0 + k); tot[r0 + k] = t; mine += t; big = max(big, t); }
+            for (int k = 0; k < CH; ++k) if (r0 + k < npx) { const int t = det_row_prefix(cnt, r0 + k); tot[r0 + k] = t; mine += padded(t); big = max(big, t); }
         } else
-        for (int k = 0; k < CH; ++k) if (r0 + k < npx) { mine += cnt[r0 + k]; big = max(big, cnt[r0 + k]); }
+        for (int k = 0; k < CH; ++k) if (r0 + k < npx) { mine += padded(cnt[r0 + k]); big = max(big, cnt[r0 + k]); }
         int incl = mine;
 #pragma unroll
         for (int o = 1; o < kWave; o <<= 1) { const int y = __shfl_up(incl, o, kWave); if (lane >= o) incl += y; }
@@ -1051,10 +1108,12 @@ __device__ __forceinline__ void bwd_value_wide_body(
 #pragma unroll
             for (int w2 = 0; w2 < kSWaves; ++w2) { if (w2 < wave) excl += ws[w2]; total += ws[w2]; }
         }
-        for (int k = 0; k < CH; ++k) if (r0 + k < npx) { start[r0 + k] = excl; excl += tot[r0 + k]; }
+        pad8 = kWidePad8 && (total >> 16) <= rec_cap;        // (uniform)
+        const int sh = pad8 ? 16 : 0;
+        for (int k = 0; k < CH; ++k) if (r0 + k < npx) { start[r0 + k] = (excl >> sh) & 0xffff; excl += padded(tot[r0 + k]); }
         __syncthreads();
         MSDA_STAMP(3);
-        return total;
+        return (total >> sh) & 0xffff;
     };
     auto longest_row = [&]() {
         const int4 wa = *reinterpret_cast<const int4 *>(wsum + 16), wb = *reinterpret_cast<const int4 *>(wsum + 20);
@@ -1062,11 +1121,12 @@ __device__ __forceinline__ void bwd_value_wide_body(
     };
 
     // steps 3-4 for the listed points.  A record = {weight, query relative to the chunk's first query (16 bits)}.
-    auto scatter_and_gather = [&](int p0, int total, bool first) {
+    auto scatter_and_gather = [&](int p0, int p1, int total, int first) {
+        if (MSDA_DIAG(5) || MSDA_DIAG(6)) return;
         const int kept = DET ? kept_w[wave] : *kept_p;
         const uint16_t *mylist = list + (DET ? wave * seg : 0);
         const int me = DET ? lane : tid, stride = DET ? kWave : kSBlock;
-        const int qbase = fdiv(p0, P, p_shift);
+        const int qbase = fdiv(p0, P, p_shift), q_count = fdiv(p1 - 1, P, p_shift) - qbase + 1;
         constexpr int U = 8;
         for (int base = 0; base < kept; base += stride * U) {
             float2 xy[U]; float at[U]; int qq[U];
@@ -1098,9 +1158,30 @@ __device__ __forceinline__ void bwd_value_wide_body(
         }
         __syncthreads();
         MSDA_STAMP(4);
+        if (MSDA_DIAG(4)) return;
+        if (DET || pad8) {
+            // start[] becomes the rows' ENDS (the deterministic variant's stayed their beginnings, the other's cursor is there
+            // already); padded layout: the slots up to the next multiple of 8 get weight 0 and a query past the descriptor
+            for (int i = tid; i < npx; i += kSBlock) {
+                int e = start[i] + (DET ? tot[i] : 0);
+                if (pad8) {
+                    const int fill = (-tot[i]) & 7;
+                    for (int k = 0; k < fill; ++k) { rw[e + k] = 0.f; rq[e + k] = (uint16_t)0xffffu; }
+                    e += fill;
+                }
+                start[i] = e;
+            }
+            __syncthreads();
+        }
+        // the records' queries are relative to qbase: so is the descriptor the gathers read grad_out through (one add less per record)
+        // (... and it ends with the attempt's last query — at most kWideMaxStep of them — so that the padding slots' query
+        // 0xffff lies past it and reads zeros)
+        const GoBuf<VT> go = pair_rows<VT>(grad_out, item_base + (long long)qbase * M, min(Lq - qbase, q_count), M, lane & 7);
         // rows of comparable length (the longest no more than one lane group's share): the balanced walk
         if (longest_row() * 64 <= max(total, 1024)) {
-            gather_balanced<VT, GT, !DET>(go, gv_base, tot, start, RecSoa{rw, rq, qbase, go.stride_b}, reinterpret_cast<int *>(list), npx,
+            if (pad8) gather_pad8<VT, GT>(go, gv_base, start, RecSoa{rw, rq, 0, go.stride_b}, reinterpret_cast<int *>(list), npx, row_stride, total, first);
+            else
+            gather_balanced<VT, GT, true>(go, gv_base, tot, start, RecSoa{rw, rq, 0, go.stride_b}, reinterpret_cast<int *>(list), npx,
                                           row_stride, total, first);
             MSDA_STAMP(5);
             return;
@@ -1108,7 +1189,7 @@ __device__ __forceinline__ void bwd_value_wide_body(
         // rows of very different lengths (coarse levels): equal stretches of records, parts combined by the row's owner.
         // (Measured against it: the split gather for every row mix — same at cfg-2 / cfg-4 encoder, but on the single-pass
         // path 784 six-record rows cost 19.5 instead of 14.5 us; gather_rows here: 20.2 instead of 11.3 us per workgroup.)
-        gather_split<VT, GT, !DET>(go, gv_base, tot, start, RecSoa{rw, rq, qbase, go.stride_b}, reinterpret_cast<float4 *>(list), npx,
+        gather_split<VT, GT, true>(go, gv_base, tot, start, RecSoa{rw, rq, 0, go.stride_b}, reinterpret_cast<float4 *>(list), npx,
                                    row_stride, total, first);
         MSDA_STAMP(5);
     };
@@ -1117,7 +1198,7 @@ __device__ __forceinline__ void bwd_value_wide_body(
     // from the count just taken (7/8 full if the points spread evenly), halved while it still does not fit.
     // A chunk of wide_chunk points always fits (4 taps per point), so the loop ends.
     int a = 0, step = min(NP, kWideMaxStep);
-    bool first = true;
+    int first = 1;
     while (a < NP) {
         const int a1 = min(NP, a + step);
         __syncthreads();                                     // the previous attempt / gather still reads the LDS arrays
@@ -1132,8 +1213,8 @@ __device__ __forceinline__ void bwd_value_wide_body(
             step = max(wide_chunk, (int)min(even, (long long)(a1 - a) / 2));
             continue;
         }
-        scatter_and_gather(a, t, first);
-        first = false;
+        scatter_and_gather(a, a1, t, first);
+        first = 0;
         a = a1;
     }
 }
