@@ -210,12 +210,13 @@ def test_argument_errors_are_reported_before_anything_is_launched(native):
 
 
 def test_int32_row_offsets_bound_the_d32_family():
-    """Role B's gathers form q * M*32 in 32 bits: the tiled family only takes geometries with N*Lq*M*32 < 2^31 (others go to
-    the generic kernels, whose indices are 64-bit).  Host logic only: no launch."""
+    """Role B's gathers read a (batch, head) pair's grad_out rows through a buffer descriptor with 32-bit BYTE offsets
+    q * M * 128: the tiled family only takes geometries with Lq * M * 128 B < 2^31 (others go to the generic kernels, whose
+    indices are 64-bit).  Host logic only: no launch."""
     import ctypes
     lib = ctypes.CDLL(os.path.join(ROOT, "uvhand_amd", "libmsda_hip.so"))
     lib.msda_prologue_supported.restype = ctypes.c_int
     lib.msda_prologue_supported.argtypes = [ctypes.c_int] * 7
-    # N = 1, M = 8, L = 1, P = 4: every other limit of the family (items < 2^30, items*L*P*2 < 2^31) still holds at Lq = 2^23
-    assert lib.msda_prologue_supported(1, 64, 8, 32, 1, (1 << 23) - 8, 4) == 1          # 2^31 - 2048 elements of out / grad_out
-    assert lib.msda_prologue_supported(1, 64, 8, 32, 1, 1 << 23, 4) == 0               # exactly 2^31
+    # N = 1, M = 8, L = 1, P = 4: every other limit of the family (items * 32 < 2^31, items*L*P*2 < 2^31) still holds at Lq = 2^21
+    assert lib.msda_prologue_supported(1, 64, 8, 32, 1, (1 << 21) - 1, 4) == 1          # 2^31 - 1024 bytes of a pair's rows
+    assert lib.msda_prologue_supported(1, 64, 8, 32, 1, 1 << 21, 4) == 0               # exactly 2^31
