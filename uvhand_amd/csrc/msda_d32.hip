@@ -671,7 +671,10 @@ __global__ __launch_bounds__(kSBlock, 4) void bwd_fused_d32_kernel(
 
 // The same single launch for LARGE problems: role B as above, role A on the LDS-stage body of msda_d32_lds.h (chunks of
 // one (batch, head) pair's queries, coarse levels served from LDS).  Both roles are 512-thread workgroups, two per CU.
-template <int ACC, typename VT, bool FUSED, typename GT, int NS, bool DET = false>
+// DENSE: the instantiation that may send coarse levels to the matrix cores (msda_d32_dense.h).  A launch whose plan rules
+// that out (more than two ranges per level) takes the other one: the dense body is a real function, and a kernel that contains
+// the call reserves scratch for every wavefront — cfg-2 encoder, where no level qualifies, paid 1.5 us of 57 for it.
+template <int ACC, typename VT, bool FUSED, typename GT, int NS, bool DET = false, bool DENSE = true>
 __global__ __launch_bounds__(kSBlock, 4) void bwd_fused_lds_d32_kernel(
     const VT *__restrict__ grad_out, const VT *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ level_start, const float *__restrict__ loc, const float *__restrict__ attn, int S, int M, int L,
@@ -688,7 +691,7 @@ __global__ __launch_bounds__(kSBlock, 4) void bwd_fused_lds_d32_kernel(
         int pr, l, ti, Wl;
         value_block_to_range(bid, W, L, shapes, pr, l, ti, Wl, ACC != kAccWide);
         // a level of a few dozen pixels: its taps are a dense [pixels x queries] matrix — matrix cores (msda_d32_dense.h)
-        if (!MSDA_DIAG(7) && dense_level(shapes[2 * l], shapes[2 * l + 1], level_start[l], S, Wl, lds_bytes)) {
+        if (DENSE && !MSDA_DIAG(7) && dense_level(shapes[2 * l], shapes[2 * l + 1], level_start[l], S, Wl, lds_bytes)) {
             if (l == 0 && ti == 0) zero_uncovered_rows<GT, kSBlock>(shapes, level_start, S, M, L, grad_value, pr / M, pr % M);
             bwd_value_dense_body<VT, GT>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, grad_value, ti, Wl, l, pr, smem);
             return;
@@ -1039,18 +1042,21 @@ static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *
             const dim3 fgrid((unsigned)(nB + (long long)N * M * lds_a.chunks));
             // (at least what the dense coarse-level body needs: two such workgroups still share a CU)
             const size_t flds = max(max(pl.lds, lds_a.lds), (size_t)dense_lds_bytes());
-#define MSDA_LAUNCH_FLD_(AC, NS_, DT)                                                                  \
-            do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_fused_lds_d32_kernel<AC, VT, false, GT, NS_, DT>), flds)) return rc; \
-            hipLaunchKernelGGL((bwd_fused_lds_d32_kernel<AC, VT, false, GT, NS_, DT>), fgrid, dim3(kSBlock), flds, stream, grad_out,  \
+            const bool dense = dense_on() && pl.W <= 2;
+#define MSDA_LAUNCH_FLD__(AC, NS_, DT, DN)                                                             \
+            do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_fused_lds_d32_kernel<AC, VT, false, GT, NS_, DT, DN>), flds)) return rc; \
+            hipLaunchKernelGGL((bwd_fused_lds_d32_kernel<AC, VT, false, GT, NS_, DT, DN>), fgrid, dim3(kSBlock), flds, stream, grad_out,  \
                                value, shapes, level_start, loc, attn, S, M, L, Lq, P, ps, lps, pl.tp_cap, pl.W, (int)nB,          \
                                lds_a.chunks, lds_a.qw, lds_a.stage_rows, grad_value, grad_loc, grad_attn,                        \
-                               PrologueOut{nullptr, 0, 0}, xcd, dense_on() ? (int)flds : 0); } while (0)
+                               PrologueOut{nullptr, 0, 0}, xcd, (DN) ? (int)flds : 0); } while (0)
+#define MSDA_LAUNCH_FLD_(AC, NS_, DT) do { if (dense) MSDA_LAUNCH_FLD__(AC, NS_, DT, true); else MSDA_LAUNCH_FLD__(AC, NS_, DT, false); } while (0)
 #define MSDA_LAUNCH_FLD(AC, NS_) do { if (deterministic) MSDA_LAUNCH_FLD_(AC, NS_, true); else MSDA_LAUNCH_FLD_(AC, NS_, false); } while (0)
             const bool one_slot = 8 * LP <= kWave;
             if (pl.acc == kAccNone) { if (one_slot) MSDA_LAUNCH_FLD(kAccNone, 1); else MSDA_LAUNCH_FLD(kAccNone, 2); }
             else                    { if (one_slot) MSDA_LAUNCH_FLD(kAccWide, 1); else MSDA_LAUNCH_FLD(kAccWide, 2); }
 #undef MSDA_LAUNCH_FLD
 #undef MSDA_LAUNCH_FLD_
+#undef MSDA_LAUNCH_FLD__
             return check_launch("msda backward (d32, fused, LDS stage)");
         }
         // ---- whole backward in one launch when role A's workgroups can share the CUs (LDS) ----
@@ -1198,16 +1204,19 @@ static int launch_bwd_prologue_t(const VT *grad_out, const VT *value, const int6
         const dim3 lgrid((unsigned)(nB + (long long)N * M * lq.chunks));
         const size_t llds = max(max(pl.lds, lq.lds), (size_t)dense_lds_bytes());
 #define MSDA_LAUNCH_BPL(AC, NS_) do { if (deterministic) MSDA_LAUNCH_BPL_(AC, NS_, true); else MSDA_LAUNCH_BPL_(AC, NS_, false); } while (0)
-#define MSDA_LAUNCH_BPL_(AC, NS_, DT)                                                                  \
-        do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_fused_lds_d32_kernel<AC, VT, true, float, NS_, DT>), llds)) return rc; \
-        hipLaunchKernelGGL((bwd_fused_lds_d32_kernel<AC, VT, true, float, NS_, DT>), lgrid, dim3(kSBlock), llds, stream, grad_out,   \
+        const bool dense = dense_on() && pl.W <= 2;
+#define MSDA_LAUNCH_BPL_(AC, NS_, DT) do { if (dense) MSDA_LAUNCH_BPL__(AC, NS_, DT, true); else MSDA_LAUNCH_BPL__(AC, NS_, DT, false); } while (0)
+#define MSDA_LAUNCH_BPL__(AC, NS_, DT, DN)                                                             \
+        do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_fused_lds_d32_kernel<AC, VT, true, float, NS_, DT, DN>), llds)) return rc; \
+        hipLaunchKernelGGL((bwd_fused_lds_d32_kernel<AC, VT, true, float, NS_, DT, DN>), lgrid, dim3(kSBlock), llds, stream, grad_out,   \
                            value, shapes, level_start, loc, attn, S, M, L, Lq, P, ps, lps, pl.tp_cap, pl.W, (int)nB, lq.chunks,   \
-                           lq.qw, lq.stage_rows, grad_value, grad_offsets, grad_logits, pro_h, xcd_remap(), dense_on() ? (int)llds : 0); } while (0)
+                           lq.qw, lq.stage_rows, grad_value, grad_offsets, grad_logits, pro_h, xcd_remap(), (DN) ? (int)llds : 0); } while (0)
         const bool one_slot = 8 * LP <= kWave;
         if (pl.acc == kAccNone) { if (one_slot) MSDA_LAUNCH_BPL(kAccNone, 1); else MSDA_LAUNCH_BPL(kAccNone, 2); }
         else                    { if (one_slot) MSDA_LAUNCH_BPL(kAccWide, 1); else MSDA_LAUNCH_BPL(kAccWide, 2); }
 #undef MSDA_LAUNCH_BPL
 #undef MSDA_LAUNCH_BPL_
+#undef MSDA_LAUNCH_BPL__
         if (int rc = check_launch("msda backward (d32, fused prologue, LDS stage)")) return rc;
         const long long cells = (long long)N * Lq * L;
         hipLaunchKernelGGL(ref_heads_reduce_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, stream,

@@ -906,7 +906,10 @@ __device__ __forceinline__ void bwd_value_small_body(
 // If the kept taps exceed the record array or the list (locations piled on this workgroup's rows), it starts
 // over in chunks whose taps always fit, accumulating like kAccRmw.
 constexpr int kWideMaxStep = 65528;                 // points per attempt (what a 16-bit list entry / relative query can address; 0xffff = no query)
-constexpr bool kWidePad8 = true;                    // rows padded to 8 records when the record array has room (gather_pad8)
+#ifndef MSDA_WIDE_PAD8
+#define MSDA_WIDE_PAD8 1
+#endif
+constexpr bool kWidePad8 = MSDA_WIDE_PAD8 != 0;      // rows padded to 8 records when the record array has room (gather_pad8)
 constexpr int kWideLdsBudget = 80 * 1024;           // two workgroups per CU
 // Capacities of a kAccWide workgroup, the same on the host (plan_value) and on the device: what is left of the LDS budget
 // after the row arrays goes to the list (16-bit entries, one per listed point; at least the 8 KB the gathers use as
