@@ -139,6 +139,48 @@ def test_module_loads_reference_state_dict_strictly():
     assert not missing and not unexpected
 
 
+def test_projection_parameters_share_one_storage():
+    """sampling_offsets / attention_weights stay two nn.Linear (names, state_dict keys, Parameter objects) whose weights and
+    biases are views of one buffer each — what the one-node path's merged GEMM reads with no concatenation (VERDICT r04 item
+    3a).  The sharing survives optimizer steps, load_state_dict and _reset_parameters, and is re-made after .to() / a
+    re-seated parameter."""
+    from uvhand_amd.modules import MSDeformAttn
+    mod = MSDeformAttn(d_model=32, n_levels=2, n_heads=4, n_points=2)
+    n_off = mod.sampling_offsets.weight.shape[0]
+
+    def shared():
+        wm, bm = mod._merged_projection_weights()
+        return (wm is not None and mod.sampling_offsets.weight.data_ptr() == wm.data_ptr()
+                and mod.attention_weights.weight.data_ptr() == wm.data_ptr() + 4 * n_off * 32
+                and mod.sampling_offsets.bias.data_ptr() == bm.data_ptr()
+                and mod.attention_weights.bias.data_ptr() == bm.data_ptr() + 4 * n_off
+                and torch.equal(wm, torch.cat([mod.sampling_offsets.weight, mod.attention_weights.weight]))
+                and torch.equal(bm, torch.cat([mod.sampling_offsets.bias, mod.attention_weights.bias])))
+    assert shared()
+    assert sorted(k for k, _ in mod.named_parameters()) == sorted(
+        p + s for p in ("sampling_offsets.", "attention_weights.", "value_proj.", "output_proj.") for s in ("weight", "bias"))
+    assert not any("merged" in k for k in mod.state_dict())
+    params = {n: p for n, p in mod.named_parameters()}
+    opt = torch.optim.AdamW(mod.parameters(), lr=0.1)
+    sum(p.sum() for p in mod.parameters()).backward()
+    opt.step()
+    assert shared() and all(params[n] is p for n, p in mod.named_parameters())
+    mod.attention_weights.bias.data.copy_(torch.arange(mod.attention_weights.bias.numel(), dtype=torch.float32))   # no version bump
+    assert shared() and mod._merged_projection_weights()[1][n_off + 3] == 3
+    mod.load_state_dict(MSDeformAttn(d_model=32, n_levels=2, n_heads=4, n_points=2).state_dict(), strict=True)
+    assert shared()
+    mod._reset_parameters()
+    assert shared()
+    mod.double()
+    assert mod._merged_projection_weights() == (None, None)          # only float32 layers share storage
+    mod.float()
+    assert shared()
+    mod.sampling_offsets.bias = torch.nn.Parameter(torch.zeros(n_off))    # re-seated from outside: shared again on use
+    assert shared() and float(mod._merged_projection_weights()[1][:n_off].abs().sum()) == 0.0
+    mod.share_projection_storage = False
+    assert mod._merged_projection_weights() == (None, None)
+
+
 def test_module_argument_errors():
     from uvhand_amd.modules import MSDeformAttn
     with pytest.raises(ValueError, match="divisible"):

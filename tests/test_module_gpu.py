@@ -609,24 +609,35 @@ def test_frozen_projections_cost_no_weight_gradient_launch():
             assert torch.equal(g, results[False][4][n]), n
 
 
-def test_merged_projection_cache_follows_parameter_updates():
-    """The cached [sampling_offsets ; attention_weights] concatenation is keyed on the parameters' storage and in-place version
-    counters: an optimizer-style in-place update, load_state_dict and _reset_parameters all show in the next forward."""
+def test_merged_projection_storage_follows_parameter_updates():
+    """[sampling_offsets ; attention_weights] is the parameters' own storage (views of one buffer): an optimizer-style in-place
+    update, a write through `.data` (invisible to version counters: ADVICE r04), load_state_dict — also with assign=True, which
+    re-seats the parameters — and _reset_parameters all show in the next forward, and no concatenation kernel runs."""
     z = load_golden("module_2d")
     mod = _module()
     q, r, s_, sh, lsi, mask = _node_inputs(z)
     out0 = mod(q, r, s_, sh, lsi, mask).detach().clone()
-    assert mod.__dict__.get("_merged_cache") is not None or not mod.cpp_node
-    with torch.no_grad():
-        mod.attention_weights.bias.add_(torch.linspace(-1, 1, mod.attention_weights.bias.numel(), device="cuda"))
+    wm, bm = mod._merged_projection_weights()
+    assert wm is not None and mod.attention_weights.bias.data_ptr() == bm.data_ptr() + 4 * mod.sampling_offsets.bias.numel()
+    delta = torch.linspace(-1, 1, mod.attention_weights.bias.numel(), device="cuda")
+    mod.attention_weights.bias.data.copy_(mod.attention_weights.bias.data + delta)     # `.data` write: no version bump
     out1 = mod(q, r, s_, sh, lsi, mask).detach().clone()
     assert not torch.equal(out0, out1)
+    with torch.no_grad():
+        mod.attention_weights.bias.sub_(delta)
+        mod.attention_weights.bias.add_(delta)
+    assert torch.equal(mod(q, r, s_, sh, lsi, mask).detach(), out1)
     ref = _module()                                          # a fresh module with the same update and no cache history
     with torch.no_grad():
         ref.attention_weights.bias.add_(torch.linspace(-1, 1, ref.attention_weights.bias.numel(), device="cuda"))
     assert torch.equal(out1, ref(q, r, s_, sh, lsi, mask).detach())
     mod.load_state_dict(_module().state_dict())
     assert torch.equal(mod(q, r, s_, sh, lsi, mask).detach(), out0)
+    assert mod._merged_projection_weights()[0].data_ptr() == wm.data_ptr()                  # copied INTO the views
+    mod.load_state_dict(ref.state_dict(), assign=True)                                       # new Parameters: shared again on use
+    assert torch.equal(mod(q, r, s_, sh, lsi, mask).detach(), out1)
+    assert mod.sampling_offsets.weight.data_ptr() == mod._merged_projection_weights()[0].data_ptr()
+    mod.load_state_dict(_module().state_dict())
     torch.manual_seed(5)                                     # (xavier_uniform_ draws the value / output projections)
     mod._reset_parameters()                                  # (re-creates the offsets' bias on the CPU, as the reference's does)
     mod.cuda()

@@ -93,11 +93,11 @@ class MSDeformAttn(nn.Module):
         # extension is built: the same kernels queued without Python in between (the eager step is host-bound at decoder
         # sizes); False = the Python composition below
         self.cpp_node = True
-        # the one-node path keeps [sampling_offsets ; attention_weights] concatenated while the parameters' storage and
-        # in-place version counters are unchanged (_merged_projection_weights).  Writes through `.data` are invisible to
-        # those counters: code that updates parameters that way sets this to False (or calls _reset_parameters / assigns
-        # new Parameters, which drop the cache)
-        self.cache_merged_projection = True
+        # the one-node path reads [sampling_offsets ; attention_weights] as ONE weight / bias: the four parameters are VIEWS of
+        # two persistent buffers (_merge_projection_storage), so nothing is concatenated per call and nothing can go stale —
+        # optimizers, load_state_dict and DDP write through the parameters into the very storage the GEMM reads.  False: the
+        # node concatenates per call (two small copies), as during a stream capture that finds the views broken
+        self.share_projection_storage = True
         self.d_model = d_model
         self.n_levels = n_levels
         self.n_heads = n_heads
@@ -111,7 +111,6 @@ class MSDeformAttn(nn.Module):
         self._reset_parameters()
 
     def _reset_parameters(self):
-        self.__dict__.pop("_merged_cache", None)                 # the initialisers below write through .data
         # sampling offsets start as the n_heads unit directions of a regular polygon, scaled to the
         # unit square's border and by the point index 1..n_points; attention logits start at zero.
         nn.init.constant_(self.sampling_offsets.weight.data, 0.0)
@@ -128,6 +127,7 @@ class MSDeformAttn(nn.Module):
         nn.init.constant_(self.value_proj.bias.data, 0.0)
         nn.init.xavier_uniform_(self.output_proj.weight.data)
         nn.init.constant_(self.output_proj.bias.data, 0.0)
+        self._merge_projection_storage()                         # (the bias above is a new Parameter: new storage)
 
     def _cpp_node(self, query, reference_points, input_flatten, spatial_shapes, level_start_index, padding_mask):
         """The torch extension, if this call can run as one of its one-node forms of the fused path (module_forward /
@@ -182,25 +182,60 @@ class MSDeformAttn(nn.Module):
             return None
         return ext
 
+    def _projection_params(self):
+        return (self.sampling_offsets.weight, self.attention_weights.weight, self.sampling_offsets.bias, self.attention_weights.bias)
+
+    def _merge_projection_storage(self):
+        """Re-seat sampling_offsets.{weight,bias} and attention_weights.{weight,bias} as views of ONE [3*M*L*P, C] weight
+        buffer and ONE [3*M*L*P] bias buffer (values kept).  The Parameter objects, their names and state_dict keys are
+        untouched (optimizer state, lr groups by name — util/settings.py:75 — and checkpoints see two nn.Linear as before);
+        only their storage is shared, so the merged GEMM of the one-node path reads the live parameters with no copy.
+        Returns False (nothing changed) when the layers are not two plain float32 nn.Linear with biases on one device."""
+        self.__dict__.pop("_merged", None)
+        ps = self._projection_params() if (type(self.sampling_offsets) is nn.Linear and type(self.attention_weights) is nn.Linear) else (None,)
+        if any(p is None for p in ps) or len({(p.dtype, p.device) for p in ps}) != 1 or ps[0].dtype != torch.float32:
+            return False
+        if ps[0].dim() != 2 or ps[1].dim() != 2 or ps[0].shape[1] != ps[1].shape[1]:
+            return False
+        n_off = ps[0].shape[0]
+        with torch.no_grad():
+            wbuf = torch.cat([ps[0].detach(), ps[1].detach()], 0)
+            bbuf = torch.cat([ps[2].detach(), ps[3].detach()], 0)
+            ps[0].data, ps[1].data = wbuf[:n_off], wbuf[n_off:]
+            ps[2].data, ps[3].data = bbuf[:n_off], bbuf[n_off:]
+        self.__dict__["_merged"] = (wbuf, bbuf)
+        return True
+
+    def _apply(self, fn, *args, **kwargs):
+        # .to() / .cuda() / .float() give every parameter storage of its own: share it again
+        out = super()._apply(fn, *args, **kwargs)
+        if self.__dict__.get("share_projection_storage", False):
+            self._merge_projection_storage()
+        return out
+
     def _merged_projection_weights(self):
-        """[sampling_offsets ; attention_weights] weight and bias as the one-node path's single GEMM reads them, kept while
-        the four parameters are unchanged (same storage, same in-place version counter): in evaluation, and for layers an
-        optimizer does not update (util/settings.py:447-515 lr groups), the two concatenations are not launched again.
-        (None, None) — the node concatenates itself — during stream capture (a cached tensor must not live in a graph's
-        private pool) and for tensors without a version counter (inference tensors)."""
-        ps = (self.sampling_offsets.weight, self.attention_weights.weight, self.sampling_offsets.bias, self.attention_weights.bias)
-        try:
-            key = tuple((p.data_ptr(), p._version) for p in ps)
-        except RuntimeError:                                     # inference tensors do not track versions
+        """The [sampling_offsets ; attention_weights] weight and bias the one-node path's single GEMM reads: the buffers the
+        four parameters are views of.  If something has re-seated a parameter since (load_state_dict(assign=True), a new
+        nn.Parameter, `.data = ...`), the storage is shared again first; during a stream capture (no allocation may end up in
+        the graph's private pool) or with share_projection_storage off: (None, None) — the node concatenates per call."""
+        if not self.share_projection_storage:
             return None, None
-        if not self.cache_merged_projection or torch.cuda.is_current_stream_capturing():
-            return None, None
-        cache = self.__dict__.get("_merged_cache")
-        if cache is None or cache[0] != key:
-            with torch.no_grad():
-                cache = (key, torch.cat([ps[0], ps[1]], 0), torch.cat([ps[2], ps[3]], 0))
-            self.__dict__["_merged_cache"] = cache
-        return cache[1], cache[2]
+        ps = self._projection_params()
+        merged = self.__dict__.get("_merged")
+        for _ in range(2):
+            if merged is not None:
+                wbuf, bbuf = merged
+                n_off, c = ps[0].shape[0] if ps[0] is not None else -1, wbuf.shape[1]
+                if (all(p is not None and p.dtype == wbuf.dtype and p.device == wbuf.device and p.is_contiguous() for p in ps)
+                        and ps[0].data_ptr() == wbuf.data_ptr() and ps[1].data_ptr() == wbuf.data_ptr() + 4 * n_off * c
+                        and ps[2].data_ptr() == bbuf.data_ptr() and ps[3].data_ptr() == bbuf.data_ptr() + 4 * n_off
+                        and ps[0].shape[0] + ps[1].shape[0] == wbuf.shape[0] and ps[0].shape[1] == c == ps[1].shape[1]):
+                    return wbuf, bbuf
+            capturing = ps[0] is not None and ps[0].is_cuda and torch.cuda.is_current_stream_capturing()
+            if capturing or not self._merge_projection_storage():
+                return None, None
+            merged = self.__dict__.get("_merged")
+        return None, None
 
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
                 input_padding_mask=None):
