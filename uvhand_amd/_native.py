@@ -232,9 +232,15 @@ _FWD_WS_ARGTYPES = [_VP] * 5 + [_CI] * 7 + [_VP, _VP, ctypes.c_ulonglong, _VP]
 
 def _forward_table(lib, N, S, M, D, L, Lq, P, device, prologue=False):
     """The buffer a forward of this geometry can fill with its point table for the backward of the same autograd node
-    (msda_forward_workspace_bytes, include/msda.h); None where the backward's plan reads none (all but small problems)."""
-    nbytes = int(lib.msda_forward_workspace_bytes(N, S, M, D, L, Lq, P, FLAG_PROLOGUE if prologue else 0))
-    return torch.empty((nbytes,), dtype=torch.uint8, device=device) if nbytes else None
+    (msda_forward_workspace_bytes, include/msda.h: the point table of small problems, the per-range point lists of large
+    ones); None where the backward's plan reads none."""
+    flags = FLAG_PROLOGUE if prologue else 0
+    nbytes = int(lib.msda_forward_workspace_bytes(N, S, M, D, L, Lq, P, flags))
+    if not nbytes:
+        return None
+    # the same buffer goes to the backward with MSDA_FLAG_FORWARD_TABLE: the table first, that call's scratch behind it
+    nbytes = max(nbytes, int(lib.msda_backward_workspace_bytes(N, S, M, D, L, Lq, P, flags | FLAG_FORWARD_TABLE)))
+    return torch.empty((nbytes,), dtype=torch.uint8, device=device)
 
 
 def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step, with_table=None):
@@ -306,9 +312,10 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
         # always through the entry with flags and scratch (msda_backward_workspace_bytes says how much a call can use: 0 for
         # most shapes); the deterministic flag reaches every kernel family and dtype
         flags = FLAG_DETERMINISTIC if det else 0
-        ws, nbytes = _backward_workspace(lib, N, S, M, D, L, Lq, P, value.device, flags)
-        if table is not None and ws is None:                 # the forward's point table of this very call (with_table=True)
+        if table is not None:                                # the forward's table of this very call (with_table=True), scratch behind it
             ws, nbytes, flags = table, table.numel(), flags | FLAG_FORWARD_TABLE
+        else:
+            ws, nbytes = _backward_workspace(lib, N, S, M, D, L, Lq, P, value.device, flags)
         rc = _entry(lib, "msda_backward_ws_" + suf + ("_gv32" if fp32_grad_value else ""), _BWD_WS_ARGTYPES)(
             grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
             sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P,
@@ -550,11 +557,13 @@ def ms_deform_attn_backward_prologue(value, spatial_shapes, level_start_index, s
         gref = torch.empty((N, Lq, L, 2), dtype=torch.float32, device=value.device)
         det = deterministic_requested() if deterministic is None else bool(deterministic)
         # use_workspace=False (tests): the call a caller without scratch makes — the library then runs the kernels that need none
-        ws, nbytes = _backward_workspace(lib, N, S, M, D, L, Lq, P, value.device,
-                                         FLAG_PROLOGUE | (FLAG_DETERMINISTIC if det else 0)) if use_workspace else (None, 0)
         flags = FLAG_DETERMINISTIC if det else 0
-        if table is not None and ws is None:                 # the forward's point table (with_table=True of the forward)
-            ws, nbytes, flags = table, table.numel(), flags | FLAG_FORWARD_TABLE
+        if table is not None:                                # the forward's table (with_table=True of the forward), scratch behind it
+            ws, flags = table, flags | FLAG_FORWARD_TABLE
+            nbytes = table.numel() if use_workspace else min(table.numel(), int(lib.msda_forward_workspace_bytes(N, S, M, D, L, Lq, P, FLAG_PROLOGUE)))
+        else:
+            ws, nbytes = _backward_workspace(lib, N, S, M, D, L, Lq, P, value.device,
+                                             FLAG_PROLOGUE | (FLAG_DETERMINISTIC if det else 0)) if use_workspace else (None, 0)
         rc = _entry(lib, "msda_backward_prologue_bf16_gv32" if bf16 else "msda_backward_prologue_ws_f32",
                     [_VP] * 6 + [_CI] * 7 + [_LL] * 2 + [_VP] * 5 + [ctypes.c_ulonglong, ctypes.c_uint, _VP])(
             grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),

@@ -101,6 +101,21 @@ static const void *table_of(const void *workspace, size_t ws_bytes, unsigned fla
     return (need > 0 && ws_bytes >= need) ? workspace : nullptr;
 }
 
+// The scratch part of a backward call's workspace: all of it, or — with MSDA_FLAG_FORWARD_TABLE on a geometry whose forward
+// leaves a table — what follows the table (include/msda.h: the table first, rounded up to 256 bytes, then the scratch).
+struct Scratch { void *p; size_t bytes; };
+static size_t table_span(int N, int S, int M, int D, int L, int Lq, int P, bool prologue)
+{
+    return (forward_table_bytes(N, S, M, D, L, Lq, P, prologue) + 255) & ~(size_t)255;
+}
+static Scratch scratch_of(void *workspace, size_t ws_bytes, unsigned flags, int N, int S, int M, int D, int L, int Lq, int P, bool prologue)
+{
+    if (!workspace || !(flags & MSDA_FLAG_FORWARD_TABLE)) return Scratch{workspace, workspace ? ws_bytes : 0};
+    const size_t span = table_span(N, S, M, D, L, Lq, P, prologue);
+    if (ws_bytes <= span) return Scratch{nullptr, 0};
+    return Scratch{static_cast<unsigned char *>(workspace) + span, ws_bytes - span};
+}
+
 template <typename T>
 static int forward_impl(const T *value, const int64_t *shapes, const int64_t *level_start,
                         const T *loc, const T *attn, int N, int S, int M, int D, int L, int Lq, int P,
@@ -118,6 +133,8 @@ static int forward_impl(const T *value, const int64_t *shapes, const int64_t *le
         if (d32 && aligned_to(value, 16) && aligned_to(out, 16) && aligned_to(loc, 8))
             return launch_fwd_d32(value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, out, stream, table);
     }
+    // (the generic kernels write no table: a buffer the caller handed over gets its stamp cleared)
+    if (table) if (int rc = invalidate_forward_table(table, N, S, M, L, Lq, P, stream)) return rc;
     return launch_fwd_generic<T>(value, shapes, level_start, loc, attn, N, S, M, D, L, Lq, P, out, stream);
 }
 
@@ -144,10 +161,13 @@ static int backward_impl(const T *grad_out, const T *value, const int64_t *shape
     if constexpr (sizeof(T) == 4) {
         if (d32 && aligned_to(grad_out, 16) && aligned_to(value, 16) && aligned_to(grad_value, 16) && aligned_to(loc, 8) &&
             aligned_to(grad_loc, 8))
+        {
+            const Scratch sc = scratch_of(workspace, ws_bytes, flags, N, S, M, D, L, Lq, P, false);
             return launch_bwd_d32(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P,
-                                  grad_value, grad_loc, grad_attn, stream, workspace, ws_bytes,
+                                  grad_value, grad_loc, grad_attn, stream, sc.p, sc.bytes,
                                   (flags & MSDA_FLAG_DETERMINISTIC) != 0,
                                   table_of(workspace, ws_bytes, flags, N, S, M, D, L, Lq, P, false));
+        }
     }
     return launch_bwd_generic<T>(grad_out, value, shapes, level_start, loc, attn, N, S, M, D, L, Lq, P,
                                  grad_value, grad_loc, grad_attn, stream, (flags & MSDA_FLAG_DETERMINISTIC) != 0);
@@ -184,18 +204,20 @@ static int backward_bf16_impl(const uint16_t *grad_out, const uint16_t *value, c
             return msda::set_error(MSDA_ERR_ARGUMENT, "msda_backward_bf16: bf16 grad_value needs the D=32 kernel family (D == 32, "
                                                       "L <= 16, L*P <= 32, 8-byte aligned rows); msda_backward_bf16_gv32 serves "
                                                       "every other shape");
+        const msda::Scratch sc = msda::scratch_of(workspace, ws_bytes, flags, N, S, M, D, L, Lq, P, false);
         return msda::launch_bwd_d32_bf16(grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M,
                                          L, Lq, P, grad_value, grad_sampling_loc, grad_attn_weight, (hipStream_t)stream,
-                                         workspace, ws_bytes, (flags & MSDA_FLAG_DETERMINISTIC) != 0,
+                                         sc.p, sc.bytes, (flags & MSDA_FLAG_DETERMINISTIC) != 0,
                                          msda::table_of(workspace, ws_bytes, flags, N, S, M, D, L, Lq, P, false));
     } else {
         if (!d32)                                                   // element-wise accesses: any D, any element offset
             return msda::launch_bwd_generic<float>(grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, N,
                                                    S, M, D, L, Lq, P, grad_value, grad_sampling_loc, grad_attn_weight,
                                                    (hipStream_t)stream, (flags & MSDA_FLAG_DETERMINISTIC) != 0);
+        const msda::Scratch sc = msda::scratch_of(workspace, ws_bytes, flags, N, S, M, D, L, Lq, P, false);
         return msda::launch_bwd_d32_bf16_gv32(grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S,
                                               M, L, Lq, P, grad_value, grad_sampling_loc, grad_attn_weight,
-                                              (hipStream_t)stream, workspace, ws_bytes, (flags & MSDA_FLAG_DETERMINISTIC) != 0,
+                                              (hipStream_t)stream, sc.p, sc.bytes, (flags & MSDA_FLAG_DETERMINISTIC) != 0,
                                               msda::table_of(workspace, ws_bytes, flags, N, S, M, D, L, Lq, P, false));
     }
 }
@@ -252,6 +274,10 @@ static int forward_bf16_impl(const uint16_t *value, const int64_t *spatial_shape
     if (S == 0) {
         const hipError_t e = hipMemsetAsync(out, 0, 2 * (size_t)N * Lq * M * D, (hipStream_t)stream);
         return e == hipSuccess ? MSDA_OK : msda::set_error(MSDA_ERR_LAUNCH, hipGetErrorString(e));
+    }
+    if (!msda::use_d32(N, S, M, D, L, Lq, P) || !msda::aligned_to(value, 8) || !msda::aligned_to(out, 8) ||
+        !msda::aligned_to(sampling_loc, 8)) {
+        if (table) if (int rc = msda::invalidate_forward_table(table, N, S, M, L, Lq, P, (hipStream_t)stream)) return rc;
     }
     if (!msda::use_d32(N, S, M, D, L, Lq, P) || !msda::aligned_to(value, 8) || !msda::aligned_to(out, 8) ||
         !msda::aligned_to(sampling_loc, 8))
@@ -325,7 +351,12 @@ unsigned long long msda_backward_workspace_bytes(int N, int S, int M, int D, int
 {
     if (N <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Lq <= 0 || P <= 0) return 0;
     if (msda::g_force_path == MSDA_PATH_GENERIC) return 0;
-    return (unsigned long long)msda::backward_workspace_bytes(N, S, M, D, L, Lq, P, flags);
+    // with MSDA_FLAG_FORWARD_TABLE: the forward's table (rounded up to 256 bytes) first, the call's scratch behind it
+    const bool prologue = (flags & MSDA_FLAG_PROLOGUE) != 0;
+    const size_t table = (flags & MSDA_FLAG_FORWARD_TABLE) ? msda::forward_table_bytes(N, S, M, D, L, Lq, P, prologue) : 0;
+    const size_t scratch = msda::backward_workspace_bytes(N, S, M, D, L, Lq, P, flags);
+    if (table == 0) return (unsigned long long)scratch;
+    return (unsigned long long)(scratch ? msda::table_span(N, S, M, D, L, Lq, P, prologue) + scratch : table);
 }
 
 int msda_backward_ws_f32(const float *grad_out, const float *value, const int64_t *spatial_shapes,
@@ -440,10 +471,11 @@ int msda_backward_prologue_ws_f32(const float *grad_out, const float *value, con
         !msda::aligned_to(sampling_loc, 8) || !msda::aligned_to(grad_reference_points, 8))
         return msda::refuse_unaligned("msda_backward_prologue_f32");
     msda::begin_call();
+    const msda::Scratch sc = msda::scratch_of(workspace, (size_t)workspace_bytes, flags, N, S, M, D, L, Lq, P, true);
     return msda::launch_bwd_prologue(grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M, L,
                                      Lq, P, grad_value, ld_grad_offsets, ld_grad_logits, grad_sampling_offsets,
-                                     grad_attn_logits, grad_reference_points, (hipStream_t)stream, workspace,
-                                     (size_t)workspace_bytes, (flags & MSDA_FLAG_DETERMINISTIC) != 0,
+                                     grad_attn_logits, grad_reference_points, (hipStream_t)stream, sc.p,
+                                     sc.bytes, (flags & MSDA_FLAG_DETERMINISTIC) != 0,
                                      msda::table_of(workspace, (size_t)workspace_bytes, flags, N, S, M, D, L, Lq, P, true));
 }
 
@@ -495,10 +527,11 @@ int msda_backward_prologue_bf16_gv32(const uint16_t *grad_out, const uint16_t *v
         !msda::aligned_to(sampling_loc, 8) || !msda::aligned_to(grad_reference_points, 8))
         return msda::refuse_unaligned("msda_backward_prologue_bf16_gv32");
     msda::begin_call();
+    const msda::Scratch sc = msda::scratch_of(workspace, (size_t)workspace_bytes, flags, N, S, M, D, L, Lq, P, true);
     return msda::launch_bwd_prologue_bf16(grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M, L,
                                           Lq, P, grad_value, ld_grad_offsets, ld_grad_logits, grad_sampling_offsets,
-                                          grad_attn_logits, grad_reference_points, (hipStream_t)stream, workspace,
-                                          (size_t)workspace_bytes, (flags & MSDA_FLAG_DETERMINISTIC) != 0,
+                                          grad_attn_logits, grad_reference_points, (hipStream_t)stream, sc.p,
+                                          sc.bytes, (flags & MSDA_FLAG_DETERMINISTIC) != 0,
                                           msda::table_of(workspace, (size_t)workspace_bytes, flags, N, S, M, D, L, Lq, P, true));
 }
 

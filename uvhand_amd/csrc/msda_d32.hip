@@ -19,6 +19,7 @@
 //     octets) still put ~2400 wavefronts with 16 row loads each in flight;
 //     SPLIT = 1: one octet per wavefront, no cross-wave reduction (encoder regime,
 //     large batches).
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -85,6 +86,23 @@ constexpr int kMaxRangeEntries = 254;                                          /
 struct alignas(32) RangeHeader { int magic, W, L, tiled, tp_cap, pad[3]; };    // entries follow
 constexpr int kRangeMagic = 0x4d534441;
 __host__ __device__ inline size_t range_header_bytes() { return sizeof(RangeHeader) + (size_t)kMaxRangeEntries * sizeof(RangeEntry); }
+
+// ---- LARGE problems (LDS-stage forward, kept-taps role B): per-RANGE point lists ---------------------------------------------
+// Role B of a multi-pass problem cuts every level into W pixel ranges, and each range's workgroup used to re-scan ALL Lq*P
+// sampling points of its (batch, head, level) for the ~1/W that have a tap on its rows (cfg-2 encoder: 6 x 12 240 points per
+// level and pair, 12 us of a 53 us workgroup; profiles/r04_notes.md section 4).  The FORWARD of the same autograd node visits
+// every point anyway (fwd_d32_lds_kernel: one lane per point): with a list buffer it also appends the point's index q*P + p
+// (16 bits) to the list of every range its taps may touch — per forward workgroup (= chunk c of the pair's queries) one
+// fixed-capacity sub-list per (pair, level, range), filled through LDS counters, so no global atomics and no second pass.
+// Role B reads the `chunks` sub-lists of its own range (2 bytes per kept point, contiguous) in place of the scan.  The
+// lists are a SUPERSET (range of the first and of the last tap pixel, border validity ignored): role B works out the exact
+// taps of the listed points as it does for scanned ones, so results do not depend on where a list came from.
+//   layout: [ListHeader 64 B] [counts: u16 [pairs*L*W][chunks], padded to 64 B] [lists: u16 [pairs*L*W][chunks][cap]]
+struct alignas(64) ListHeader { int magic, W, L, chunks, cap, NP, pairs, qw, pad[8]; };
+constexpr int kListMagic = 0x4d53444c;
+constexpr int kMaxListRanges = 256;                                             // L * W (the forward keeps that many LDS counters)
+struct ListOut { ListHeader *hdr; uint16_t *counts; uint16_t *lists; int W, cap; };         // forward side (lists = null: none)
+struct ListIn { const ListHeader *hdr; const uint16_t *counts; const uint16_t *lists; int chunks, cap; };   // role B side
 
 // The table entry of a point from its geometry (the same values the tap records are made of, so that the table and a scan
 // of sampling_loc / attn_weight give role B bit-identical records).
@@ -680,7 +698,7 @@ __global__ __launch_bounds__(kSBlock, 4) void bwd_fused_lds_d32_kernel(
     const int64_t *__restrict__ level_start, const float *__restrict__ loc, const float *__restrict__ attn, int S, int M, int L,
     int Lq, int P, int p_shift, int lp_shift, int tp_cap, int W, int nB, int chunks, int qw, int stage_rows,
     GT *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attn, const PrologueOut pro, int xcd,
-    int lds_bytes)
+    int lds_bytes, const ListIn li = ListIn{nullptr, nullptr, nullptr, 0, 0})
 {
     static_assert(kSBlock == kLBlock, "both roles run in 512-thread workgroups");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -697,7 +715,7 @@ __global__ __launch_bounds__(kSBlock, 4) void bwd_fused_lds_d32_kernel(
             return;
         }
         bwd_value_body<ACC, kSinglePPT, VT, GT, false, DET>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift,
-                                                            tp_cap, grad_value, ti, Wl, l, pr, smem);
+                                                            tp_cap, grad_value, ti, Wl, l, pr, smem, li);
     } else {
         bwd_query_lds_body<VT, FUSED, NS>(grad_out, value, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, lp_shift, chunks,
                                           qw, stage_rows, grad_loc, grad_attn, pro,
@@ -815,14 +833,16 @@ static LdsPlan plan_lds(int N, int S, int M, int L, int Lq, int P, long long rol
 template <typename VT, bool FUSED>
 static int launch_fwd_lds(const LdsPlan &lp, const VT *value, const int64_t *shapes, const int64_t *level_start, const float *loc,
                           const float *attn, int N, int S, int M, int L, int Lq, int P, VT *out, const PrologueIn &pro,
-                          hipStream_t stream)
+                          hipStream_t stream, const ListOut lo = ListOut{nullptr, nullptr, nullptr, 0, 0})
 {
     const dim3 grid((unsigned)(N * M * lp.chunks));
+    // (with lists to write: LDS cursors [L*W] and the ranges' first pixels [L][W + 1] behind the records)
+    const size_t lds = lp.lds + (lo.lists ? (size_t)(L * lo.W + L * (lo.W + 1)) * sizeof(int) : 0);
 #define MSDA_LAUNCH_FL(NS_)                                                                            \
-    do { if (int rc = allow_lds(reinterpret_cast<const void *>(fwd_d32_lds_kernel<VT, FUSED, NS_>), lp.lds)) return rc;            \
-         hipLaunchKernelGGL((fwd_d32_lds_kernel<VT, FUSED, NS_>), grid, dim3(kLBlock), lp.lds, stream, value, shapes, level_start, \
+    do { if (int rc = allow_lds(reinterpret_cast<const void *>(fwd_d32_lds_kernel<VT, FUSED, NS_>), lds)) return rc;               \
+         hipLaunchKernelGGL((fwd_d32_lds_kernel<VT, FUSED, NS_>), grid, dim3(kLBlock), lds, stream, value, shapes, level_start,    \
                             loc, attn, S, M, L, Lq, P, pow2_shift(P), pow2_shift(L * P), lp.chunks, lp.qw, lp.stage_rows, out,   \
-                            pro, xcd_remap()); } while (0)
+                            pro, xcd_remap(), lo); } while (0)
     if (8 * L * P <= kWave) MSDA_LAUNCH_FL(1); else MSDA_LAUNCH_FL(2);             // plan_lds: L*P <= 16
 #undef MSDA_LAUNCH_FL
     return check_launch("msda forward (d32, LDS stage)");
@@ -845,14 +865,16 @@ static int launch_query_lds(const LdsPlan &lp, const VT *grad_out, const VT *val
 }
 
 // ranges per level / rows per range of the backward's role-B plan, for the header the forward writes behind the point table
-// (0: no header — the plan has more slots than the header holds)
 static void table_header_plan(int N, int S, int M, int L, int Lq, int P, int &W, int &tp_cap);
-// the header behind the point entries of a table (null: no table, or a plan with more slots than the header holds)
+// the header behind the point entries of a table (null: no table)
 static const RangeHeader *table_header_of(const PointEntry *table, int N, int M, int L, int Lq, int P, int W)
 {
-    if (!table || W * L > kMaxRangeEntries) return nullptr;
+    if (!table) return nullptr;
     return reinterpret_cast<const RangeHeader *>(table + (long long)N * M * L * Lq * P);
 }
+
+// per-range point lists of large problems (ListHeader): plan_lists below
+static ListOut list_out(void *table, int N, int S, int M, int L, int Lq, int P);
 
 template <typename VT>
 static int launch_fwd_d32_t(const VT *value, const int64_t *shapes, const int64_t *level_start,
@@ -862,7 +884,7 @@ static int launch_fwd_d32_t(const VT *value, const int64_t *shapes, const int64_
     const LdsPlan lp = plan_lds<VT>(N, S, M, L, Lq, P);
     if (lp.use)
         return launch_fwd_lds<VT, false>(lp, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, out,
-                                         PrologueIn{nullptr, nullptr, nullptr, 0, 0}, stream);
+                                         PrologueIn{nullptr, nullptr, nullptr, 0, 0}, stream, list_out(table, N, S, M, L, Lq, P));
     const int items = N * Lq * M, LP = L * P;
     const int item_stride = LP * kRecBytes + kItemPad;
     const int split = pick_split(items, LP);
@@ -933,6 +955,52 @@ static ValuePlan plan_value(int N, int S, int M, int L, int Lq, int P, int targe
     return pl;
 }
 
+static ValuePlan plan_value_f32(int N, int S, int M, int L, int Lq, int P) { return plan_value<float>(N, S, M, L, Lq, P, bwd_target_wgs(), false); }
+
+// Per-range point lists (ListHeader): where the forward is the LDS-stage kernel and role B the kept-taps pass with W ranges per
+// level — the same plan functions the launchers run, so the forward's writer and the backward's reader agree on the layout
+// (the header repeats it and role B checks).  Row storage does not matter: chunks / qw do not depend on it.
+struct ListPlan { bool use; int W, chunks, cap; size_t counts_off, lists_off, bytes; };
+static ListPlan plan_lists(int N, int S, int M, int L, int Lq, int P)
+{
+    static const int enabled = env_int("MSDA_LISTS", 1);                // A/B knob (tuning build): 0 = role B scans
+    ListPlan lp{false, 0, 0, 0, 0, 0, 0};
+    if (!enabled) return lp;
+    const LdsPlan f = plan_lds<float>(N, S, M, L, Lq, P);
+    if (!f.use) return lp;
+    const ValuePlan pl = plan_value_f32(N, S, M, L, Lq, P);
+    const long long NP = (long long)Lq * P, pairs = (long long)N * M, cap = ((long long)f.qw * P + 7) & ~7LL;
+    if (pl.acc != kAccWide || pl.ppt != kSinglePPT || NP > kWideMaxStep || pl.W * L > kMaxListRanges) return lp;
+    const long long sublists = pairs * L * pl.W * f.chunks;
+    if (cap > 65528 || (long long)f.chunks * cap >= (1LL << 23) || sublists * cap >= (1LL << 31)) return lp;
+    lp.use = true; lp.W = pl.W; lp.chunks = f.chunks; lp.cap = (int)cap;
+    lp.counts_off = sizeof(ListHeader);
+    lp.lists_off = lp.counts_off + (((size_t)sublists * 2 + 63) & ~(size_t)63);
+    lp.bytes = lp.lists_off + (size_t)sublists * (size_t)cap * 2;
+    return lp;
+}
+static ListOut list_out(void *table, int N, int S, int M, int L, int Lq, int P)
+{
+    ListOut lo{nullptr, nullptr, nullptr, 0, 0};
+    if (!table) return lo;
+    const ListPlan lp = plan_lists(N, S, M, L, Lq, P);
+    if (!lp.use) return lo;
+    unsigned char *b = static_cast<unsigned char *>(table);
+    return ListOut{reinterpret_cast<ListHeader *>(b), reinterpret_cast<uint16_t *>(b + lp.counts_off),
+                   reinterpret_cast<uint16_t *>(b + lp.lists_off), lp.W, lp.cap};
+}
+// (role B reads them only where its own plan is the kept-taps pass with the same W; never under the deterministic flag)
+static ListIn list_in(const void *table, int N, int S, int M, int L, int Lq, int P, int acc, int W, bool deterministic)
+{
+    ListIn li{nullptr, nullptr, nullptr, 0, 0};
+    if (!table || deterministic || acc != kAccWide) return li;
+    const ListPlan lp = plan_lists(N, S, M, L, Lq, P);
+    if (!lp.use || lp.W != W) return li;
+    const unsigned char *b = static_cast<const unsigned char *>(table);
+    return ListIn{reinterpret_cast<const ListHeader *>(b), reinterpret_cast<const uint16_t *>(b + lp.counts_off),
+                  reinterpret_cast<const uint16_t *>(b + lp.lists_off), lp.chunks, lp.cap};
+}
+
 static int allow_lds(const void *fn, size_t bytes)
 {
     if (bytes <= 64 * 1024) return MSDA_OK;
@@ -967,12 +1035,25 @@ static size_t prologue_heads_bytes(int N, int M, int L, int Lq) { return ((size_
 
 static void table_header_plan(int N, int S, int M, int L, int Lq, int P, int &W, int &tp_cap)
 {
+    // (W >= 1 always: the header's magic is the table's "written" stamp; a plan with more slots than the header holds gets
+    // the stamp and no entries — write_range_header)
     const ValuePlan pl = plan_value<float>(N, S, M, L, Lq, P, bwd_target_wgs(), false);
-    W = pl.W * L <= kMaxRangeEntries ? pl.W : 0;
+    W = pl.W;
     tp_cap = pl.tp_cap;
 }
 
 #if MSDA_D32_HAS(0)
+// A forward call that was handed a table buffer but runs kernels that write none (the generic family: rows that are not
+// 16-byte aligned) clears the table's stamp, so that the backward can never mistake an earlier call's contents — the caching
+// allocator may hand the same block out again — for this call's.
+int invalidate_forward_table(void *table, int N, int S, int M, int L, int Lq, int P, hipStream_t stream)
+{
+    const size_t off = plan_lds<float>(N, S, M, L, Lq, P).use ? 0 : (size_t)N * M * L * Lq * P * sizeof(PointEntry);
+    static_assert(offsetof(RangeHeader, magic) == 0 && offsetof(ListHeader, magic) == 0, "the stamp is the header's first word");
+    const hipError_t e = hipMemsetAsync(static_cast<unsigned char *>(table) + off, 0, sizeof(int), stream);
+    return e == hipSuccess ? MSDA_OK : set_error(MSDA_ERR_LAUNCH, hipGetErrorString(e));
+}
+
 // Bytes of the point table a forward of this geometry can leave for its backward (msda_forward_workspace_bytes): non-zero
 // exactly where the backward would take the small-problem role B (plan_fused.fixed: single pass, every workgroup resident,
 // no LDS stage) — the same plan functions the launchers run.  prologue: the fused-prologue entry points (whole queries per
@@ -980,7 +1061,10 @@ static void table_header_plan(int N, int S, int M, int L, int Lq, int P, int &W,
 size_t forward_table_bytes(int N, int S, int M, int D, int L, int Lq, int P, bool prologue)
 {
     if (!d32_supported(N, S, M, D, L, Lq, P) || (prologue && !prologue_supported(N, S, M, D, L, Lq, P))) return 0;
-    if (plan_lds<float>(N, S, M, L, Lq, P).use) return 0;
+    if (plan_lds<float>(N, S, M, L, Lq, P).use) {                       // large problems: per-range point lists, if role B reads them
+        const ListPlan ll = plan_lists(N, S, M, L, Lq, P);
+        return ll.use ? ll.bytes : 0;
+    }
     const ValuePlan pl = plan_value<float>(N, S, M, L, Lq, P, bwd_target_wgs(), false);
     if (pl.acc != kAccNone || pl.ppt != kSinglePPT) return 0;
     const FusedPlan fp = plan_fused(N * Lq * M, L * P, pick_split(N * Lq * M, L * P), (long long)pl.W * N * M * L, pl.acc, prologue ? M : 0, false);
@@ -1043,12 +1127,13 @@ static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *
             // (at least what the dense coarse-level body needs: two such workgroups still share a CU)
             const size_t flds = max(max(pl.lds, lds_a.lds), (size_t)dense_lds_bytes());
             const bool dense = dense_on() && pl.W <= 2;
+            const ListIn lists = list_in(table, N, S, M, L, Lq, P, pl.acc, pl.W, deterministic);
 #define MSDA_LAUNCH_FLD__(AC, NS_, DT, DN)                                                             \
             do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_fused_lds_d32_kernel<AC, VT, false, GT, NS_, DT, DN>), flds)) return rc; \
             hipLaunchKernelGGL((bwd_fused_lds_d32_kernel<AC, VT, false, GT, NS_, DT, DN>), fgrid, dim3(kSBlock), flds, stream, grad_out,  \
                                value, shapes, level_start, loc, attn, S, M, L, Lq, P, ps, lps, pl.tp_cap, pl.W, (int)nB,          \
                                lds_a.chunks, lds_a.qw, lds_a.stage_rows, grad_value, grad_loc, grad_attn,                        \
-                               PrologueOut{nullptr, 0, 0}, xcd, (DN) ? (int)flds : 0); } while (0)
+                               PrologueOut{nullptr, 0, 0}, xcd, (DN) ? (int)flds : 0, lists); } while (0)
 #define MSDA_LAUNCH_FLD_(AC, NS_, DT) do { if (dense) MSDA_LAUNCH_FLD__(AC, NS_, DT, true); else MSDA_LAUNCH_FLD__(AC, NS_, DT, false); } while (0)
 #define MSDA_LAUNCH_FLD(AC, NS_) do { if (deterministic) MSDA_LAUNCH_FLD_(AC, NS_, true); else MSDA_LAUNCH_FLD_(AC, NS_, false); } while (0)
             const bool one_slot = 8 * LP <= kWave;
@@ -1163,7 +1248,9 @@ static int launch_fwd_prologue_t(const VT *value, const int64_t *shapes, const i
     const dim3 grid((items + ipw - 1) / ipw + (hdr_W > 0 ? 1 : 0)), block(kBlock);      // (+ the header's workgroup)
     const PrologueIn pro{ref, loc_out, attn_out, (int)((ld_offsets - 2LL * M * LP) / 2), (int)(ld_logits - (long long)M * LP)};
     const LdsPlan lp = plan_lds<VT>(N, S, M, L, Lq, P);
-    if (lp.use) return launch_fwd_lds<VT, true>(lp, value, shapes, level_start, offsets, logits, N, S, M, L, Lq, P, out, pro, stream);
+    if (lp.use)
+        return launch_fwd_lds<VT, true>(lp, value, shapes, level_start, offsets, logits, N, S, M, L, Lq, P, out, pro, stream,
+                                        list_out(table, N, S, M, L, Lq, P));
     const int xcd = xcd_remap();
 #define MSDA_LAUNCH_FP(SP)                                                                             \
     hipLaunchKernelGGL((fwd_d32_kernel<SP, VT, true>), grid, block, lds, stream, value, shapes, level_start, offsets, \
@@ -1205,12 +1292,13 @@ static int launch_bwd_prologue_t(const VT *grad_out, const VT *value, const int6
         const size_t llds = max(max(pl.lds, lq.lds), (size_t)dense_lds_bytes());
 #define MSDA_LAUNCH_BPL(AC, NS_) do { if (deterministic) MSDA_LAUNCH_BPL_(AC, NS_, true); else MSDA_LAUNCH_BPL_(AC, NS_, false); } while (0)
         const bool dense = dense_on() && pl.W <= 2;
+        const ListIn lists = list_in(table, N, S, M, L, Lq, P, pl.acc, pl.W, deterministic);
 #define MSDA_LAUNCH_BPL_(AC, NS_, DT) do { if (dense) MSDA_LAUNCH_BPL__(AC, NS_, DT, true); else MSDA_LAUNCH_BPL__(AC, NS_, DT, false); } while (0)
 #define MSDA_LAUNCH_BPL__(AC, NS_, DT, DN)                                                             \
         do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_fused_lds_d32_kernel<AC, VT, true, float, NS_, DT, DN>), llds)) return rc; \
         hipLaunchKernelGGL((bwd_fused_lds_d32_kernel<AC, VT, true, float, NS_, DT, DN>), lgrid, dim3(kSBlock), llds, stream, grad_out,   \
                            value, shapes, level_start, loc, attn, S, M, L, Lq, P, ps, lps, pl.tp_cap, pl.W, (int)nB, lq.chunks,   \
-                           lq.qw, lq.stage_rows, grad_value, grad_offsets, grad_logits, pro_h, xcd_remap(), (DN) ? (int)llds : 0); } while (0)
+                           lq.qw, lq.stage_rows, grad_value, grad_offsets, grad_logits, pro_h, xcd_remap(), (DN) ? (int)llds : 0, lists); } while (0)
         const bool one_slot = 8 * LP <= kWave;
         if (pl.acc == kAccNone) { if (one_slot) MSDA_LAUNCH_BPL(kAccNone, 1); else MSDA_LAUNCH_BPL(kAccNone, 2); }
         else                    { if (one_slot) MSDA_LAUNCH_BPL(kAccWide, 1); else MSDA_LAUNCH_BPL(kAccWide, 2); }
@@ -1357,8 +1445,10 @@ static int describe_plan_t(int N, int S, int M, int L, int Lq, int P, bool prolo
     const bool lds_ok = la.use && pl.ppt == kSinglePPT && (pl.acc == kAccNone || pl.acc == kAccWide) && (!prologue || has_ws);
     if (lds_ok)
         // dense_px: a level of at most this many pixels (that the launch deals W workgroups) goes to the matrix cores
-        put(" bwd=fused_lds(acc=%s,W=%d,tp_cap=%d,roleB=%lld,roleA=%d,qw=%d,dense_px=%d%s%s)", acc, pl.W, pl.tp_cap, nB, N * M * la.chunks, la.qw,
-            !dense_on() || pl.W > 2 ? 0 : pl.W == 2 ? kDenseMaxRows : kDensePassRows, det ? ",det" : "", prologue ? ",heads_reduce" : "");
+        // lists: role B takes its points from the per-range lists a forward with a workspace leaves (msda_forward_ws_*)
+        put(" bwd=fused_lds(acc=%s,W=%d,tp_cap=%d,roleB=%lld,roleA=%d,qw=%d,dense_px=%d%s%s%s)", acc, pl.W, pl.tp_cap, nB, N * M * la.chunks, la.qw,
+            !dense_on() || pl.W > 2 ? 0 : pl.W == 2 ? kDenseMaxRows : kDensePassRows, det ? ",det" : "", prologue ? ",heads_reduce" : "",
+            (!det && pl.acc == kAccWide && plan_lists(N, S, M, L, Lq, P).use && plan_lists(N, S, M, L, Lq, P).W == pl.W) ? ",lists" : "");
     else if (pl.ppt == kSinglePPT && pl.acc != kAccTile) {
         const FusedPlan fp = plan_fused(items, LP, pick_split(items, LP), nB, pl.acc, prologue ? M : 0, det);
         put(" bwd=fused(acc=%s,W=%d,tp_cap=%d,roleB=%lld,roleA=%d,split=%d,%s%s)", acc, pl.W, pl.tp_cap, nB,

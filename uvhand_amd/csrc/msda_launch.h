@@ -50,6 +50,8 @@ int launch_bwd_d32(const float *grad_out, const float *value, const int64_t *sha
 // the point table a small problem's forward can leave for its backward (bytes; 0 = the backward's plan reads none); `table`
 // arguments of the launchers below: that table (forward: written, backward: read), or null
 size_t forward_table_bytes(int N, int S, int M, int D, int L, int Lq, int P, bool prologue);
+// clears the 'written' stamp of a table buffer that a forward call could not fill (see msda_d32.hip)
+int invalidate_forward_table(void *table, int N, int S, int M, int L, int Lq, int P, hipStream_t stream);
 // scratch the D = 32 backward can use to cut long levels into query chunks (0 = none needed); see msda.h
 size_t backward_workspace_bytes(int N, int S, int M, int D, int L, int Lq, int P, unsigned flags);
 

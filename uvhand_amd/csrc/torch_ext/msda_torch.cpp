@@ -77,8 +77,11 @@ void once_differentiable(const torch::autograd::variable_list &grads, const char
 // include/msda.h); undefined where the backward's plan reads none.
 at::Tensor forward_table(const at::Tensor &like, const Dims &d, unsigned flags)
 {
-    const unsigned long long n = msda_forward_workspace_bytes(d.N, d.S, d.M, d.D, d.L, d.Lq, d.P, flags);
-    return n ? at::empty({(int64_t)n}, like.options().dtype(at::kByte)) : at::Tensor();
+    unsigned long long n = msda_forward_workspace_bytes(d.N, d.S, d.M, d.D, d.L, d.Lq, d.P, flags);
+    if (!n) return at::Tensor();
+    // the same buffer goes to the backward with MSDA_FLAG_FORWARD_TABLE: the table first, that call's scratch behind it
+    n = std::max(n, msda_backward_workspace_bytes(d.N, d.S, d.M, d.D, d.L, d.Lq, d.P, flags | MSDA_FLAG_FORWARD_TABLE));
+    return at::empty({(int64_t)n}, like.options().dtype(at::kByte));
 }
 
 at::Tensor forward_t(const at::Tensor &value, const at::Tensor &shapes, const at::Tensor &lsi, const at::Tensor &loc,
@@ -127,9 +130,10 @@ std::vector<at::Tensor> backward_t(const at::Tensor &value, const at::Tensor &sh
     unsigned flags = deterministic ? MSDA_FLAG_DETERMINISTIC : 0u;
     at::Tensor ws;
     // (also without flags: the library says how much scratch a call of this geometry can use, mostly none)
-    unsigned long long nbytes = msda_backward_workspace_bytes(d.N, d.S, d.M, d.D, d.L, d.Lq, d.P, flags);
-    if (nbytes) ws = at::empty({(int64_t)nbytes}, value.options().dtype(at::kByte));
-    else if (table.defined()) { ws = table; nbytes = (unsigned long long)table.numel(); flags |= MSDA_FLAG_FORWARD_TABLE; }   // the forward's point table
+    unsigned long long nbytes = 0;
+    if (table.defined()) { ws = table; nbytes = (unsigned long long)table.numel(); flags |= MSDA_FLAG_FORWARD_TABLE; }   // the forward's table, scratch behind it
+    else if ((nbytes = msda_backward_workspace_bytes(d.N, d.S, d.M, d.D, d.L, d.Lq, d.P, flags)) != 0)
+        ws = at::empty({(int64_t)nbytes}, value.options().dtype(at::kByte));
     if (value.scalar_type() == at::kFloat)
         rc = msda_backward_ws_f32(grad_out.data_ptr<float>(), value.data_ptr<float>(), shapes.data_ptr<int64_t>(),
                                   lsi.data_ptr<int64_t>(), loc.data_ptr<float>(), attn.data_ptr<float>(), d.N, d.S, d.M, d.D, d.L,
@@ -258,9 +262,10 @@ public:
         auto gv = at::empty_like(v16, v16.options().dtype(gv32 ? at::kFloat : at::kBFloat16));
         auto gl = at::empty_like(l32), ga = at::empty_like(a32);
         at::Tensor ws;
-        unsigned long long nbytes = msda_backward_workspace_bytes(d.N, d.S, d.M, d.D, d.L, d.Lq, d.P, flags);
-        if (nbytes) ws = at::empty({(int64_t)nbytes}, v16.options().dtype(at::kByte));
-        else if (saved[5].defined()) { ws = saved[5]; nbytes = (unsigned long long)ws.numel(); flags |= MSDA_FLAG_FORWARD_TABLE; }
+        unsigned long long nbytes = 0;
+        if (saved[5].defined()) { ws = saved[5]; nbytes = (unsigned long long)ws.numel(); flags |= MSDA_FLAG_FORWARD_TABLE; }
+        else if ((nbytes = msda_backward_workspace_bytes(d.N, d.S, d.M, d.D, d.L, d.Lq, d.P, flags)) != 0)
+            ws = at::empty({(int64_t)nbytes}, v16.options().dtype(at::kByte));
         auto stream = (msda_stream_t)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(v16.device().index()).stream();
         int rc;
         if (gv32)
@@ -485,11 +490,12 @@ public:
         // the reference points
         const bool det = ctx->saved_data["det"].toBool() || at::globalContext().deterministicAlgorithms();
         const unsigned flags = MSDA_FLAG_PROLOGUE | (det ? MSDA_FLAG_DETERMINISTIC : 0u);
-        unsigned long long nbytes = msda_backward_workspace_bytes(N, S, M, D, L, Lq, P, flags);
+        unsigned long long nbytes = 0;
         at::Tensor ws;
         unsigned table_flag = 0;
-        if (nbytes) ws = at::empty({(int64_t)nbytes}, q2.options().dtype(at::kByte));
-        else if (sv[12].defined()) { ws = sv[12]; nbytes = (unsigned long long)ws.numel(); table_flag = MSDA_FLAG_FORWARD_TABLE; }
+        if (sv[12].defined()) { ws = sv[12]; nbytes = (unsigned long long)ws.numel(); table_flag = MSDA_FLAG_FORWARD_TABLE; }   // table first, scratch behind it
+        else if ((nbytes = msda_backward_workspace_bytes(N, S, M, D, L, Lq, P, flags)) != 0)
+            ws = at::empty({(int64_t)nbytes}, q2.options().dtype(at::kByte));
         auto gv = at::empty_like(value), gproj = at::empty({(int64_t)N * Lq, 3LL * mlp}, q2.options());
         auto gref = at::empty({N, Lq, L, 2}, q2.options());
         raise_if(msda_backward_prologue_ws_f32(g_sampled.data_ptr<float>(), value.data_ptr<float>(), shapes.data_ptr<int64_t>(),
@@ -618,11 +624,12 @@ public:
         // the sampling kernels: bf16 rows in, float32 gradients out
         const bool det = ctx->saved_data["det"].toBool() || at::globalContext().deterministicAlgorithms();
         const unsigned flags = MSDA_FLAG_PROLOGUE | (det ? MSDA_FLAG_DETERMINISTIC : 0u);
-        unsigned long long nbytes = msda_backward_workspace_bytes(N, S, M, D, L, Lq, P, flags);
+        unsigned long long nbytes = 0;
         at::Tensor ws;
         unsigned table_flag = 0;
-        if (nbytes) ws = at::empty({(int64_t)nbytes}, q2.options().dtype(at::kByte));
-        else if (sv[12].defined()) { ws = sv[12]; nbytes = (unsigned long long)ws.numel(); table_flag = MSDA_FLAG_FORWARD_TABLE; }
+        if (sv[12].defined()) { ws = sv[12]; nbytes = (unsigned long long)ws.numel(); table_flag = MSDA_FLAG_FORWARD_TABLE; }   // table first, scratch behind it
+        else if ((nbytes = msda_backward_workspace_bytes(N, S, M, D, L, Lq, P, flags)) != 0)
+            ws = at::empty({(int64_t)nbytes}, q2.options().dtype(at::kByte));
         auto gv = at::empty({N, S, C}, q2.options()), gproj = at::empty({(int64_t)N * Lq, 3LL * mlp}, q2.options());
         auto gref = at::empty({N, Lq, L, 2}, q2.options());
         raise_if(msda_backward_prologue_bf16_gv32(reinterpret_cast<const uint16_t *>(g_sampled.data_ptr<at::BFloat16>()),
