@@ -25,9 +25,10 @@ while the kernel sources are the profiled ones) and `cpu_baseline` (the PyTorch-
 fallback port timed on the host cores of this node; test infrastructure under oracle/,
 never the thing measured as `value`).  At N = 1 the same line carries the rest of
 DESIGN.md's performance table, measured in the same run (none of it is `value`):
-`workloads` — cfg2_encoder / cfg4_decoder / cfg4_encoder in fp32 and cfg2_decoder with
-bf16 rows: graph-replay step, the two kernels on their own, algorithmic bytes and
-fractions — and `modules` — the MSDeformAttn module forward+backward at cfg2_decoder and
+`workloads` — cfg2_encoder / cfg4_decoder / cfg4_encoder in fp32, cfg2_decoder with
+bf16 rows, model-like locations (SURVEY 8d distribution B) at cfg2_decoder / cfg4_encoder and one
+row per shape with the deterministic flag: graph-replay step, the two kernels on their own,
+algorithmic bytes and fractions — and `modules` — the MSDeformAttn module forward+backward at cfg2_decoder and
 cfg4_encoder, fp32 and autocast-bf16, per HIP graph and eager wall time (--no-table skips both).
 """
 import argparse
@@ -242,9 +243,10 @@ def timed_us(call, per, stream, budget_s=0.6):
     return 1e3 * event_time_ms(call, n, stream) / per
 
 
-def measure_op(workload, dtype, device, stream, seed, locations="uniform", budget_s=0.6):
+def measure_op(workload, dtype, device, stream, seed, locations="uniform", budget_s=0.6, deterministic=False):
     """One extra row of the performance table (not `value`): the same step as the headline — Function.apply forward +
-    backward, 10 steps per HIP graph — on another workload / storage type, plus the two kernels on their own."""
+    backward, 10 steps per HIP graph — on another workload / storage type / location distribution ("model" =
+    distribution B) / with the deterministic flag, plus the two kernels on their own."""
     from uvhand_amd import _native
     from uvhand_amd.functions import MSDeformAttnBF16Function, MSDeformAttnFunction
     bf16 = dtype == "bf16"
@@ -259,27 +261,41 @@ def measure_op(workload, dtype, device, stream, seed, locations="uniform", budge
         value.grad = loc.grad = attn.grad = None
         apply(value, d["shapes"], d["lsi"], loc, attn, 64).backward(go)
 
+    # (the Functions read the switch when they run: MSDA_DETERMINISTIC=1 for the life of this row's captures)
+    prev_det = os.environ.get("MSDA_DETERMINISTIC")
+    if deterministic:
+        os.environ["MSDA_DETERMINISTIC"] = "1"
     vd, ld, ad = value.detach(), loc.detach(), attn.detach()
     gv32 = bf16 and _native.backward_passes(Lq, P) > 1
     # the two kernels as the autograd step runs them: the forward leaves its point table where the backward's plan reads one
     table = _native.ms_deform_attn_forward(vd, d["shapes"], d["lsi"], ld, ad, 64, with_table=True)[1]
     fwd = lambda: _native.ms_deform_attn_forward(vd, d["shapes"], d["lsi"], ld, ad, 64, with_table=True if table is not None else None)
-    bwd = lambda: _native.ms_deform_attn_backward(vd, d["shapes"], d["lsi"], ld, ad, go, 64, fp32_grad_value=gv32, table=table)
-    row = {"workload": workload, "dtype": dtype, "locations": locations, "N": N, "Lq": Lq, "S": S}
-    with torch.cuda.stream(stream):
-        for name, fn in (("step", step), ("fwd", fwd), ("bwd", bwd)):
-            g = graph_of(fn, stream)
-            row[name + "_us"] = timed_us(g.replay if g is not None else fn, 10 if g is not None else 1, stream, budget_s)
-            del g
-        stream.synchronize()
+    bwd = lambda: _native.ms_deform_attn_backward(vd, d["shapes"], d["lsi"], ld, ad, go, 64, fp32_grad_value=gv32, table=table,
+                                                  deterministic=deterministic)
+    row = {"workload": workload, "dtype": dtype, "locations": locations, "deterministic": bool(deterministic), "N": N, "Lq": Lq, "S": S}
+    try:
+        with torch.cuda.stream(stream):
+            for name, fn in (("step", step), ("fwd", fwd), ("bwd", bwd)):
+                g = graph_of(fn, stream)
+                row[name + "_us"] = timed_us(g.replay if g is not None else fn, 10 if g is not None else 1, stream, budget_s)
+                del g
+            stream.synchronize()
+    finally:
+        if deterministic:
+            if prev_det is None:
+                os.environ.pop("MSDA_DETERMINISTIC", None)
+            else:
+                os.environ["MSDA_DETERMINISTIC"] = prev_det
     fwd_b, bwd_b = algorithmic_bytes(N, S, M, D, L, Lq, P, e=2 if bf16 else 4)
     row.update({"ms_per_step": row["step_us"] * 1e-3, "samples_per_s": N / (row["step_us"] * 1e-6),
                 "fwd_algorithmic_bytes": fwd_b, "bwd_algorithmic_bytes": bwd_b,
                 "fwd_frac": fwd_b / (row["fwd_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
                 "bwd_frac": bwd_b / (row["bwd_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
                 "launch": "hipGraph replay, 10 steps per graph; HIP events"})
-    tr, at = pmc_traffic(workload + ("_bf16" if bf16 else ""), "bwd")
+    tr, at = pmc_traffic(workload + ("_bf16" if bf16 else ""), "bwd") if (locations == "uniform" and not deterministic) else (None, None)
     row["bwd_traffic"] = tr
+    row["bwd_traffic_ratio"] = tr / bwd_b if tr else None
+    row["forward_table_bytes"] = int(table.numel()) if table is not None else 0
     return row
 
 
@@ -524,6 +540,10 @@ def main():
                        "step": "MSDeformAttnFunction.apply forward + backward (3 grads)",
                        "launch": ("hipGraph replay, %d step(s) per graph" % per_graph) if graph is not None
                                  else "eager autograd",
+                       # the same step launched the way the reference's training loop does (plain autograd calls, no graph)
+                       # and as one graph launch per step: NOT `value`, here so that the launch mode cannot be missed
+                       "eager_ms_per_step": side.get("eager_ms_per_step"),
+                       "graph1_ms_per_step": side.get("graph1_ms_per_step"),
                        "sharding": "batch-sharded, no collective",
                        "timing": "median of %d blocks of %d steps, each bracketed by barrier + synchronize; max over ranks "
                                  "per block (min %.4f / max %.4f ms per step)" % (len(block_max), args.steps,
@@ -534,7 +554,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "backward: msda::bwd_fused_d32_kernel (grad_value sort+gather "
                                                     "workgroups and grad_loc/grad_attn workgroups in one launch)",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_profiled_at": traffic_at, "sources_sha16": kernel_sources_sha16(),
+                         "traffic": traffic, "traffic_ratio": (traffic / bwd_b) if traffic else None,
+                         "traffic_profiled_at": traffic_at, "sources_sha16": kernel_sources_sha16(),
                          "algorithmic_bytes": bwd_b, "ms": kt["bwd"]},
             "kernels": {"fwd": {"ms": kt["fwd"], "algorithmic_bytes": fwd_b,
                                 "GBps": fwd_b / (kt["fwd"] * 1e-3) / 1e9},
@@ -568,14 +589,19 @@ def main():
         if world == 1 and not args.no_table:
             # the rest of DESIGN.md's performance table, measured in the same run (none of it is `value`)
             seed = harness.rank_seed(1000, rank)
-            table = [(w, "f32") for w in WORKLOADS if (w, "f32") != (args.workload, args.dtype)]
-            table += [("cfg2_decoder", "bf16")] if (args.workload, args.dtype) != ("cfg2_decoder", "bf16") else []
+            table = [(w, "f32", "uniform", False) for w in WORKLOADS if (w, "f32") != (args.workload, args.dtype)]
+            table += [("cfg2_decoder", "bf16", "uniform", False)] if (args.workload, args.dtype) != ("cfg2_decoder", "bf16") else []
+            # SURVEY 8d distribution B (model-like locations) on the headline shape and the training encoder shape, and the
+            # deterministic flag's cost on every shape
+            table += [("cfg2_decoder", "f32", "model", False), ("cfg4_encoder", "f32", "model", False)]
+            table += [(w, "f32", "uniform", True) for w in WORKLOADS]
             result["workloads"] = []
-            for w, dt in table:
+            for w, dt, locs, det in table:
                 try:
-                    result["workloads"].append(measure_op(w, dt, device, stream, seed))
+                    result["workloads"].append(measure_op(w, dt, device, stream, seed, locs, 0.4 if (det or locs != "uniform") else 0.6, det))
                 except Exception as exc:                  # a row that cannot be measured says so; the headline stands
-                    result["workloads"].append({"workload": w, "dtype": dt, "error": "%s: %s" % (type(exc).__name__, exc)})
+                    result["workloads"].append({"workload": w, "dtype": dt, "locations": locs, "deterministic": det,
+                                                "error": "%s: %s" % (type(exc).__name__, exc)})
                 torch.cuda.empty_cache()
             result["modules"] = []
             for w, amp in (("cfg2_decoder", False), ("cfg4_encoder", False), ("cfg2_decoder", True), ("cfg4_encoder", True)):

@@ -149,11 +149,25 @@ int msda_backward_passes(int Lq, int P);
  * grad_sampling_loc / grad_attn_weight workgroups see one head each and leave the reference-point gradient per head in
  * the scratch; without scratch the call runs the kernels that need none). */
 #define MSDA_FLAG_PROLOGUE 2u
-/* the workspace of this backward call STARTS WITH the point table a msda_forward_ws_* / msda_forward_prologue_ws_* call of
- * the same geometry filled from the same sampling locations / attention weights (below).  Ignored where the backward's plan
- * reads no table (msda_forward_workspace_bytes() == 0 for the geometry, the deterministic flag) or the buffer is too small. */
+/* the workspace of this backward call STARTS WITH the table a msda_forward_ws_* / msda_forward_prologue_ws_* call of the same
+ * geometry filled from the same sampling locations / attention weights (below); any scratch the call uses follows it, at the
+ * table's size rounded up to 256 bytes (msda_backward_workspace_bytes with this flag = both).  The table is ignored where the
+ * backward's plan reads none (msda_forward_workspace_bytes() == 0, the deterministic flag), where the buffer is too small,
+ * or where its stamp says that the forward did not write it. */
 #define MSDA_FLAG_FORWARD_TABLE 4u
+/* grad_value of EVERY level through the sort + gather kernels, none as a dense product on the matrix cores (large problems,
+ * levels of at most 64 pixels: uvhand_amd/csrc/msda_d32_dense.h).  The results agree to fp32 summation order either way while
+ * grad_out is finite.  A non-finite grad_out row differs: in the dense product a zero weight still multiplies every query's
+ * row (0 x Inf = NaN), so ALL pixels of that (batch, head)'s dense levels become NaN, where the reference's atomicAdd
+ * (ms_deform_im2col_cuda.cuh:125-152) — and this flag — poison only the pixels that query's taps land on.  Costs the dense
+ * levels' speed-up (cfg-4 encoder backward +8 %); GradScaler-style loops that discard a non-finite step do not need it. */
+#define MSDA_FLAG_EXACT_NONFINITE 8u
 unsigned long long msda_backward_workspace_bytes(int N, int S, int M, int D, int L, int Lq, int P, unsigned flags);
+/* 1 if a backward of this geometry honours MSDA_FLAG_DETERMINISTIC, 0 if it would be refused (MSDA_ERR_ARGUMENT): outside
+ * the D = 32 family (elem_bytes 8 = fp64, any D != 32, ...) the deterministic kernel is a brute-force test of every sampling
+ * point against every pixel row, bounded at N*S*M x Lq*P <= 2^36.  Hosts that run under
+ * torch.use_deterministic_algorithms(True, warn_only=True) ask first, warn, and clear the flag.  Pure host logic. */
+int msda_deterministic_supported(int elem_bytes, int N, int S, int M, int D, int L, int Lq, int P);
 int msda_backward_ws_f32(const float *grad_out, const float *value, const int64_t *spatial_shapes,
                          const int64_t *level_start, const float *sampling_loc, const float *attn_weight,
                          int N, int S, int M, int D, int L, int Lq, int P,
@@ -175,19 +189,26 @@ int msda_backward_ws_bf16_gv32(const uint16_t *grad_out, const uint16_t *value, 
                                float *grad_value, float *grad_sampling_loc, float *grad_attn_weight,
                                void *workspace, unsigned long long workspace_bytes, unsigned flags, msda_stream_t stream);
 
-/* ---- Forward that leaves the backward its point table (small problems, D = 32 family) -------------------------
+/* ---- Forward that prepares its backward (D = 32 family) -----------------------------------------------------
  * The reference's backward re-derives every sampling point's geometry from sampling_loc / attn_weight
  * (ms_deform_im2col_cuda.cuh:340-371, inside every one of its 32 channel threads).  Here the FORWARD already computes it once
- * per point; msda_forward_ws_* additionally writes it to `workspace` as a level-major table — 16 bytes per sampling point,
- * entry ((b*M + m)*L + l) * Lq*P + q*P + p = {tap validity bits << 24 | pixel index of the top-left tap + W + 1, the two bilinear
- * fractions, the attention weight} — which the backward of the same autograd node reads, coalesced, in place of its strided scan of
- * sampling_loc / attn_weight (pass the same buffer as `workspace` with MSDA_FLAG_FORWARD_TABLE to msda_backward_ws_*; for the
- * fused-prologue pair: msda_forward_prologue_ws_* and msda_backward_prologue_ws_f32 / _bf16_gv32).  Results are bit-identical
- * with and without the table.  msda_forward_workspace_bytes(): the table's size for a geometry, 0 where the backward's plan
- * reads none (only small problems do: every workgroup of the backward launch resident at once — the 300-query decoder shape;
- * large problems keep their scans, a table would be tens of MB of extra traffic there); flags: MSDA_FLAG_PROLOGUE for the
- * fused-prologue pair.  workspace NULL / too small / unaligned (16 bytes): exactly msda_forward_*.  The caller owns the buffer
- * and keeps it, unmodified, with the tensors it saves for the backward. */
+ * per point; msda_forward_ws_* additionally leaves in `workspace` what the backward of the same autograd node would otherwise
+ * work out again (pass the same buffer as `workspace` with MSDA_FLAG_FORWARD_TABLE to msda_backward_ws_*; for the
+ * fused-prologue pair: msda_forward_prologue_ws_* and msda_backward_prologue_ws_f32 / _bf16_gv32):
+ *   small problems (every workgroup of the backward launch resident at once — the 300-query decoder shape): a level-major
+ *     POINT TABLE, 16 bytes per sampling point, entry ((b*M + m)*L + l) * Lq*P + q*P + p = {tap validity bits << 24 | pixel
+ *     index of the top-left tap + W + 1, the two bilinear fractions, the attention weight}, and behind it a header with the
+ *     pixel range of every grad_value workgroup;
+ *   large problems whose grad_value pass cuts the levels into W <= 8 pixel ranges (the encoder shapes): RANGE MASKS, one
+ *     byte per sampling point, level-major — bit t set iff a tap of the point may land in range t — which turn every range's
+ *     strided scan of sampling_loc into a coalesced byte scan.
+ * grad_sampling_loc and grad_attn_weight are bit-identical with and without the buffer; grad_value is equal up to the order
+ * in which a pixel's contributions are summed (as between any two runs of the default kernels).  Each buffer carries a stamp
+ * that the forward writes and the backward checks: a forward call that cannot fill the buffer (rows that are not 16-byte
+ * aligned take the generic kernels) clears it, and the backward then ignores the buffer.
+ * msda_forward_workspace_bytes(): the buffer's size for a geometry, 0 where the backward's plan reads none; flags:
+ * MSDA_FLAG_PROLOGUE for the fused-prologue pair.  workspace NULL / too small / unaligned (16 bytes): exactly msda_forward_*.
+ * The caller owns the buffer and keeps it, unmodified, with the tensors it saves for the backward. */
 unsigned long long msda_forward_workspace_bytes(int N, int S, int M, int D, int L, int Lq, int P, unsigned flags);
 int msda_forward_ws_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
                         const float *sampling_loc, const float *attn_weight,

@@ -251,6 +251,63 @@ def test_argument_errors_are_reported_before_anything_is_launched(native):
     assert lib.msda_unflatten_workspace_bytes(4, hs4, ws4, 32, 256) == 32 * (13 + 4 + 1 + 1) * 4 * 64 * 4
 
 
+def test_deterministic_work_bound_is_host_logic(native):
+    """outside the D = 32 family MSDA_FLAG_DETERMINISTIC is a brute force bounded at N*S*M x Lq*P <= 2^36 point
+    tests; msda_deterministic_supported says on which side a geometry falls (hosts under warn_only=True ask, warn, and run the
+    default kernels instead of raising)."""
+    lib = native._lib
+    I = ctypes.c_int
+    lib.msda_deterministic_supported.restype = I
+    lib.msda_deterministic_supported.argtypes = [I] * 8
+    assert lib.msda_deterministic_supported(4, 2, 3060, 8, 32, 4, 3060, 4) == 1           # D = 32 family: always
+    assert lib.msda_deterministic_supported(4, 32, 1045, 8, 32, 4, 1045, 4) == 1
+    # fp64 (generic family): 4 * 65536 * 8 rows x 32768 * 1 points = 2^36 exactly -> allowed; one more query -> refused
+    assert lib.msda_deterministic_supported(8, 4, 65536, 8, 32, 1, 32768, 1) == 1
+    assert lib.msda_deterministic_supported(8, 4, 65536, 8, 32, 1, 32769, 1) == 0
+    assert lib.msda_deterministic_supported(4, 4, 65536, 8, 30, 1, 32769, 1) == 0           # D = 30: generic as well
+    assert lib.msda_deterministic_supported(4, 4, 65536, 8, 32, 1, 32769, 1) == 1           # the same sizes at D = 32
+    assert lib.msda_deterministic_supported(8, 1, 30, 2, 4, 2, 2, 2) == 1                 # test.py's gradcheck shape
+    assert lib.msda_deterministic_supported(8, 0, 30, 2, 4, 2, 2, 2) == 1                 # empty: nothing to order
+
+
+def test_warn_only_clears_the_flag_for_geometries_without_a_deterministic_kernel(native):
+    import warnings
+    big = (8, 4, 65536, 8, 32, 1, 32769, 1)
+    assert native._deterministic_for(native._lib, True, *big) is True                     # not warn_only: the library refuses later
+    prev = torch.are_deterministic_algorithms_enabled(), torch.is_deterministic_algorithms_warn_only_enabled()
+    torch.use_deterministic_algorithms(True, warn_only=True)
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            assert native._deterministic_for(native._lib, True, *big) is False
+            assert native._deterministic_for(native._lib, True, 8, 4, 65536, 8, 32, 1, 32768, 1) is True
+            assert native._deterministic_for(native._lib, False, *big) is False
+        assert len(w) == 1 and "warn_only" in str(w[0].message)
+    finally:
+        torch.use_deterministic_algorithms(prev[0], warn_only=prev[1])
+
+
+def test_a_backward_workspace_with_the_forward_table_is_table_then_scratch(native):
+    """MSDA_FLAG_FORWARD_TABLE: the forward's buffer first (rounded up to 256 bytes), the call's own scratch behind it."""
+    lib = native._lib
+    I = ctypes.c_int
+    lib.msda_backward_workspace_bytes.restype = ctypes.c_ulonglong
+    lib.msda_backward_workspace_bytes.argtypes = [I] * 7 + [ctypes.c_uint]
+    lib.msda_forward_workspace_bytes.restype = ctypes.c_ulonglong
+    lib.msda_forward_workspace_bytes.argtypes = [I] * 7 + [ctypes.c_uint]
+    enc = (2, 3060, 8, 32, 4, 3060, 4)                                                    # cfg-2 encoder: range masks + per-head scratch
+    masks = lib.msda_forward_workspace_bytes(*enc, 2)
+    heads = lib.msda_backward_workspace_bytes(*enc, 2)
+    assert masks == 64 + 2 * 8 * 4 * 3060 * 4 and heads == 2 * 3060 * 8 * 4 * 8
+    assert lib.msda_backward_workspace_bytes(*enc, 2 | 4) == ((masks + 255) & ~255) + heads
+    assert lib.msda_backward_workspace_bytes(*enc, 4) == lib.msda_forward_workspace_bytes(*enc, 0) == masks   # no scratch: the table alone
+    dec = (2, 3060, 8, 32, 4, 300, 4)                                                     # cfg-2 decoder: point table, no scratch
+    table = lib.msda_forward_workspace_bytes(*dec, 2)
+    assert table > 2 * 8 * 4 * 300 * 4 * 16 and lib.msda_backward_workspace_bytes(*dec, 2 | 4) == table
+    assert lib.msda_forward_workspace_bytes(32, 1045, 8, 32, 4, 300, 4, 0) == 0           # cfg-4 decoder: one range per level, no masks
+    assert lib.msda_backward_workspace_bytes(32, 1045, 8, 32, 4, 300, 4, 4) == 0
+
+
 def test_int32_row_offsets_bound_the_d32_family():
     """Role B's gathers read a (batch, head) pair's grad_out rows through a buffer descriptor with 32-bit BYTE offsets
     q * M * 128: the tiled family only takes geometries with Lq * M * 128 B < 2^31 (others go to the generic kernels, whose

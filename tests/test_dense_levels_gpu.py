@@ -114,3 +114,61 @@ def test_dense_levels_bf16_rows(native, oracle, name):
     out.backward(dev(z["grad_out"], torch.bfloat16))
     torch.cuda.synchronize()
     assert rel_err(v.grad.float().cpu().numpy(), r_gv) < 1e-2
+
+
+def _rows_hit_by(z, b, q, m):
+    """Pixel rows (indices into S) of batch element b that a VALID tap of query q, head m lands on — the rows the reference's
+    atomicAdd touches for that query (ms_deform_im2col_cuda.cuh:56-78 guards, :125-152 adds)."""
+    rows = set()
+    for l, (H, Wd) in enumerate(z["shapes"]):
+        H, Wd = int(H), int(Wd)
+        for p in range(z["loc"].shape[4]):
+            x, y = np.float32(z["loc"][b, q, m, l, p, 0]), np.float32(z["loc"][b, q, m, l, p, 1])
+            h_im, w_im = y * np.float32(H) - np.float32(0.5), x * np.float32(Wd) - np.float32(0.5)
+            if not (h_im > -1 and w_im > -1 and h_im < H and w_im < Wd):
+                continue
+            h0, w0 = int(np.floor(h_im)), int(np.floor(w_im))
+            for hh, ww in ((h0, w0), (h0, w0 + 1), (h0 + 1, w0), (h0 + 1, w0 + 1)):
+                if 0 <= hh < H and 0 <= ww < Wd:
+                    rows.add(int(z["level_start"][l]) + hh * Wd + ww)
+    return rows
+
+
+@pytest.mark.parametrize("name", ["w2_64_32_16", "w1_49_32_16"])
+def test_which_rows_a_non_finite_grad_out_row_poisons(native, name):
+    """one Inf in grad_out[b, q, m-th head's channels].  Reference semantics (atomicAdd of weight * grad_out
+    per tap, ms_deform_im2col_cuda.cuh:125-152): exactly the rows that query's taps land on become non-finite.
+    * MSDA_FLAG_EXACT_NONFINITE (uvhand_amd.set_exact_nonfinite): exactly those rows, on every level;
+    * default: the same on the sort + gather levels; on a DENSE level (matrix-core product: a zero weight still multiplies the
+      row) every row of that level of (b, m) — a superset, confined to that (batch, head, level);
+    nothing outside (b, m) is touched either way, and grad_sampling_loc / grad_attn_weight are non-finite for that one item only."""
+    case, _ = DENSE[name]
+    N, shapes, M, D, Lq, P = case
+    S = sum(h * w for h, w in shapes)
+    z = make_case(35, *case)
+    b, q, m = 1, 7, 3
+    z["grad_out"].reshape(N, Lq, M, D)[b, q, m, 5] = np.inf
+    v, go = dev(z["value"]), dev(z["grad_out"])
+    s, i, l, a = dev(z["shapes"]), dev(z["level_start"]), dev(z["loc"]), dev(z["attn"])
+    want = _rows_hit_by(z, b, q, m)
+    assert want, "the chosen query has no valid tap"
+    limit = 64 if "w2" in name else 32
+    dense_rows = set()
+    for lv, (H, Wd) in enumerate(shapes):
+        if H * Wd <= limit and any(int(z["level_start"][lv]) <= r < int(z["level_start"][lv]) + H * Wd for r in want):
+            dense_rows |= set(range(int(z["level_start"][lv]), int(z["level_start"][lv]) + H * Wd))
+    assert dense_rows, "no dense level is hit"
+    assert "dense_px=0" in native.describe_plan(N, S, M, D, len(shapes), Lq, P, exact_nonfinite=True)
+    for exact in (False, True):
+        native.set_exact_nonfinite(exact)
+        try:
+            gv, gl, ga = native.ms_deform_attn_backward(v, s, i, l, a, go, 64)
+        finally:
+            native.set_exact_nonfinite(False)
+        bad = ~torch.isfinite(gv).all(-1)                                   # [N, S, M]
+        got = set(torch.nonzero(bad[b, :, m]).flatten().tolist())
+        assert got == (want if exact else want | dense_rows), (exact, sorted(got ^ want)[:10])
+        bad[b, :, m] = False
+        assert not bad.any(), "rows outside the (batch, head) pair touched"
+        bad_items = ~(torch.isfinite(gl).all(-1).all(-1).all(-1) & torch.isfinite(ga).all(-1).all(-1))      # [N, Lq, M]
+        assert set(map(tuple, torch.nonzero(bad_items).tolist())) == {(b, q, m)}

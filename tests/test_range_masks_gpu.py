@@ -1,13 +1,13 @@
-"""Per-range point lists: on large problems the LDS-stage FORWARD leaves, for every (batch, head, level,
-pixel range) of the backward's role-B plan, the indices of the sampling points whose taps may land in that range
-(msda_forward_ws_* / msda_forward_prologue_ws_*, ListHeader in uvhand_amd/csrc/msda_d32.hip); role B of the same node's
-backward reads its range's list instead of scanning all Lq*P points of the level once per range
+"""Per-point range masks: on large problems the LDS-stage FORWARD leaves one byte per sampling point —
+bit t set iff a tap of the point may land in pixel range t of its level, the ranges being those of the backward's role-B plan
+(msda_forward_ws_* / msda_forward_prologue_ws_*, MaskHeader in uvhand_amd/csrc/msda_d32.hip); role B of the same node's
+backward finds its candidates with a coalesced byte scan instead of a strided float scan of sampling_loc once per range
 (replaces the per-thread re-derivation of ms_deform_im2col_cuda.cuh:340-371).
 
-Checked here: the lists are a duplicate-free SUPERSET of the exact answer (numpy restatement of the reference's tap rule,
-ms_deform_im2col_cuda.cuh:285-288, :56-78), the backward from the lists equals the backward from a scan (grad_sampling_loc /
+Checked here: the masks are a tight SUPERSET of the exact answer (numpy restatement of the reference's tap rule,
+ms_deform_im2col_cuda.cuh:285-288, :56-78), the backward from the masks equals the backward from a scan (grad_sampling_loc /
 grad_attn_weight bit for bit, grad_value up to the order of a row's sum) and the C oracle at the bench's own sizes, a cleared
-stamp or a foreign buffer falls back to the scan, and piled-up locations (more listed points than the LDS list holds) take
+stamp or a foreign buffer falls back to the scan, and piled-up locations (more candidates than the LDS list holds) take
 the chunked passes."""
 import numpy as np
 import pytest
@@ -21,7 +21,7 @@ C2 = [(48, 48), (24, 24), (12, 12), (6, 6)]
 C4 = [(28, 28), (14, 14), (7, 7), (4, 4)]
 BIG = {"cfg2_encoder": (2, 3060, C2), "cfg4_decoder": (32, 300, C4), "cfg4_encoder": (32, 1045, C4)}
 M, P, D = 8, 4, 32
-MAGIC = 0x4d53444c
+MAGIC = 0x4d53444d
 
 
 @pytest.fixture(scope="module")
@@ -53,15 +53,11 @@ def _case(name, seed=0, spread=1.3, shift=-0.15):
 
 
 def _decode(table):
-    """(header dict, counts[pairs*L*W, chunks], lists[pairs*L*W, chunks, cap]) of a list buffer (uint8 tensor)."""
+    """(header dict, masks[pairs, L, NP]) of a mask buffer (uint8 tensor)."""
     raw = table.cpu().numpy()
-    hdr = raw[:64].view(np.int32)
-    h = dict(zip(("magic", "W", "L", "chunks", "cap", "NP", "pairs", "qw"), hdr[:8].tolist()))
-    n_sub = h["pairs"] * h["L"] * h["W"] * h["chunks"]
-    counts_bytes = (n_sub * 2 + 63) & ~63
-    counts = raw[64:64 + n_sub * 2].view(np.uint16).reshape(-1, h["chunks"])
-    lists = raw[64 + counts_bytes:64 + counts_bytes + n_sub * h["cap"] * 2].view(np.uint16).reshape(-1, h["chunks"], h["cap"])
-    return h, counts, lists
+    h = dict(zip(("magic", "W", "L", "NP", "pairs"), raw[:64].view(np.int32)[:5].tolist()))
+    n = h["pairs"] * h["L"] * h["NP"]
+    return h, raw[64:64 + n].reshape(h["pairs"], h["L"], h["NP"])
 
 
 def _exact_ranges(loc, shapes, W):
@@ -87,52 +83,41 @@ def _exact_ranges(loc, shapes, W):
 
 
 @pytest.mark.parametrize("name", list(BIG))
-def test_plans_that_read_lists(native, name):
-    """Lists exist exactly where role B is the kept-taps pass (more points per level than one pass sorts): the two encoder
+def test_plans_that_read_masks(native, name):
+    """Masks exist exactly where role B is the kept-taps pass (more points per level than one pass sorts): the two encoder
     shapes; cfg-4 decoder (1200 points per level and pair, one range per level) scans once anyway and gets none."""
     N, Lq, shapes = BIG[name]
     S = sum(h * w for h, w in shapes)
     plan = native.describe_plan(N, S, M, D, len(shapes), Lq, P)
     nbytes = int(native._lib.msda_forward_workspace_bytes(N, S, M, D, len(shapes), Lq, P, 0))
-    assert ("lists" in plan) == (name != "cfg4_decoder"), plan
-    assert (nbytes > 0) == ("lists" in plan)
-    assert "lists" not in native.describe_plan(N, S, M, D, len(shapes), Lq, P, deterministic=True)
+    assert ("masks" in plan) == (name != "cfg4_decoder"), plan
+    assert nbytes == (64 + N * M * len(shapes) * Lq * P if "masks" in plan else 0)
+    assert "masks" not in native.describe_plan(N, S, M, D, len(shapes), Lq, P, deterministic=True)
 
 
 @pytest.mark.parametrize("name", ["cfg2_encoder", "cfg4_encoder"])
-def test_lists_are_a_duplicate_free_superset_of_the_exact_answer(native, name):
+def test_masks_are_a_tight_superset_of_the_exact_answer(native, name):
     sh, lsi, value, loc, attn, go = _case(name)
     N, Lq, shapes = BIG[name]
     out, table = native.ms_deform_attn_forward(value.cuda(), sh.cuda(), lsi.cuda(), loc.cuda(), attn.cuda(), 64, with_table=True)
     assert table is not None
-    h, counts, lists = _decode(table)
-    assert h["magic"] == MAGIC and h["L"] == 4 and h["NP"] == Lq * P and h["pairs"] == N * M and h["cap"] >= h["qw"] * P
-    W, L, chunks = h["W"], h["L"], h["chunks"]
-    assert (counts <= h["qw"] * P).all()
+    h, masks = _decode(table)
+    assert h["magic"] == MAGIC and h["L"] == 4 and h["NP"] == Lq * P and h["pairs"] == N * M and 1 <= h["W"] <= 8
+    W = h["W"]
     exact = _exact_ranges(loc.numpy(), shapes, W)                            # [N, Lq, M, L, P, W]
-    listed_total, exact_total = 0, 0
-    for b in range(N):
-        for m in range(M):
-            for l in range(L):
-                for t in range(W):
-                    bucket = ((b * M + m) * L + l) * W + t
-                    got = np.concatenate([lists[bucket, c, :counts[bucket, c]] for c in range(chunks)]).astype(np.int64)
-                    assert len(np.unique(got)) == len(got), "a point listed twice"
-                    assert (got < Lq * P).all()
-                    # chunk c holds queries [c*qw, (c+1)*qw) only
-                    for c in range(chunks):
-                        q = lists[bucket, c, :counts[bucket, c]].astype(np.int64) // P
-                        assert ((q >= c * h["qw"]) & (q < (c + 1) * h["qw"])).all()
-                    want = np.nonzero(exact[b, :, m, l, :, t].reshape(-1))[0]      # index q*P + p
-                    assert np.isin(want, got).all(), "a point with a tap in the range is missing from its list"
-                    listed_total += len(got)
-                    exact_total += len(want)
-    assert listed_total <= 1.25 * exact_total + 64, (listed_total, exact_total)    # a superset, but a tight one
+    got = ((masks[..., None] >> np.arange(W)) & 1).astype(bool)              # [pairs, L, NP, W]
+    got = got.reshape(N, M, 4, Lq, P, W).transpose(0, 3, 1, 2, 4, 5)         # -> [N, Lq, M, L, P, W]
+    assert (masks >> W == 0).all(), "bits beyond the plan's ranges"
+    assert not (exact & ~got).any(), "a point with a tap in a range whose bit is clear"
+    assert got.sum() <= 1.25 * exact.sum() + 64, (int(got.sum()), int(exact.sum()))       # a superset, but a tight one
+    outside = ~exact.any(-1)                                                  # points with no valid tap at all ...
+    far = outside & ((loc.numpy() < -0.1) | (loc.numpy() > 1.1)).any(-1)       # ... that lie well outside the map
+    assert not got[far].any()
 
 
 @pytest.mark.parametrize("rows", ["f32", "bf16"])
 @pytest.mark.parametrize("name", list(BIG))
-def test_backward_from_the_lists_equals_backward_from_a_scan(native, oracle, name, rows):
+def test_backward_from_the_masks_equals_backward_from_a_scan(native, oracle, name, rows):
     sh, lsi, value, loc, attn, go = _case(name, seed=1)
     bf16 = rows == "bf16"
     dt = torch.bfloat16 if bf16 else torch.float32
@@ -154,52 +139,52 @@ def test_backward_from_the_lists_equals_backward_from_a_scan(native, oracle, nam
     r_gv, r_gl, r_ga = oracle.backward(go.numpy(), value.numpy(), sh.numpy(), lsi.numpy(), loc.numpy(), attn.numpy())
     assert rel_err(got[0].cpu().numpy(), r_gv) < 2e-5
     assert rel_err(got[2].cpu().numpy(), r_ga) < 2e-5
-    # the deterministic flag never reads lists: bit-equal to its own result without the buffer
+    # the deterministic flag never reads masks: bit-equal to its own result without the buffer
     det_a = native.ms_deform_attn_backward(v, s, i, l, a, g, 64, table=table, deterministic=True, **kw)
     det_b = native.ms_deform_attn_backward(v, s, i, l, a, g, 64, deterministic=True, **kw)
     assert all(torch.equal(x, y) for x, y in zip(det_a, det_b))
 
 
 def test_a_cleared_stamp_or_a_foreign_buffer_means_a_scan(native):
-    """Role B trusts the lists only behind the header the forward of the same plan wrote: with the stamp cleared (what a
-    forward that could not write them does) or another plan's numbers in it, the result is the scan's; entries that are
-    garbage behind a valid header still never index outside sampling_loc."""
+    """Role B trusts the masks only behind the header the forward of the same plan wrote: with the stamp cleared (what a
+    forward that could not write them does) or another plan's numbers in it, the result is the scan's; masks that are
+    garbage behind a valid header give wrong candidates at worst (all bits set = every point a candidate: still exact)."""
     sh, lsi, value, loc, attn, go = _case("cfg2_encoder", seed=2)
     v, g, s, i, l, a = value.cuda(), go.cuda(), sh.cuda(), lsi.cuda(), loc.cuda(), attn.cuda()
     _, table = native.ms_deform_attn_forward(v, s, i, l, a, 64, with_table=True)
     base = native.ms_deform_attn_backward(v, s, i, l, a, g, 64)
-    for word, val in ((0, 0), (1, 5), (3, 31), (4, 8), (5, 7)):              # magic, W, chunks, cap, NP
+    for word, val in ((0, 0), (1, 5), (2, 3), (3, 7), (4, 1)):               # magic, W, L, NP, pairs
         t2 = table.clone()
         t2[:64].view(torch.int32)[word] = val
         got = native.ms_deform_attn_backward(v, s, i, l, a, g, 64, table=t2)
         assert torch.equal(got[1], base[1]) and torch.equal(got[2], base[2])
         assert rel_err(got[0].cpu().numpy(), base[0].cpu().numpy()) < 2e-6
     t3 = table.clone()
-    t3[64:] = 0xff                                                            # counts and entries all 0xffff
-    got = native.ms_deform_attn_backward(v, s, i, l, a, g, 64, table=t3)     # wrong numbers, but no fault
-    torch.cuda.synchronize()
-    assert torch.isfinite(got[0]).all()
+    t3[64:] = 0xff                                                            # every point a candidate of every range
+    got = native.ms_deform_attn_backward(v, s, i, l, a, g, 64, table=t3)
+    assert torch.equal(got[1], base[1]) and torch.equal(got[2], base[2])
+    assert rel_err(got[0].cpu().numpy(), base[0].cpu().numpy()) < 2e-6
 
 
 def test_piled_up_locations_overflow_the_list_and_take_the_chunked_passes(native, oracle):
-    """Every point within a few pixels: one range's list holds (almost) all Lq*P points of the level — more records than its
-    workgroup's LDS holds — so that workgroup starts over in query chunks (which scan), the other ranges' lists are empty."""
+    """Every point within a few pixels: one range's workgroup finds (almost) all Lq*P points of the level to be candidates —
+    more records than its LDS holds — and starts over in query chunks (which scan); the other ranges find none."""
     sh, lsi, value, loc, attn, go = _case("cfg2_encoder", seed=3)
     loc[..., 0] = 0.40 + 0.05 * loc[..., 0].clamp(0, 1)
     loc[..., 1] = 0.55 + 0.05 * loc[..., 1].clamp(0, 1)
     v, g, s, i, l, a = value.cuda(), go.cuda(), sh.cuda(), lsi.cuda(), loc.cuda(), attn.cuda()
     _, table = native.ms_deform_attn_forward(v, s, i, l, a, 64, with_table=True)
-    h, counts, _ = _decode(table)
-    per_bucket = counts.astype(np.int64).sum(1)
-    assert per_bucket.max() >= 3060 * 4 * 0.9                                 # a list with nearly every point of the level
+    h, masks = _decode(table)
+    per_range = ((masks[..., None] >> np.arange(h["W"])) & 1).sum(2)          # [pairs, L, W]
+    assert per_range.max() >= 3060 * 4 * 0.9                                 # a range with nearly every point of the level
     got = native.ms_deform_attn_backward(v, s, i, l, a, g, 64, table=table)
     r_gv, r_gl, r_ga = oracle.backward(go.numpy(), value.numpy(), sh.numpy(), lsi.numpy(), loc.numpy(), attn.numpy())
     assert rel_err(got[0].cpu().numpy(), r_gv) < 2e-5
     assert rel_err(got[2].cpu().numpy(), r_ga) < 2e-5
 
 
-def test_the_fused_prologue_pair_passes_lists_and_scratch_in_one_buffer(native):
-    """msda_forward_prologue_ws_* + msda_backward_prologue_ws_f32 on a large problem: the buffer carries the lists first and
+def test_the_fused_prologue_pair_passes_masks_and_scratch_in_one_buffer(native):
+    """msda_forward_prologue_ws_* + msda_backward_prologue_ws_f32 on a large problem: the buffer carries the masks first and
     the per-head reference-point scratch behind them (msda_backward_workspace_bytes with MSDA_FLAG_FORWARD_TABLE)."""
     name = "cfg2_encoder"
     N, Lq, shapes = BIG[name]

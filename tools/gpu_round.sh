@@ -17,8 +17,9 @@ print("headline %.0f samples/s  %.4f ms/step  fwd %.2f us  bwd %.2f us  frac %.3
     1e3 * r.get("eager_ms_per_step", 0), r.get("cpu_baseline", {}).get("value")))
 for w in r.get("workloads", []):
     if "error" in w: print(w); continue
-    print("%-13s %-4s step %8.2f us  fwd %7.2f (%.3f)  bwd %7.2f (%.3f)  %9.0f samples/s" % (
-        w["workload"], w["dtype"], w["step_us"], w["fwd_us"], w["fwd_frac"], w["bwd_us"], w["bwd_frac"], w["samples_per_s"]))
+    print("%-13s %-4s %-7s %-3s step %8.2f us  fwd %7.2f (%.3f)  bwd %7.2f (%.3f)  %9.0f samples/s" % (
+        w["workload"], w["dtype"], w.get("locations", "uniform"), "det" if w.get("deterministic") else "", w["step_us"], w["fwd_us"],
+        w["fwd_frac"], w["bwd_us"], w["bwd_frac"], w["samples_per_s"]))
 for m in r.get("modules", []):
     print("module", m)
 PY

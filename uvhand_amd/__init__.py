@@ -9,8 +9,9 @@ Python host code on PyTorch-ROCm, hand-written HIP kernels (``csrc/``) behind th
 declared in ``include/msda.h``.  There is no CPU or pure-PyTorch implementation in this
 package: without the built HIP library every call raises.
 """
+from ._native import set_exact_nonfinite
 from .functions import MSDeformAttnFunction
 from .modules import MSDeformAttn
 
-__all__ = ["MSDeformAttn", "MSDeformAttnFunction"]
+__all__ = ["MSDeformAttn", "MSDeformAttnFunction", "set_exact_nonfinite"]
 __version__ = "0.1.0"

@@ -12,6 +12,7 @@ CPU-tensor error of models/ops/src/ms_deform_attn.h:38,60.
 """
 import ctypes
 import os
+import warnings
 
 import torch
 
@@ -23,7 +24,7 @@ _lib = None
 _SYMBOLS = (
     "msda_forward_f32", "msda_backward_f32", "msda_forward_f64", "msda_backward_f64",
     "msda_forward_bf16", "msda_backward_bf16", "msda_backward_bf16_gv32", "msda_backward_passes",
-    "msda_backward_workspace_bytes", "msda_backward_ws_f32", "msda_backward_ws_f64", "msda_backward_ws_bf16",
+    "msda_backward_workspace_bytes", "msda_deterministic_supported", "msda_backward_ws_f32", "msda_backward_ws_f64", "msda_backward_ws_bf16",
     "msda_backward_ws_bf16_gv32",
     "msda_backward_prologue_ws_f32", "msda_forward_prologue_bf16", "msda_backward_prologue_bf16_gv32",
     "msda_add_layernorm_workspace_bytes", "msda_add_layernorm_forward_f32", "msda_add_layernorm_backward_f32",
@@ -177,12 +178,42 @@ _BWD_WS_ARGTYPES = [_VP] * 6 + [_CI] * 7 + [_VP] * 4 + [ctypes.c_ulonglong, ctyp
 FLAG_DETERMINISTIC = 1                                # MSDA_FLAG_DETERMINISTIC (include/msda.h)
 FLAG_PROLOGUE = 2                                     # MSDA_FLAG_PROLOGUE
 FLAG_FORWARD_TABLE = 4                                # MSDA_FLAG_FORWARD_TABLE
+FLAG_EXACT_NONFINITE = 8                              # MSDA_FLAG_EXACT_NONFINITE
+
+_extra_flags = 0
+
+
+def set_exact_nonfinite(on=True):
+    """Process-wide: every backward of the D = 32 family keeps the coarse levels on the sort + gather kernels instead of the
+    dense matrix-core product (MSDA_FLAG_EXACT_NONFINITE, include/msda.h), so that a non-finite grad_output row makes exactly
+    the grad_value rows non-finite that the reference's atomicAdd would (ms_deform_im2col_cuda.cuh:125-152) — the dense product
+    spreads it over the whole level of that (batch, head).  Costs the dense levels' speed-up on large problems."""
+    global _extra_flags
+    _extra_flags = FLAG_EXACT_NONFINITE if on else 0
+    from . import _ext
+    ext = _ext.get()
+    if ext is not None and hasattr(ext, "set_exact_nonfinite"):
+        ext.set_exact_nonfinite(bool(on))
 
 
 def deterministic_requested():
     """True when grad_value should be bitwise reproducible: torch.use_deterministic_algorithms(True) (the reference
     sets cudnn.deterministic, main.py:65-66, which does not cover its atomicAdd scatter) or MSDA_DETERMINISTIC=1."""
     return torch.are_deterministic_algorithms_enabled() or os.environ.get("MSDA_DETERMINISTIC", "0") not in ("", "0")
+
+def _deterministic_for(lib, det, elem_bytes, N, S, M, D, L, Lq, P):
+    """The deterministic flag of a backward call: `det`, unless the geometry has no deterministic kernel within the library's
+    work bound (msda_deterministic_supported: outside the D = 32 family above 2^36 point tests) AND torch runs with
+    use_deterministic_algorithms(True, warn_only=True) — then a warning and the default kernels, as torch does for its own
+    ops without a deterministic form.  Without warn_only the library's refusal is raised."""
+    if det and torch.is_deterministic_algorithms_warn_only_enabled():
+        lib.msda_deterministic_supported.argtypes = [ctypes.c_int] * 8
+        if not lib.msda_deterministic_supported(elem_bytes, N, S, M, D, L, Lq, P):
+            warnings.warn("ms_deform_attn_backward: no deterministic grad_value kernel for this geometry within the work bound "
+                          "(include/msda.h, MSDA_FLAG_DETERMINISTIC); running the default (atomic) kernel [warn_only]")
+            return False
+    return det
+
 
 _entry_cache = {}
 
@@ -309,9 +340,10 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
         grad_loc = torch.empty_like(sampling_loc)
         grad_attn = torch.empty_like(attn_weight)
         det = deterministic_requested() if deterministic is None else bool(deterministic)
+        det = _deterministic_for(lib, det, 8 if suf == "f64" else 4, N, S, M, D, L, Lq, P)
         # always through the entry with flags and scratch (msda_backward_workspace_bytes says how much a call can use: 0 for
         # most shapes); the deterministic flag reaches every kernel family and dtype
-        flags = FLAG_DETERMINISTIC if det else 0
+        flags = (FLAG_DETERMINISTIC if det else 0) | _extra_flags
         if table is not None:                                # the forward's table of this very call (with_table=True), scratch behind it
             ws, nbytes, flags = table, table.numel(), flags | FLAG_FORWARD_TABLE
         else:
@@ -557,7 +589,7 @@ def ms_deform_attn_backward_prologue(value, spatial_shapes, level_start_index, s
         gref = torch.empty((N, Lq, L, 2), dtype=torch.float32, device=value.device)
         det = deterministic_requested() if deterministic is None else bool(deterministic)
         # use_workspace=False (tests): the call a caller without scratch makes — the library then runs the kernels that need none
-        flags = FLAG_DETERMINISTIC if det else 0
+        flags = (FLAG_DETERMINISTIC if det else 0) | _extra_flags
         if table is not None:                                # the forward's table (with_table=True of the forward), scratch behind it
             ws, flags = table, flags | FLAG_FORWARD_TABLE
             nbytes = table.numel() if use_workspace else min(table.numel(), int(lib.msda_forward_workspace_bytes(N, S, M, D, L, Lq, P, FLAG_PROLOGUE)))
@@ -700,11 +732,12 @@ def path_for(elem_bytes, M, D, L, P):
 
 
 def describe_plan(N, S, M, D, L, Lq, P, row_bytes=4, grad_value_bytes=None, prologue=False, deterministic=False,
-                  has_workspace=True):
+                  has_workspace=True, exact_nonfinite=False):
     """msda_describe_plan (include/msda.h): which kernels / launch plan a call of this geometry takes, as text."""
     lib = _lib or load()
     buf = ctypes.create_string_buffer(512)
-    flags = (FLAG_PROLOGUE if prologue else 0) | (FLAG_DETERMINISTIC if deterministic else 0)
+    flags = ((FLAG_PROLOGUE if prologue else 0) | (FLAG_DETERMINISTIC if deterministic else 0)
+             | (FLAG_EXACT_NONFINITE if exact_nonfinite else 0))
     with _ForcedPathScope(lib):
         lib.msda_describe_plan(row_bytes, grad_value_bytes or row_bytes, N, S, M, D, L, Lq, P, flags, 1 if has_workspace else 0,
                                buf, len(buf))

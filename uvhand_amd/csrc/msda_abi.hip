@@ -166,7 +166,8 @@ static int backward_impl(const T *grad_out, const T *value, const int64_t *shape
             return launch_bwd_d32(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P,
                                   grad_value, grad_loc, grad_attn, stream, sc.p, sc.bytes,
                                   (flags & MSDA_FLAG_DETERMINISTIC) != 0,
-                                  table_of(workspace, ws_bytes, flags, N, S, M, D, L, Lq, P, false));
+                                  table_of(workspace, ws_bytes, flags, N, S, M, D, L, Lq, P, false),
+                                  (flags & MSDA_FLAG_EXACT_NONFINITE) != 0);
         }
     }
     return launch_bwd_generic<T>(grad_out, value, shapes, level_start, loc, attn, N, S, M, D, L, Lq, P,
@@ -208,7 +209,8 @@ static int backward_bf16_impl(const uint16_t *grad_out, const uint16_t *value, c
         return msda::launch_bwd_d32_bf16(grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M,
                                          L, Lq, P, grad_value, grad_sampling_loc, grad_attn_weight, (hipStream_t)stream,
                                          sc.p, sc.bytes, (flags & MSDA_FLAG_DETERMINISTIC) != 0,
-                                         msda::table_of(workspace, ws_bytes, flags, N, S, M, D, L, Lq, P, false));
+                                         msda::table_of(workspace, ws_bytes, flags, N, S, M, D, L, Lq, P, false),
+                                  (flags & MSDA_FLAG_EXACT_NONFINITE) != 0);
     } else {
         if (!d32)                                                   // element-wise accesses: any D, any element offset
             return msda::launch_bwd_generic<float>(grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, N,
@@ -218,7 +220,8 @@ static int backward_bf16_impl(const uint16_t *grad_out, const uint16_t *value, c
         return msda::launch_bwd_d32_bf16_gv32(grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S,
                                               M, L, Lq, P, grad_value, grad_sampling_loc, grad_attn_weight,
                                               (hipStream_t)stream, sc.p, sc.bytes, (flags & MSDA_FLAG_DETERMINISTIC) != 0,
-                                              msda::table_of(workspace, ws_bytes, flags, N, S, M, D, L, Lq, P, false));
+                                              msda::table_of(workspace, ws_bytes, flags, N, S, M, D, L, Lq, P, false),
+                                  (flags & MSDA_FLAG_EXACT_NONFINITE) != 0);
     }
 }
 
@@ -359,6 +362,13 @@ unsigned long long msda_backward_workspace_bytes(int N, int S, int M, int D, int
     return (unsigned long long)(scratch ? msda::table_span(N, S, M, D, L, Lq, P, prologue) + scratch : table);
 }
 
+int msda_deterministic_supported(int elem_bytes, int N, int S, int M, int D, int L, int Lq, int P)
+{
+    if (N <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Lq <= 0 || P <= 0) return 1;              // (nothing to order)
+    if (elem_bytes != 8 && msda::g_force_path != MSDA_PATH_GENERIC && msda::d32_supported(N, S, M, D, L, Lq, P)) return 1;
+    return (double)N * (double)S * (double)M * (double)Lq * (double)P <= 68719476736.0 ? 1 : 0;      // msda_generic.hip: 2^36 point tests
+}
+
 int msda_backward_ws_f32(const float *grad_out, const float *value, const int64_t *spatial_shapes,
                          const int64_t *level_start, const float *sampling_loc, const float *attn_weight,
                          int N, int S, int M, int D, int L, int Lq, int P, float *grad_value,
@@ -476,7 +486,8 @@ int msda_backward_prologue_ws_f32(const float *grad_out, const float *value, con
                                      Lq, P, grad_value, ld_grad_offsets, ld_grad_logits, grad_sampling_offsets,
                                      grad_attn_logits, grad_reference_points, (hipStream_t)stream, sc.p,
                                      sc.bytes, (flags & MSDA_FLAG_DETERMINISTIC) != 0,
-                                     msda::table_of(workspace, (size_t)workspace_bytes, flags, N, S, M, D, L, Lq, P, true));
+                                     msda::table_of(workspace, (size_t)workspace_bytes, flags, N, S, M, D, L, Lq, P, true),
+                                  (flags & MSDA_FLAG_EXACT_NONFINITE) != 0);
 }
 
 int msda_forward_prologue_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start,
@@ -532,7 +543,8 @@ int msda_backward_prologue_bf16_gv32(const uint16_t *grad_out, const uint16_t *v
                                           Lq, P, grad_value, ld_grad_offsets, ld_grad_logits, grad_sampling_offsets,
                                           grad_attn_logits, grad_reference_points, (hipStream_t)stream, sc.p,
                                           sc.bytes, (flags & MSDA_FLAG_DETERMINISTIC) != 0,
-                                          msda::table_of(workspace, (size_t)workspace_bytes, flags, N, S, M, D, L, Lq, P, true));
+                                          msda::table_of(workspace, (size_t)workspace_bytes, flags, N, S, M, D, L, Lq, P, true),
+                                  (flags & MSDA_FLAG_EXACT_NONFINITE) != 0);
 }
 
 unsigned long long msda_linear_wgrad_workspace_bytes(int M, int N, int K)
@@ -780,7 +792,7 @@ int msda_describe_plan(int row_bytes, int grad_value_bytes, int N, int S, int M,
         return k < buf_len ? k : buf_len - 1;
     }
     const int k = msda::describe_plan(row_bytes, row_bytes == 4 ? 4 : grad_value_bytes, N, S, M, L, Lq, P, prologue, has_workspace != 0,
-                                      (flags & MSDA_FLAG_DETERMINISTIC) != 0, buf, buf_len);
+                                      (flags & MSDA_FLAG_DETERMINISTIC) != 0, buf, buf_len, (flags & MSDA_FLAG_EXACT_NONFINITE) != 0);
     return k < buf_len ? k : buf_len - 1;
 }
 

@@ -72,7 +72,7 @@ struct alignas(16) FwdRec { int off[4]; float w[4]; };
 // backward record: same offsets, the two fractions and the attention weight.
 struct alignas(16) BwdRec { int off[4]; float lh, lw, a, pad; };
 
-// One sampling point as the FORWARD can leave it for the backward of the same autograd node (msda_forward_ctx_*), level-major:
+// One sampling point as the FORWARD can leave it for the backward of the same autograd node (msda_forward_ws_*), level-major:
 // entry ((b*M + m)*L + l) * Lq*P + q*P + p.  Role B of a small problem reads its level's entries coalesced instead of
 // re-deriving them from a strided scan of sampling_loc / attn_weight (msda_d32_value.h: bwd_value_small_body).
 struct alignas(16) PointEntry { int cell; float lh, lw, a; };   // cell: tap validity bits << 24 | (h0 * W + w0 + W + 1); 0 = no tap
@@ -87,22 +87,23 @@ struct alignas(32) RangeHeader { int magic, W, L, tiled, tp_cap, pad[3]; };    /
 constexpr int kRangeMagic = 0x4d534441;
 __host__ __device__ inline size_t range_header_bytes() { return sizeof(RangeHeader) + (size_t)kMaxRangeEntries * sizeof(RangeEntry); }
 
-// ---- LARGE problems (LDS-stage forward, kept-taps role B): per-RANGE point lists ---------------------------------------------
+// ---- LARGE problems (LDS-stage forward, kept-taps role B): per-point RANGE MASKS ------------------------------------------------
 // Role B of a multi-pass problem cuts every level into W pixel ranges, and each range's workgroup used to re-scan ALL Lq*P
-// sampling points of its (batch, head, level) for the ~1/W that have a tap on its rows (cfg-2 encoder: 6 x 12 240 points per
-// level and pair, 12 us of a 53 us workgroup; profiles/r04_notes.md section 4).  The FORWARD of the same autograd node visits
-// every point anyway (fwd_d32_lds_kernel: one lane per point): with a list buffer it also appends the point's index q*P + p
-// (16 bits) to the list of every range its taps may touch — per forward workgroup (= chunk c of the pair's queries) one
-// fixed-capacity sub-list per (pair, level, range), filled through LDS counters, so no global atomics and no second pass.
-// Role B reads the `chunks` sub-lists of its own range (2 bytes per kept point, contiguous) in place of the scan.  The
-// lists are a SUPERSET (range of the first and of the last tap pixel, border validity ignored): role B works out the exact
-// taps of the listed points as it does for scanned ones, so results do not depend on where a list came from.
-//   layout: [ListHeader 64 B] [counts: u16 [pairs*L*W][chunks], padded to 64 B] [lists: u16 [pairs*L*W][chunks][cap]]
-struct alignas(64) ListHeader { int magic, W, L, chunks, cap, NP, pairs, qw, pad[8]; };
-constexpr int kListMagic = 0x4d53444c;
-constexpr int kMaxListRanges = 256;                                             // L * W (the forward keeps that many LDS counters)
-struct ListOut { ListHeader *hdr; uint16_t *counts; uint16_t *lists; int W, cap; };         // forward side (lists = null: none)
-struct ListIn { const ListHeader *hdr; const uint16_t *counts; const uint16_t *lists; int chunks, cap; };   // role B side
+// sampling points of its (batch, head, level) — a strided float2 read and a float range test per point — for the ~1/W that have
+// a tap on its rows (cfg-2 encoder: 6 x 12 240 points per level and pair, 12 us of a 53 us workgroup; profiles/r04_notes.md
+// section 4).  The FORWARD of the same autograd node visits every point anyway (fwd_d32_lds_kernel: one lane per point):
+// with a mask buffer it also stores ONE BYTE per point, level-major — bit t set iff one of the point's taps may land in range
+// t of its level — and role B's scan becomes a coalesced read of Lq*P bytes and a bit test.  The masks are a SUPERSET (all
+// ranges from the first tap pixel's to the last one's, border validity ignored): role B works out the exact taps of the
+// points it keeps as it does after its own scan, so results do not depend on where the candidates came from.
+// (First version, measured and replaced: per-range LISTS of 16-bit point indices appended through LDS cursors — role B's
+// scan gone just the same, but the scattered 2-byte stores cost the forward 4-10 us, all the backward gained.)
+//   layout: [MaskHeader 64 B] [masks: u8 [pairs][L][Lq*P]]        (W <= 8, Lq*P a multiple of 4)
+struct alignas(64) MaskHeader { int magic, W, L, NP, pairs, pad[11]; };
+constexpr int kMaskMagic = 0x4d53444d;
+constexpr int kMaxMaskRanges = 8;                                               // W: one bit per range
+struct MaskOut { MaskHeader *hdr; uint8_t *masks; int W; };                    // forward side (masks = null: none)
+struct MaskIn { const MaskHeader *hdr; const uint8_t *masks; };                // role B side
 
 // The table entry of a point from its geometry (the same values the tap records are made of, so that the table and a scan
 // of sampling_loc / attn_weight give role B bit-identical records).
@@ -698,7 +699,7 @@ __global__ __launch_bounds__(kSBlock, 4) void bwd_fused_lds_d32_kernel(
     const int64_t *__restrict__ level_start, const float *__restrict__ loc, const float *__restrict__ attn, int S, int M, int L,
     int Lq, int P, int p_shift, int lp_shift, int tp_cap, int W, int nB, int chunks, int qw, int stage_rows,
     GT *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attn, const PrologueOut pro, int xcd,
-    int lds_bytes, const ListIn li = ListIn{nullptr, nullptr, nullptr, 0, 0})
+    int lds_bytes, const MaskIn mi = MaskIn{nullptr, nullptr})
 {
     static_assert(kSBlock == kLBlock, "both roles run in 512-thread workgroups");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -715,7 +716,7 @@ __global__ __launch_bounds__(kSBlock, 4) void bwd_fused_lds_d32_kernel(
             return;
         }
         bwd_value_body<ACC, kSinglePPT, VT, GT, false, DET>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift,
-                                                            tp_cap, grad_value, ti, Wl, l, pr, smem, li);
+                                                            tp_cap, grad_value, ti, Wl, l, pr, smem, mi);
     } else {
         bwd_query_lds_body<VT, FUSED, NS>(grad_out, value, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, lp_shift, chunks,
                                           qw, stage_rows, grad_loc, grad_attn, pro,
@@ -833,16 +834,16 @@ static LdsPlan plan_lds(int N, int S, int M, int L, int Lq, int P, long long rol
 template <typename VT, bool FUSED>
 static int launch_fwd_lds(const LdsPlan &lp, const VT *value, const int64_t *shapes, const int64_t *level_start, const float *loc,
                           const float *attn, int N, int S, int M, int L, int Lq, int P, VT *out, const PrologueIn &pro,
-                          hipStream_t stream, const ListOut lo = ListOut{nullptr, nullptr, nullptr, 0, 0})
+                          hipStream_t stream, const MaskOut mo = MaskOut{nullptr, nullptr, 0})
 {
     const dim3 grid((unsigned)(N * M * lp.chunks));
-    // (with lists to write: LDS cursors [L*W] and the ranges' first pixels [L][W + 1] behind the records)
-    const size_t lds = lp.lds + (lo.lists ? (size_t)(L * lo.W + L * (lo.W + 1)) * sizeof(int) : 0);
+    // (with masks to write: the ranges' first pixels [L][W + 1] and a float scale per level behind the records)
+    const size_t lds = lp.lds + (mo.masks ? (size_t)(L * (mo.W + 1) + L) * sizeof(int) : 0);
 #define MSDA_LAUNCH_FL(NS_)                                                                            \
     do { if (int rc = allow_lds(reinterpret_cast<const void *>(fwd_d32_lds_kernel<VT, FUSED, NS_>), lds)) return rc;               \
          hipLaunchKernelGGL((fwd_d32_lds_kernel<VT, FUSED, NS_>), grid, dim3(kLBlock), lds, stream, value, shapes, level_start,    \
                             loc, attn, S, M, L, Lq, P, pow2_shift(P), pow2_shift(L * P), lp.chunks, lp.qw, lp.stage_rows, out,   \
-                            pro, xcd_remap(), lo); } while (0)
+                            pro, xcd_remap(), mo); } while (0)
     if (8 * L * P <= kWave) MSDA_LAUNCH_FL(1); else MSDA_LAUNCH_FL(2);             // plan_lds: L*P <= 16
 #undef MSDA_LAUNCH_FL
     return check_launch("msda forward (d32, LDS stage)");
@@ -873,8 +874,8 @@ static const RangeHeader *table_header_of(const PointEntry *table, int N, int M,
     return reinterpret_cast<const RangeHeader *>(table + (long long)N * M * L * Lq * P);
 }
 
-// per-range point lists of large problems (ListHeader): plan_lists below
-static ListOut list_out(void *table, int N, int S, int M, int L, int Lq, int P);
+// per-point range masks of large problems (MaskHeader): plan_masks below
+static MaskOut mask_out(void *table, int N, int S, int M, int L, int Lq, int P);
 
 template <typename VT>
 static int launch_fwd_d32_t(const VT *value, const int64_t *shapes, const int64_t *level_start,
@@ -884,7 +885,7 @@ static int launch_fwd_d32_t(const VT *value, const int64_t *shapes, const int64_
     const LdsPlan lp = plan_lds<VT>(N, S, M, L, Lq, P);
     if (lp.use)
         return launch_fwd_lds<VT, false>(lp, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, out,
-                                         PrologueIn{nullptr, nullptr, nullptr, 0, 0}, stream, list_out(table, N, S, M, L, Lq, P));
+                                         PrologueIn{nullptr, nullptr, nullptr, 0, 0}, stream, mask_out(table, N, S, M, L, Lq, P));
     const int items = N * Lq * M, LP = L * P;
     const int item_stride = LP * kRecBytes + kItemPad;
     const int split = pick_split(items, LP);
@@ -957,48 +958,40 @@ static ValuePlan plan_value(int N, int S, int M, int L, int Lq, int P, int targe
 
 static ValuePlan plan_value_f32(int N, int S, int M, int L, int Lq, int P) { return plan_value<float>(N, S, M, L, Lq, P, bwd_target_wgs(), false); }
 
-// Per-range point lists (ListHeader): where the forward is the LDS-stage kernel and role B the kept-taps pass with W ranges per
-// level — the same plan functions the launchers run, so the forward's writer and the backward's reader agree on the layout
-// (the header repeats it and role B checks).  Row storage does not matter: chunks / qw do not depend on it.
-struct ListPlan { bool use; int W, chunks, cap; size_t counts_off, lists_off, bytes; };
-static ListPlan plan_lists(int N, int S, int M, int L, int Lq, int P)
+// Per-point range masks (MaskHeader): where the forward is the LDS-stage kernel and role B the kept-taps pass with W <= 8
+// ranges per level — the same plan functions the launchers run, so the forward's writer and the backward's reader agree
+// (the header repeats the plan and role B checks it).  Row storage does not matter.
+struct MaskPlan { bool use; int W; size_t bytes; };
+static MaskPlan plan_masks(int N, int S, int M, int L, int Lq, int P)
 {
-    static const int enabled = env_int("MSDA_LISTS", 1);                // A/B knob (tuning build): 0 = role B scans
-    ListPlan lp{false, 0, 0, 0, 0, 0, 0};
-    if (!enabled) return lp;
-    const LdsPlan f = plan_lds<float>(N, S, M, L, Lq, P);
-    if (!f.use) return lp;
+    static const int enabled = env_int("MSDA_MASKS", 1);                // A/B knob (tuning build): 0 = role B scans sampling_loc
+    MaskPlan mp{false, 0, 0};
+    if (!enabled || !plan_lds<float>(N, S, M, L, Lq, P).use) return mp;
     const ValuePlan pl = plan_value_f32(N, S, M, L, Lq, P);
-    const long long NP = (long long)Lq * P, pairs = (long long)N * M, cap = ((long long)f.qw * P + 7) & ~7LL;
-    if (pl.acc != kAccWide || pl.ppt != kSinglePPT || NP > kWideMaxStep || pl.W * L > kMaxListRanges) return lp;
-    const long long sublists = pairs * L * pl.W * f.chunks;
-    if (cap > 65528 || (long long)f.chunks * cap >= (1LL << 23) || sublists * cap >= (1LL << 31)) return lp;
-    lp.use = true; lp.W = pl.W; lp.chunks = f.chunks; lp.cap = (int)cap;
-    lp.counts_off = sizeof(ListHeader);
-    lp.lists_off = lp.counts_off + (((size_t)sublists * 2 + 63) & ~(size_t)63);
-    lp.bytes = lp.lists_off + (size_t)sublists * (size_t)cap * 2;
-    return lp;
+    const long long NP = (long long)Lq * P;
+    if (pl.acc != kAccWide || pl.ppt != kSinglePPT || pl.W > kMaxMaskRanges || (NP & 3) || (long long)L * NP >= (1LL << 31)) return mp;
+    mp.use = true; mp.W = pl.W;
+    mp.bytes = sizeof(MaskHeader) + (size_t)N * M * L * (size_t)NP;
+    return mp;
 }
-static ListOut list_out(void *table, int N, int S, int M, int L, int Lq, int P)
+static MaskOut mask_out(void *table, int N, int S, int M, int L, int Lq, int P)
 {
-    ListOut lo{nullptr, nullptr, nullptr, 0, 0};
-    if (!table) return lo;
-    const ListPlan lp = plan_lists(N, S, M, L, Lq, P);
-    if (!lp.use) return lo;
+    MaskOut mo{nullptr, nullptr, 0};
+    if (!table) return mo;
+    const MaskPlan mp = plan_masks(N, S, M, L, Lq, P);
+    if (!mp.use) return mo;
     unsigned char *b = static_cast<unsigned char *>(table);
-    return ListOut{reinterpret_cast<ListHeader *>(b), reinterpret_cast<uint16_t *>(b + lp.counts_off),
-                   reinterpret_cast<uint16_t *>(b + lp.lists_off), lp.W, lp.cap};
+    return MaskOut{reinterpret_cast<MaskHeader *>(b), b + sizeof(MaskHeader), mp.W};
 }
 // (role B reads them only where its own plan is the kept-taps pass with the same W; never under the deterministic flag)
-static ListIn list_in(const void *table, int N, int S, int M, int L, int Lq, int P, int acc, int W, bool deterministic)
+static MaskIn mask_in(const void *table, int N, int S, int M, int L, int Lq, int P, int acc, int W, bool deterministic)
 {
-    ListIn li{nullptr, nullptr, nullptr, 0, 0};
-    if (!table || deterministic || acc != kAccWide) return li;
-    const ListPlan lp = plan_lists(N, S, M, L, Lq, P);
-    if (!lp.use || lp.W != W) return li;
+    MaskIn mi{nullptr, nullptr};
+    if (!table || deterministic || acc != kAccWide) return mi;
+    const MaskPlan mp = plan_masks(N, S, M, L, Lq, P);
+    if (!mp.use || mp.W != W) return mi;
     const unsigned char *b = static_cast<const unsigned char *>(table);
-    return ListIn{reinterpret_cast<const ListHeader *>(b), reinterpret_cast<const uint16_t *>(b + lp.counts_off),
-                  reinterpret_cast<const uint16_t *>(b + lp.lists_off), lp.chunks, lp.cap};
+    return MaskIn{reinterpret_cast<const MaskHeader *>(b), b + sizeof(MaskHeader)};
 }
 
 static int allow_lds(const void *fn, size_t bytes)
@@ -1049,7 +1042,7 @@ static void table_header_plan(int N, int S, int M, int L, int Lq, int P, int &W,
 int invalidate_forward_table(void *table, int N, int S, int M, int L, int Lq, int P, hipStream_t stream)
 {
     const size_t off = plan_lds<float>(N, S, M, L, Lq, P).use ? 0 : (size_t)N * M * L * Lq * P * sizeof(PointEntry);
-    static_assert(offsetof(RangeHeader, magic) == 0 && offsetof(ListHeader, magic) == 0, "the stamp is the header's first word");
+    static_assert(offsetof(RangeHeader, magic) == 0 && offsetof(MaskHeader, magic) == 0, "the stamp is the header's first word");
     const hipError_t e = hipMemsetAsync(static_cast<unsigned char *>(table) + off, 0, sizeof(int), stream);
     return e == hipSuccess ? MSDA_OK : set_error(MSDA_ERR_LAUNCH, hipGetErrorString(e));
 }
@@ -1061,9 +1054,9 @@ int invalidate_forward_table(void *table, int N, int S, int M, int L, int Lq, in
 size_t forward_table_bytes(int N, int S, int M, int D, int L, int Lq, int P, bool prologue)
 {
     if (!d32_supported(N, S, M, D, L, Lq, P) || (prologue && !prologue_supported(N, S, M, D, L, Lq, P))) return 0;
-    if (plan_lds<float>(N, S, M, L, Lq, P).use) {                       // large problems: per-range point lists, if role B reads them
-        const ListPlan ll = plan_lists(N, S, M, L, Lq, P);
-        return ll.use ? ll.bytes : 0;
+    if (plan_lds<float>(N, S, M, L, Lq, P).use) {                       // large problems: per-point range masks, if role B reads them
+        const MaskPlan mm = plan_masks(N, S, M, L, Lq, P);
+        return mm.use ? mm.bytes : 0;
     }
     const ValuePlan pl = plan_value<float>(N, S, M, L, Lq, P, bwd_target_wgs(), false);
     if (pl.acc != kAccNone || pl.ppt != kSinglePPT) return 0;
@@ -1089,7 +1082,7 @@ static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *
                             const int64_t *level_start, const float *loc, const float *attn, int N, int S,
                             int M, int L, int Lq, int P, GT *grad_value, float *grad_loc, float *grad_attn,
                             hipStream_t stream, void *workspace = nullptr, size_t ws_bytes = 0, bool deterministic = false,
-                            const PointEntry *table = nullptr)
+                            const PointEntry *table = nullptr, bool no_dense = false)
 {
     const int items = N * Lq * M, LP = L * P;
     const int item_stride = LP * kRecBytes + kItemPad;
@@ -1126,14 +1119,14 @@ static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *
             const dim3 fgrid((unsigned)(nB + (long long)N * M * lds_a.chunks));
             // (at least what the dense coarse-level body needs: two such workgroups still share a CU)
             const size_t flds = max(max(pl.lds, lds_a.lds), (size_t)dense_lds_bytes());
-            const bool dense = dense_on() && pl.W <= 2;
-            const ListIn lists = list_in(table, N, S, M, L, Lq, P, pl.acc, pl.W, deterministic);
+            const bool dense = dense_on() && pl.W <= 2 && !no_dense;
+            const MaskIn masks = mask_in(table, N, S, M, L, Lq, P, pl.acc, pl.W, deterministic);
 #define MSDA_LAUNCH_FLD__(AC, NS_, DT, DN)                                                             \
             do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_fused_lds_d32_kernel<AC, VT, false, GT, NS_, DT, DN>), flds)) return rc; \
             hipLaunchKernelGGL((bwd_fused_lds_d32_kernel<AC, VT, false, GT, NS_, DT, DN>), fgrid, dim3(kSBlock), flds, stream, grad_out,  \
                                value, shapes, level_start, loc, attn, S, M, L, Lq, P, ps, lps, pl.tp_cap, pl.W, (int)nB,          \
                                lds_a.chunks, lds_a.qw, lds_a.stage_rows, grad_value, grad_loc, grad_attn,                        \
-                               PrologueOut{nullptr, 0, 0}, xcd, (DN) ? (int)flds : 0, lists); } while (0)
+                               PrologueOut{nullptr, 0, 0}, xcd, (DN) ? (int)flds : 0, masks); } while (0)
 #define MSDA_LAUNCH_FLD_(AC, NS_, DT) do { if (dense) MSDA_LAUNCH_FLD__(AC, NS_, DT, true); else MSDA_LAUNCH_FLD__(AC, NS_, DT, false); } while (0)
 #define MSDA_LAUNCH_FLD(AC, NS_) do { if (deterministic) MSDA_LAUNCH_FLD_(AC, NS_, true); else MSDA_LAUNCH_FLD_(AC, NS_, false); } while (0)
             const bool one_slot = 8 * LP <= kWave;
@@ -1250,7 +1243,7 @@ static int launch_fwd_prologue_t(const VT *value, const int64_t *shapes, const i
     const LdsPlan lp = plan_lds<VT>(N, S, M, L, Lq, P);
     if (lp.use)
         return launch_fwd_lds<VT, true>(lp, value, shapes, level_start, offsets, logits, N, S, M, L, Lq, P, out, pro, stream,
-                                        list_out(table, N, S, M, L, Lq, P));
+                                        mask_out(table, N, S, M, L, Lq, P));
     const int xcd = xcd_remap();
 #define MSDA_LAUNCH_FP(SP)                                                                             \
     hipLaunchKernelGGL((fwd_d32_kernel<SP, VT, true>), grid, block, lds, stream, value, shapes, level_start, offsets, \
@@ -1267,7 +1260,7 @@ static int launch_bwd_prologue_t(const VT *grad_out, const VT *value, const int6
                                  const float *loc, const float *attn, int N, int S, int M, int L, int Lq, int P, float *grad_value,
                                  long long ld_grad_offsets, long long ld_grad_logits, float *grad_offsets, float *grad_logits,
                                  float *grad_ref, hipStream_t stream, void *workspace, size_t ws_bytes, bool deterministic,
-                                 const PointEntry *table = nullptr)
+                                 const PointEntry *table = nullptr, bool no_dense = false)
 {
     const int items = N * Lq * M, LP = L * P;
     const int item_stride = LP * kRecBytes + kItemPad;
@@ -1291,14 +1284,14 @@ static int launch_bwd_prologue_t(const VT *grad_out, const VT *value, const int6
         const dim3 lgrid((unsigned)(nB + (long long)N * M * lq.chunks));
         const size_t llds = max(max(pl.lds, lq.lds), (size_t)dense_lds_bytes());
 #define MSDA_LAUNCH_BPL(AC, NS_) do { if (deterministic) MSDA_LAUNCH_BPL_(AC, NS_, true); else MSDA_LAUNCH_BPL_(AC, NS_, false); } while (0)
-        const bool dense = dense_on() && pl.W <= 2;
-        const ListIn lists = list_in(table, N, S, M, L, Lq, P, pl.acc, pl.W, deterministic);
+        const bool dense = dense_on() && pl.W <= 2 && !no_dense;
+        const MaskIn masks = mask_in(table, N, S, M, L, Lq, P, pl.acc, pl.W, deterministic);
 #define MSDA_LAUNCH_BPL_(AC, NS_, DT) do { if (dense) MSDA_LAUNCH_BPL__(AC, NS_, DT, true); else MSDA_LAUNCH_BPL__(AC, NS_, DT, false); } while (0)
 #define MSDA_LAUNCH_BPL__(AC, NS_, DT, DN)                                                             \
         do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_fused_lds_d32_kernel<AC, VT, true, float, NS_, DT, DN>), llds)) return rc; \
         hipLaunchKernelGGL((bwd_fused_lds_d32_kernel<AC, VT, true, float, NS_, DT, DN>), lgrid, dim3(kSBlock), llds, stream, grad_out,   \
                            value, shapes, level_start, loc, attn, S, M, L, Lq, P, ps, lps, pl.tp_cap, pl.W, (int)nB, lq.chunks,   \
-                           lq.qw, lq.stage_rows, grad_value, grad_offsets, grad_logits, pro_h, xcd_remap(), (DN) ? (int)llds : 0, lists); } while (0)
+                           lq.qw, lq.stage_rows, grad_value, grad_offsets, grad_logits, pro_h, xcd_remap(), (DN) ? (int)llds : 0, masks); } while (0)
         const bool one_slot = 8 * LP <= kWave;
         if (pl.acc == kAccNone) { if (one_slot) MSDA_LAUNCH_BPL(kAccNone, 1); else MSDA_LAUNCH_BPL(kAccNone, 2); }
         else                    { if (one_slot) MSDA_LAUNCH_BPL(kAccWide, 1); else MSDA_LAUNCH_BPL(kAccWide, 2); }
@@ -1358,11 +1351,12 @@ int launch_fwd_prologue_bf16(const uint16_t *value, const int64_t *shapes, const
 int launch_bwd_prologue(const float *grad_out, const float *value, const int64_t *shapes, const int64_t *level_start,
                         const float *loc, const float *attn, int N, int S, int M, int L, int Lq, int P, float *grad_value,
                         long long ld_grad_offsets, long long ld_grad_logits, float *grad_offsets, float *grad_logits,
-                        float *grad_ref, hipStream_t stream, void *workspace, size_t ws_bytes, bool deterministic, const void *table)
+                        float *grad_ref, hipStream_t stream, void *workspace, size_t ws_bytes, bool deterministic, const void *table,
+                        bool no_dense)
 {
     return launch_bwd_prologue_t<float>(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, grad_value,
                                         ld_grad_offsets, ld_grad_logits, grad_offsets, grad_logits, grad_ref, stream, workspace,
-                                        ws_bytes, deterministic, static_cast<const PointEntry *>(table));
+                                        ws_bytes, deterministic, static_cast<const PointEntry *>(table), no_dense);
 }
 #endif
 #if MSDA_D32_HAS(2)
@@ -1370,11 +1364,11 @@ int launch_bwd_prologue_bf16(const uint16_t *grad_out, const uint16_t *value, co
                              const float *loc, const float *attn, int N, int S, int M, int L, int Lq, int P, float *grad_value,
                              long long ld_grad_offsets, long long ld_grad_logits, float *grad_offsets, float *grad_logits,
                              float *grad_ref, hipStream_t stream, void *workspace, size_t ws_bytes, bool deterministic,
-                             const void *table)
+                             const void *table, bool no_dense)
 {
     return launch_bwd_prologue_t<bf16_t>(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, grad_value,
                                          ld_grad_offsets, ld_grad_logits, grad_offsets, grad_logits, grad_ref, stream, workspace,
-                                         ws_bytes, deterministic, static_cast<const PointEntry *>(table));
+                                         ws_bytes, deterministic, static_cast<const PointEntry *>(table), no_dense);
 }
 #endif
 
@@ -1389,10 +1383,10 @@ int launch_fwd_d32(const float *value, const int64_t *shapes, const int64_t *lev
 int launch_bwd_d32(const float *grad_out, const float *value, const int64_t *shapes, const int64_t *level_start,
                    const float *loc, const float *attn, int N, int S, int M, int L, int Lq, int P,
                    float *grad_value, float *grad_loc, float *grad_attn, hipStream_t stream, void *workspace, size_t ws_bytes,
-                   bool deterministic, const void *table)
+                   bool deterministic, const void *table, bool no_dense)
 {
     return launch_bwd_d32_t<float>(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, grad_value,
-                                   grad_loc, grad_attn, stream, workspace, ws_bytes, deterministic, static_cast<const PointEntry *>(table));
+                                   grad_loc, grad_attn, stream, workspace, ws_bytes, deterministic, static_cast<const PointEntry *>(table), no_dense);
 }
 #endif
 #if MSDA_D32_HAS(1)
@@ -1407,20 +1401,20 @@ int launch_fwd_d32_bf16(const uint16_t *value, const int64_t *shapes, const int6
 int launch_bwd_d32_bf16(const uint16_t *grad_out, const uint16_t *value, const int64_t *shapes,
                         const int64_t *level_start, const float *loc, const float *attn, int N, int S, int M, int L,
                         int Lq, int P, uint16_t *grad_value, float *grad_loc, float *grad_attn, hipStream_t stream,
-                        void *workspace, size_t ws_bytes, bool deterministic, const void *table)
+                        void *workspace, size_t ws_bytes, bool deterministic, const void *table, bool no_dense)
 {
     return launch_bwd_d32_t<bf16_t>(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, grad_value,
-                                    grad_loc, grad_attn, stream, workspace, ws_bytes, deterministic, static_cast<const PointEntry *>(table));
+                                    grad_loc, grad_attn, stream, workspace, ws_bytes, deterministic, static_cast<const PointEntry *>(table), no_dense);
 }
 #endif
 #if MSDA_D32_HAS(2)
 int launch_bwd_d32_bf16_gv32(const uint16_t *grad_out, const uint16_t *value, const int64_t *shapes,
                              const int64_t *level_start, const float *loc, const float *attn, int N, int S, int M, int L,
                              int Lq, int P, float *grad_value, float *grad_loc, float *grad_attn, hipStream_t stream,
-                             void *workspace, size_t ws_bytes, bool deterministic, const void *table)
+                             void *workspace, size_t ws_bytes, bool deterministic, const void *table, bool no_dense)
 {
     return launch_bwd_d32_t<bf16_t, float>(grad_out, value, shapes, level_start, loc, attn, N, S, M, L, Lq, P, grad_value,
-                                           grad_loc, grad_attn, stream, workspace, ws_bytes, deterministic, static_cast<const PointEntry *>(table));
+                                           grad_loc, grad_attn, stream, workspace, ws_bytes, deterministic, static_cast<const PointEntry *>(table), no_dense);
 }
 #endif
 
@@ -1430,7 +1424,7 @@ int backward_passes(int Lq, int P) { return (Lq * P + kSingleMaxPoints - 1) / kS
 // What the launchers above would do for a geometry, as text (msda_describe_plan, include/msda.h): the same plan functions,
 // nothing launched.  row_bytes = 4 (fp32 rows) or 2 (bf16 rows); gv_bytes the same for grad_value.
 template <typename VT, typename GT>
-static int describe_plan_t(int N, int S, int M, int L, int Lq, int P, bool prologue, bool has_ws, bool det, char *buf, int len)
+static int describe_plan_t(int N, int S, int M, int L, int Lq, int P, bool prologue, bool has_ws, bool det, char *buf, int len, bool no_dense)
 {
     const int items = N * Lq * M, LP = L * P;
     int n = 0;
@@ -1445,10 +1439,10 @@ static int describe_plan_t(int N, int S, int M, int L, int Lq, int P, bool prolo
     const bool lds_ok = la.use && pl.ppt == kSinglePPT && (pl.acc == kAccNone || pl.acc == kAccWide) && (!prologue || has_ws);
     if (lds_ok)
         // dense_px: a level of at most this many pixels (that the launch deals W workgroups) goes to the matrix cores
-        // lists: role B takes its points from the per-range lists a forward with a workspace leaves (msda_forward_ws_*)
+        // masks: role B finds its points through the per-point range masks a forward with a workspace leaves (msda_forward_ws_*)
         put(" bwd=fused_lds(acc=%s,W=%d,tp_cap=%d,roleB=%lld,roleA=%d,qw=%d,dense_px=%d%s%s%s)", acc, pl.W, pl.tp_cap, nB, N * M * la.chunks, la.qw,
-            !dense_on() || pl.W > 2 ? 0 : pl.W == 2 ? kDenseMaxRows : kDensePassRows, det ? ",det" : "", prologue ? ",heads_reduce" : "",
-            (!det && pl.acc == kAccWide && plan_lists(N, S, M, L, Lq, P).use && plan_lists(N, S, M, L, Lq, P).W == pl.W) ? ",lists" : "");
+            !dense_on() || no_dense || pl.W > 2 ? 0 : pl.W == 2 ? kDenseMaxRows : kDensePassRows, det ? ",det" : "", prologue ? ",heads_reduce" : "",
+            (!det && pl.acc == kAccWide && plan_masks(N, S, M, L, Lq, P).use && plan_masks(N, S, M, L, Lq, P).W == pl.W) ? ",masks" : "");
     else if (pl.ppt == kSinglePPT && pl.acc != kAccTile) {
         const FusedPlan fp = plan_fused(items, LP, pick_split(items, LP), nB, pl.acc, prologue ? M : 0, det);
         put(" bwd=fused(acc=%s,W=%d,tp_cap=%d,roleB=%lld,roleA=%d,split=%d,%s%s)", acc, pl.W, pl.tp_cap, nB,
@@ -1458,11 +1452,11 @@ static int describe_plan_t(int N, int S, int M, int L, int Lq, int P, bool prolo
     return n;
 }
 int describe_plan(int row_bytes, int gv_bytes, int N, int S, int M, int L, int Lq, int P, bool prologue, bool has_ws, bool det,
-                  char *buf, int len)
+                  char *buf, int len, bool no_dense)
 {
-    if (row_bytes == 4) return describe_plan_t<float, float>(N, S, M, L, Lq, P, prologue, has_ws, det, buf, len);
-    if (gv_bytes == 4) return describe_plan_t<bf16_t, float>(N, S, M, L, Lq, P, prologue, has_ws, det, buf, len);
-    return describe_plan_t<bf16_t, bf16_t>(N, S, M, L, Lq, P, prologue, has_ws, det, buf, len);
+    if (row_bytes == 4) return describe_plan_t<float, float>(N, S, M, L, Lq, P, prologue, has_ws, det, buf, len, no_dense);
+    if (gv_bytes == 4) return describe_plan_t<bf16_t, float>(N, S, M, L, Lq, P, prologue, has_ws, det, buf, len, no_dense);
+    return describe_plan_t<bf16_t, bf16_t>(N, S, M, L, Lq, P, prologue, has_ws, det, buf, len, no_dense);
 }
 #endif
 

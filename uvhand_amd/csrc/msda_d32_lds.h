@@ -174,7 +174,7 @@ __global__ __launch_bounds__(kLBlock, 4) void fwd_d32_lds_kernel(
     const VT *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
     const float *__restrict__ loc, const float *__restrict__ attn, int S, int M, int L, int Lq, int P, int p_shift, int lp_shift,
     int chunks, int qw, int stage_rows, VT *__restrict__ out, const PrologueIn pro, int xcd,
-    const ListOut lo = ListOut{nullptr, nullptr, nullptr, 0, 0})
+    const MaskOut mo = MaskOut{nullptr, nullptr, 0})
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     LdsLevel *tab = reinterpret_cast<LdsLevel *>(smem);
@@ -186,31 +186,28 @@ __global__ __launch_bounds__(kLBlock, 4) void fwd_d32_lds_kernel(
     const int lbid = xcd ? xcd_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
     lds_block_range(lbid, chunks, qw, M, Lq, b, m, q0, q1);
     lds_level_table(shapes, level_start, S, L, stage_rows, tab);
-    // Per-range point lists for role B of this node's backward (ListHeader, msda_d32.hip): LDS cursors [L*W] and the ranges'
-    // first pixels [L][W + 1] — the very expression role B cuts its ranges with.  (uniform: lo.lists is a kernel argument)
-    const int LW = lo.W;
-    int *bcnt = reinterpret_cast<int *>(smem + lds_variant_bytes<VT>(stage_rows, LP));
-    int *bnd = bcnt + L * LW;
-    if (lo.lists) {
-        for (int i = tid; i < L * LW; i += kLBlock) bcnt[i] = 0;
+    // Per-point range masks for role B of this node's backward (MaskHeader, msda_d32.hip): the ranges' first pixels [L][W + 1]
+    // — the very expression role B cuts its ranges with — and W / (H*W) per level.  (uniform: mo.masks is a kernel argument)
+    const int LW = mo.W;
+    int *bnd = reinterpret_cast<int *>(smem + lds_variant_bytes<VT>(stage_rows, LP));
+    float *bscale = reinterpret_cast<float *>(bnd + L * (LW + 1));
+    if (mo.masks) {
         for (int i = tid; i < L * (LW + 1); i += kLBlock) {
             const int l = i / (LW + 1), t = i - l * (LW + 1);
             const long long H = shapes[2 * l], Wd = shapes[2 * l + 1];
             const int HW = level_fits(H, Wd, level_start[l], S) ? (int)(H * Wd) : 0;
             bnd[i] = (int)((unsigned)(t * HW) / (unsigned)LW);
+            if (t == 0) bscale[l] = HW > 0 ? (float)LW / (float)HW : 0.f;
         }
         if (lbid == 0 && tid == 0) {
-            ListHeader h;
-            h.magic = kListMagic; h.W = LW; h.L = L; h.chunks = chunks; h.cap = lo.cap; h.NP = Lq * P; h.pairs = (int)gridDim.x / chunks; h.qw = qw;
+            MaskHeader h;
+            h.magic = kMaskMagic; h.W = LW; h.L = L; h.NP = Lq * P; h.pairs = (int)gridDim.x / chunks;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) h.pad[k] = 0;
-            *lo.hdr = h;
+            for (int k = 0; k < 11; ++k) h.pad[k] = 0;
+            *mo.hdr = h;
         }
     }
-    // element offset of this workgroup's sub-list of (level 0, range 0): sub-list (pair, l, t, c) starts at
-    // (((pair * L + l) * W + t) * chunks + c) * cap
-    const int pair_i = lbid / chunks, chunk_i = lbid - pair_i * chunks;
-    const size_t list_base = ((size_t)pair_i * L * LW * chunks + chunk_i) * (size_t)lo.cap;
+    const size_t mask_base = (size_t)(lbid / chunks) * L * ((size_t)Lq * P);       // this pair's [L][Lq*P] bytes
     __syncthreads();
     lds_stage_rows<VT>(value, tab, L, S, M, b, m, stage);
     if (tid < 8) Row<VT>::store(stage + stage_rows * kD + tid * 4, make_float4(0.f, 0.f, 0.f, 0.f));
@@ -268,24 +265,22 @@ __global__ __launch_bounds__(kLBlock, 4) void fwd_d32_lds_kernel(
             // (outside the map lh = lw = 0 and every tap reads zeros: the weight only has to be finite -> 0)
             const float aw = g.inside ? a : 0.f;
             *reinterpret_cast<float4 *>(slot + 16) = make_float4(hh * hw * aw, hh * g.lw * aw, g.lh * hw * aw, g.lh * g.lw * aw);
-            if (lo.lists) {                                                  // (uniform) this point -> the lists of the ranges it may touch
+            if (mo.masks) {                                                  // (uniform) bit t: a tap of this point may land in range t
                 const int *bl = bnd + l * (LW + 1);
                 const int HW = bl[LW];
-                if (live && g.inside && HW > 0) {
+                unsigned mk = 0;
+                if (g.inside && HW > 0) {
                     const int pix = g.h0 * t.W + g.w0;                       // tap (h0, w0); its neighbours: +1, +W, +W+1
                     const int pmin = max(pix, 0), pmax = min(pix + t.W + 1, HW - 1);
-                    // range of pixel pmin: ranges start at floor(k * HW / W); a float estimate, made exact against the table
-                    int ti = (int)((float)(pmin + 1) * ((float)LW * __builtin_amdgcn_rcpf((float)HW)));
-                    ti = min(max(ti, 0), LW - 1);
-                    ti += (int)(pmin >= bl[ti + 1]) - (int)(pmin < bl[ti]);
-                    const unsigned pidx = (unsigned)((qo + i2) * P + (pt - l * P));
-                    const unsigned slot0 = (unsigned)__mul24(l * LW, chunks * lo.cap);
-                    do {
-                        const int pos = atomicAdd(&bcnt[l * LW + ti], 1);    // (< cap: a chunk has at most qw * P points per level)
-                        lo.lists[(size_t)list_base + slot0 + (unsigned)__mul24(ti, chunks * lo.cap) + (unsigned)pos] = (uint16_t)pidx;
-                        ++ti;
-                    } while (ti < LW && pmax >= bl[ti]);
+                    // range of a pixel: ranges start at floor(k * HW / W); a float estimate, made exact against the table
+                    const float sc = bscale[l];
+                    int t0 = min(max((int)((float)(pmin + 1) * sc), 0), LW - 1);
+                    int t1 = min(max((int)((float)(pmax + 1) * sc), 0), LW - 1);
+                    t0 += (int)(pmin >= bl[t0 + 1]) - (int)(pmin < bl[t0]);
+                    t1 += (int)(pmax >= bl[t1 + 1]) - (int)(pmax < bl[t1]);
+                    mk = (2u << t1) - (1u << t0);
                 }
+                if (live) mo.masks[mask_base + (size_t)(l * (Lq * P) + (qo + i2) * P + (pt - l * P))] = (uint8_t)mk;
             }
         }
         if (qo + step < q1) fetch(qo + step);                    // next octet's locations: in flight during the gather
@@ -316,11 +311,6 @@ __global__ __launch_bounds__(kLBlock, 4) void fwd_d32_lds_kernel(
         }
         if (qo + grp < q1) Row<VT>::store(out + (((long long)b * Lq + qo + grp) * M + m) * kD + j * 4, acc);
         __builtin_amdgcn_wave_barrier();                         // the records are rewritten for the next octet
-    }
-    if (lo.lists) {                                              // (uniform) this chunk's entries per (level, range)
-        __syncthreads();
-        for (int i = tid; i < L * LW; i += kLBlock)
-            lo.counts[((size_t)pair_i * L * LW + i) * chunks + chunk_i] = (uint16_t)bcnt[i];
     }
 }
 

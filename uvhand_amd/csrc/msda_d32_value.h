@@ -480,7 +480,7 @@ __device__ __forceinline__ void gather_split(const GoBuf<VT> go, GT *__restrict_
 template <typename VT, typename GT, bool DET>
 __device__ __forceinline__ void bwd_value_wide_body(const VT *__restrict__, const int64_t *__restrict__, const int64_t *__restrict__,
                                                     const float *__restrict__, const float *__restrict__, int, int, int, int, int,
-                                                    int, int, GT *__restrict__, int, int, int, int, unsigned char *, const ListIn);   // kAccWide, below
+                                                    int, int, GT *__restrict__, int, int, int, int, unsigned char *, const MaskIn);   // kAccWide, below
 
 // PPT = sampling points per thread per pass: all of a thread's points are loaded up front (2*PPT
 // independent global loads in flight), their taps and histogram ranks stay in registers between
@@ -493,12 +493,12 @@ __device__ __forceinline__ void bwd_value_body(
     const int64_t *__restrict__ level_start, const float *__restrict__ loc,
     const float *__restrict__ attn, int S, int M, int L, int Lq, int P, int p_shift, int tp_cap,
     GT *__restrict__ grad_value, int ti, int W, int l, int pr, unsigned char *smem,
-    const ListIn li = ListIn{nullptr, nullptr, nullptr, 0, 0})
+    const MaskIn mi = MaskIn{nullptr, nullptr})
 {
     static_assert(!(FIXED && DET), "the fixed-capacity segments take ranks in arrival order");
     if constexpr (ACC == kAccWide) {
         bwd_value_wide_body<VT, GT, DET>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, tp_cap, grad_value,
-                                         ti, W, l, pr, smem, li);
+                                         ti, W, l, pr, smem, mi);
         return;
     }
     constexpr int NPC = PPT * kSBlock;                       // points per pass
@@ -939,7 +939,7 @@ __device__ __forceinline__ void bwd_value_wide_body(
     const VT *__restrict__ grad_out, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ level_start, const float *__restrict__ loc,
     const float *__restrict__ attn, int S, int M, int L, int Lq, int P, int p_shift, int tp_cap,
-    GT *__restrict__ grad_value, int ti, int W, int l, int pr, unsigned char *smem, const ListIn li)
+    GT *__restrict__ grad_value, int ti, int W, int l, int pr, unsigned char *smem, const MaskIn mi)
 {
     // LDS: [cnt tp_cap (DET: 4 words per row)] [start tp_cap] [DET: row totals tp_cap] [wsum 32] [list: list_cap x u16, at least
     //      8 KB] [weights rec_cap x f32] [queries rec_cap x u16]
@@ -999,13 +999,13 @@ __device__ __forceinline__ void bwd_value_wide_body(
 
     bool pad8 = false;                                       // layout of the record array for the current attempt (count_points)
     // steps 1-2 for the points [p0, p1); returns the number of record slots they take
-    // The forward's per-range lists (ListHeader, msda_d32.hip), if the caller handed them over and they were written for exactly
-    // this plan: then the first attempt (all points at once) takes its list from there instead of scanning the level.
-    bool have_lists = false;
+    // The forward's per-point range masks (MaskHeader, msda_d32.hip), if the caller handed them over and they were written for
+    // exactly this plan: then the first attempt (all points at once) finds its candidates there instead of in sampling_loc.
+    bool have_masks = false;
     if constexpr (!DET) {
-        if (li.lists) {                                      // (uniform: kernel argument; the header comes through the scalar cache)
-            const ListHeader *h = li.hdr;
-            have_lists = h->magic == kListMagic && h->W == W && h->L == L && h->chunks == li.chunks && h->cap == li.cap && h->NP == Lq * P;
+        if (mi.masks) {                                      // (uniform: kernel argument; the header comes through the scalar cache)
+            const MaskHeader *h = mi.hdr;
+            have_masks = h->magic == kMaskMagic && h->W == W && h->L == L && h->NP == Lq * P && pr < h->pairs && (Lq * P & 3) == 0;
         }
     }
     auto count_points = [&](int p0, int p1) -> int {
@@ -1013,52 +1013,45 @@ __device__ __forceinline__ void bwd_value_wide_body(
         if (tid == 0) *kept_p = 0;
         if (DET && tid < kSWaves) kept_w[tid] = 0;
         __syncthreads();
-        const bool from_lists = !DET && have_lists && p0 == 0 && p1 == Lq * P;      // (uniform)
-        if (from_lists) {
-            // 1a'. the listed points of my range: `chunks` sub-lists (one per forward workgroup of the pair), each a count and
-            // up to `cap` 16-bit point indices.  Every wavefront prefix-sums the counts (64 sub-lists at a time, one per lane);
-            // the entries of those 64 sub-lists are then ONE run of positions dealt to all 512 threads — a thread finds the
-            // sub-list of its position by a binary search over the lanes' prefixes (six cross-lane reads), so two long sub-lists
-            // (cfg-4 encoder) and thirty-two short ones (cfg-2 encoder) copy equally well.  Four loads in flight per thread.
-            const size_t bucket = ((size_t)pr * L + l) * W + ti;
-            const uint16_t *cn = li.counts + bucket * li.chunks;
-            const uint16_t *src = li.lists + bucket * li.chunks * (size_t)li.cap;
-            const int last_point = Lq * P - 1;
-            int run = 0;
-            for (int c0 = 0; c0 < li.chunks; c0 += kWave) {
-                const int c = c0 + lane;
-                const int n = c < li.chunks ? min((int)cn[c], li.cap) : 0;
-                int incl = n;
+        const bool from_masks = !DET && have_masks && p0 == 0 && p1 == Lq * P;      // (uniform)
+        if (from_masks) {
+            // 1a'. candidates from the masks: Lq*P bytes of this (pair, level), four points per 32-bit load, fully coalesced;
+            // a point is listed iff bit `ti` of its byte is set.  Same list, same order of work as the scan below, minus the
+            // strided float2 loads and the float range test.
+            const unsigned *mw = reinterpret_cast<const unsigned *>(mi.masks + ((size_t)pr * L + l) * (size_t)(Lq * P));
+            const int nd = (Lq * P) >> 2;
+            constexpr int UM = 4;                                             // loads in flight per thread: 8192 points per trip
+            for (int base = 0; base < nd; base += kSBlock * UM) {
+                unsigned wv[UM];
 #pragma unroll
-                for (int o = 1; o < kWave; o <<= 1) { const int y = __shfl_up(incl, o, kWave); if (lane >= o) incl += y; }
-                const int excl = incl - n;                               // within these 64 sub-lists
-                const int here = __shfl(incl, kWave - 1, kWave);
-                constexpr int UL = 4;
-                for (int base = 0; base < here; base += UL * kSBlock) {
-                    uint16_t v[UL];
-#pragma unroll
-                    for (int u = 0; u < UL; ++u) {
-                        const int pos = base + u * kSBlock + tid;
-                        int k = 0;                                           // the largest lane whose prefix is <= pos: its sub-list holds pos
-#pragma unroll
-                        for (int stepk = kWave / 2; stepk > 0; stepk >>= 1) {
-                            const int e = __shfl(excl, k + stepk, kWave);
-                            if (e <= pos) k += stepk;
-                        }
-                        const int ek = __shfl(excl, k, kWave);
-                        v[u] = 0;
-                        if (pos < here) v[u] = src[(size_t)(c0 + k) * li.cap + (pos - ek)];
-                    }
-#pragma unroll
-                    for (int u = 0; u < UL; ++u) {
-                        const int pos = base + u * kSBlock + tid;
-                        // (an index is only ever used below Lq*P: whatever the buffer holds, no read leaves sampling_loc)
-                        if (pos < here && run + pos < list_cap) list[run + pos] = (uint16_t)min((int)v[u], last_point);
-                    }
+                for (int u = 0; u < UM; ++u) {
+                    const int d = base + u * kSBlock + tid;
+                    wv[u] = d < nd ? (mw[d] >> ti) & 0x01010101u : 0u;          // bit 8j: point 4d + j is a candidate
                 }
-                run += here;
+                unsigned long long mask[UM][4];
+                int n = 0;
+#pragma unroll
+                for (int u = 0; u < UM; ++u)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        mask[u][jj] = 0;
+                        if (base + u * kSBlock >= nd) continue;                 // uniform: no point in this slot
+                        mask[u][jj] = __ballot((wv[u] >> (8 * jj)) & 1u);
+                        n += __popcll(mask[u][jj]);
+                    }
+                if (n == 0) continue;                                           // uniform
+                int wbase = 0;
+                if (lane == 0) wbase = atomicAdd(kept_p, n);
+                wbase = __shfl(wbase, 0, kWave);
+#pragma unroll
+                for (int u = 0; u < UM; ++u)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int pos = wbase + __popcll(mask[u][jj] & ((1ull << lane) - 1ull));
+                        if (((mask[u][jj] >> lane) & 1ull) && pos < seg) list[pos] = (uint16_t)(4 * (base + u * kSBlock + tid) + jj);
+                        wbase += __popcll(mask[u][jj]);
+                    }
             }
-            if (tid == 0) *kept_p = run;
         } else {
         // 1a. the points that MAY have a tap on this workgroup's rows -> list.  No histogram yet (an LDS atomic costs
         // ~30 cycles per wavefront instruction however few lanes take part, and here ~1/W of them would); the test is

@@ -46,7 +46,7 @@ int launch_bwd_d32(const float *grad_out, const float *value, const int64_t *sha
                    const int64_t *level_start, const float *loc, const float *attn, int N, int S,
                    int M, int L, int Lq, int P, float *grad_value, float *grad_loc, float *grad_attn,
                    hipStream_t stream, void *workspace = nullptr, size_t ws_bytes = 0, bool deterministic = false,
-                   const void *table = nullptr);
+                   const void *table = nullptr, bool no_dense = false);
 // the point table a small problem's forward can leave for its backward (bytes; 0 = the backward's plan reads none); `table`
 // arguments of the launchers below: that table (forward: written, backward: read), or null
 size_t forward_table_bytes(int N, int S, int M, int D, int L, int Lq, int P, bool prologue);
@@ -63,19 +63,20 @@ int launch_bwd_d32_bf16(const uint16_t *grad_out, const uint16_t *value, const i
                         const int64_t *level_start, const float *loc, const float *attn, int N, int S,
                         int M, int L, int Lq, int P, uint16_t *grad_value, float *grad_loc, float *grad_attn,
                         hipStream_t stream, void *workspace = nullptr, size_t ws_bytes = 0, bool deterministic = false,
-                        const void *table = nullptr);
+                        const void *table = nullptr, bool no_dense = false);
 
 // bf16 rows in, fp32 grad_value out: nothing is rounded between the passes of a multi-pass backward (and a
 // caller whose value tensor is fp32 needs no conversion of the result)
 int launch_bwd_d32_bf16_gv32(const uint16_t *grad_out, const uint16_t *value, const int64_t *shapes,
                              const int64_t *level_start, const float *loc, const float *attn, int N, int S, int M, int L,
                              int Lq, int P, float *grad_value, float *grad_loc, float *grad_attn, hipStream_t stream,
-                             void *workspace = nullptr, size_t ws_bytes = 0, bool deterministic = false, const void *table = nullptr);
+                             void *workspace = nullptr, size_t ws_bytes = 0, bool deterministic = false, const void *table = nullptr,
+                             bool no_dense = false);
 // number of query chunks ("passes") role B of the D = 32 backward takes for Lq*P sampling points per (b, m, l)
 int backward_passes(int Lq, int P);
 // text form of the launch plan of a D = 32 geometry (msda_describe_plan); returns the length written
 int describe_plan(int row_bytes, int gv_bytes, int N, int S, int M, int L, int Lq, int P, bool prologue, bool has_ws, bool det,
-                  char *buf, int len);
+                  char *buf, int len, bool no_dense = false);
 
 // ---- fused prologue (fp32, D = 32 family): softmax over L*P and loc = ref + offset/(W,H) inside the kernels.
 // ld_* = floats between consecutive (batch, query) rows of the raw offsets / logits and of their gradients
@@ -89,7 +90,7 @@ int launch_bwd_prologue(const float *grad_out, const float *value, const int64_t
                         const float *loc, const float *attn, int N, int S, int M, int L, int Lq, int P, float *grad_value,
                         long long ld_grad_offsets, long long ld_grad_logits, float *grad_offsets, float *grad_logits,
                         float *grad_ref, hipStream_t stream, void *workspace = nullptr, size_t ws_bytes = 0, bool deterministic = false,
-                        const void *table = nullptr);
+                        const void *table = nullptr, bool no_dense = false);
 
 // bf16 rows (value, out, grad_out); offsets / logits / reference points and every gradient fp32 (grad_value included)
 int launch_fwd_prologue_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *level_start, const float *ref,
@@ -100,7 +101,8 @@ int launch_bwd_prologue_bf16(const uint16_t *grad_out, const uint16_t *value, co
                              const float *loc, const float *attn, int N, int S, int M, int L, int Lq, int P, float *grad_value,
                              long long ld_grad_offsets, long long ld_grad_logits, float *grad_offsets, float *grad_logits,
                              float *grad_ref, hipStream_t stream, void *workspace = nullptr, size_t ws_bytes = 0,
-                             bool deterministic = false, const void *table = nullptr);
+                             bool deterministic = false, const void *table = nullptr,
+                             bool no_dense = false);
 
 // ---- weight / bias gradient of the bracketing nn.Linear layers (msda_linear.hip) -----------------
 size_t linear_wgrad_workspace_bytes(int M, int N, int K);

@@ -6,6 +6,7 @@
 //
 // No kernels here and no torch types beyond this file: every call ends in msda_forward_* / msda_backward_ws_* of
 // libmsda_hip.so with raw device pointers, sizes and the current HIP stream.
+#include <atomic>
 #include <torch/extension.h>
 
 // PyTorch-ROCm presents its HIP devices as DeviceType::CUDA: the guard and the stream are the "masquerading" ones
@@ -75,6 +76,9 @@ void once_differentiable(const torch::autograd::variable_list &grads, const char
 
 // The buffer a forward of this geometry fills with its point table for the backward of the same node (msda_forward_ws_*,
 // include/msda.h); undefined where the backward's plan reads none.
+// MSDA_FLAG_EXACT_NONFINITE for every backward queued from here (uvhand_amd.set_exact_nonfinite; include/msda.h)
+static std::atomic<unsigned> g_extra_flags{0};
+
 at::Tensor forward_table(const at::Tensor &like, const Dims &d, unsigned flags)
 {
     unsigned long long n = msda_forward_workspace_bytes(d.N, d.S, d.M, d.D, d.L, d.Lq, d.P, flags);
@@ -127,7 +131,15 @@ std::vector<at::Tensor> backward_t(const at::Tensor &value, const at::Tensor &sh
     auto gv = at::empty_like(value), gl = at::empty_like(loc), ga = at::empty_like(attn);
     auto stream = (msda_stream_t)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(value.device().index()).stream();
     int rc;
-    unsigned flags = deterministic ? MSDA_FLAG_DETERMINISTIC : 0u;
+    // no deterministic kernel for this geometry within the library's work bound + warn_only: warn and run the default kernels,
+    // as torch does for its own ops without a deterministic form (without warn_only the library's refusal is raised)
+    if (deterministic && at::globalContext().deterministicAlgorithmsWarnOnly() &&
+        !msda_deterministic_supported(value.scalar_type() == at::kDouble ? 8 : 4, d.N, d.S, d.M, d.D, d.L, d.Lq, d.P)) {
+        TORCH_WARN_ONCE("ms_deform_attn_backward: no deterministic grad_value kernel for this geometry within the work bound "
+                        "(include/msda.h, MSDA_FLAG_DETERMINISTIC); running the default (atomic) kernel [warn_only]");
+        deterministic = false;
+    }
+    unsigned flags = (deterministic ? MSDA_FLAG_DETERMINISTIC : 0u) | g_extra_flags.load();
     at::Tensor ws;
     // (also without flags: the library says how much scratch a call of this geometry can use, mostly none)
     unsigned long long nbytes = 0;
@@ -257,7 +269,13 @@ public:
         const bool gv32 = value.scalar_type() == at::kFloat || msda_backward_passes(d.Lq, d.P) > 1 ||
                           msda_path_for(2, d.M, d.D, d.L, d.P) != MSDA_PATH_D32 ||
                           (((uintptr_t)go.data_ptr() | (uintptr_t)v16.data_ptr() | (uintptr_t)l32.data_ptr()) & 7) != 0;
-        unsigned flags = (ctx->saved_data["det"].toBool() || at::globalContext().deterministicAlgorithms()) ? MSDA_FLAG_DETERMINISTIC : 0u;
+        bool det = ctx->saved_data["det"].toBool() || at::globalContext().deterministicAlgorithms();
+        if (det && at::globalContext().deterministicAlgorithmsWarnOnly() && !msda_deterministic_supported(2, d.N, d.S, d.M, d.D, d.L, d.Lq, d.P)) {
+            TORCH_WARN_ONCE("ms_deform_attn_backward (bf16 rows): no deterministic grad_value kernel for this geometry within the work "
+                            "bound; running the default (atomic) kernel [warn_only]");
+            det = false;
+        }
+        unsigned flags = (det ? MSDA_FLAG_DETERMINISTIC : 0u) | g_extra_flags.load();
         c10::hip::HIPGuardMasqueradingAsCUDA guard(v16.device());
         auto gv = at::empty_like(v16, v16.options().dtype(gv32 ? at::kFloat : at::kBFloat16));
         auto gl = at::empty_like(l32), ga = at::empty_like(a32);
@@ -502,7 +520,7 @@ public:
                                                lsi.data_ptr<int64_t>(), loc.data_ptr<float>(), attn.data_ptr<float>(), N, S, M, D, L,
                                                Lq, P, 3LL * mlp, 3LL * mlp, gv.data_ptr<float>(), gproj.data_ptr<float>(),
                                                gproj.data_ptr<float>() + 2 * mlp, gref.data_ptr<float>(),
-                                               nbytes ? ws.data_ptr() : nullptr, nbytes, (det ? MSDA_FLAG_DETERMINISTIC : 0u) | table_flag, stream),
+                                               nbytes ? ws.data_ptr() : nullptr, nbytes, (det ? MSDA_FLAG_DETERMINISTIC : 0u) | table_flag | g_extra_flags.load(), stream),
                  "ms_deform_attn_backward_prologue");
         // merged projection
         at::Tensor g_query;
@@ -638,7 +656,7 @@ public:
                                                   attn.data_ptr<float>(), N, S, M, D, L, Lq, P, 3LL * mlp, 3LL * mlp,
                                                   gv.data_ptr<float>(), gproj.data_ptr<float>(), gproj.data_ptr<float>() + 2 * mlp,
                                                   gref.data_ptr<float>(), nbytes ? ws.data_ptr() : nullptr, nbytes,
-                                                  (det ? MSDA_FLAG_DETERMINISTIC : 0u) | table_flag, stream),
+                                                  (det ? MSDA_FLAG_DETERMINISTIC : 0u) | table_flag | g_extra_flags.load(), stream),
                  "ms_deform_attn_backward_prologue (bf16 rows)");
         // merged projection (float32)
         at::Tensor g_query;
@@ -725,4 +743,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 #undef MSDA_MODULE_ARGS
     // the header this file was COMPILED against (not the loaded library's msda_version(): _ext.py compares the two)
     m.def("abi_version", [] { return (int)MSDA_ABI_VERSION; });
+    m.def("set_exact_nonfinite", [](bool on) { g_extra_flags.store(on ? MSDA_FLAG_EXACT_NONFINITE : 0u); },
+          "MSDA_FLAG_EXACT_NONFINITE on every backward the C++ nodes queue (include/msda.h)");
 }
