@@ -19,7 +19,8 @@ pytestmark = pytest.mark.gpu
 
 C2 = [(48, 48), (24, 24), (12, 12), (6, 6)]
 C4 = [(28, 28), (14, 14), (7, 7), (4, 4)]
-BIG = {"cfg2_encoder": (2, 3060, C2), "cfg4_decoder": (32, 300, C4), "cfg4_encoder": (32, 1045, C4)}
+BIG = {"cfg2_encoder": (2, 3060, C2), "cfg4_decoder": (32, 300, C4), "cfg4_encoder": (32, 1045, C4),
+       "l3_w4_encoder": (4, 2100, [(40, 40), (20, 20), (10, 10)])}      # a 3-level pyramid whose plan has W = 4 ranges per level
 M, P, D = 8, 4, 32
 MAGIC = 0x4d53444d
 
@@ -84,29 +85,32 @@ def _exact_ranges(loc, shapes, W):
 
 @pytest.mark.parametrize("name", list(BIG))
 def test_plans_that_read_masks(native, name):
-    """Masks exist exactly where role B is the kept-taps pass (more points per level than one pass sorts): the two encoder
-    shapes; cfg-4 decoder (1200 points per level and pair, one range per level) scans once anyway and gets none."""
+    """Masks exist where role B is the kept-taps pass (more points per level than one pass sorts) with at least four ranges per
+    level: cfg-2 encoder (W = 6).  cfg-4 encoder (W = 2: its scan reads every point twice, cheaper than the forward's bytes —
+    measured, profiles/r05_notes.md) and cfg-4 decoder (one range per level, one pass) get none."""
     N, Lq, shapes = BIG[name]
     S = sum(h * w for h, w in shapes)
     plan = native.describe_plan(N, S, M, D, len(shapes), Lq, P)
     nbytes = int(native._lib.msda_forward_workspace_bytes(N, S, M, D, len(shapes), Lq, P, 0))
-    assert ("masks" in plan) == (name != "cfg4_decoder"), plan
+    assert ("masks" in plan) == (name in ("cfg2_encoder", "l3_w4_encoder")), plan
     assert nbytes == (64 + N * M * len(shapes) * Lq * P if "masks" in plan else 0)
     assert "masks" not in native.describe_plan(N, S, M, D, len(shapes), Lq, P, deterministic=True)
 
 
-@pytest.mark.parametrize("name", ["cfg2_encoder", "cfg4_encoder"])
+
+
+@pytest.mark.parametrize("name", ["cfg2_encoder", "l3_w4_encoder"])
 def test_masks_are_a_tight_superset_of_the_exact_answer(native, name):
     sh, lsi, value, loc, attn, go = _case(name)
     N, Lq, shapes = BIG[name]
     out, table = native.ms_deform_attn_forward(value.cuda(), sh.cuda(), lsi.cuda(), loc.cuda(), attn.cuda(), 64, with_table=True)
     assert table is not None
     h, masks = _decode(table)
-    assert h["magic"] == MAGIC and h["L"] == 4 and h["NP"] == Lq * P and h["pairs"] == N * M and 1 <= h["W"] <= 8
+    assert h["magic"] == MAGIC and h["L"] == len(shapes) and h["NP"] == Lq * P and h["pairs"] == N * M and 1 <= h["W"] <= 8
     W = h["W"]
     exact = _exact_ranges(loc.numpy(), shapes, W)                            # [N, Lq, M, L, P, W]
     got = ((masks[..., None] >> np.arange(W)) & 1).astype(bool)              # [pairs, L, NP, W]
-    got = got.reshape(N, M, 4, Lq, P, W).transpose(0, 3, 1, 2, 4, 5)         # -> [N, Lq, M, L, P, W]
+    got = got.reshape(N, M, len(shapes), Lq, P, W).transpose(0, 3, 1, 2, 4, 5)   # -> [N, Lq, M, L, P, W]
     assert (masks >> W == 0).all(), "bits beyond the plan's ranges"
     assert not (exact & ~got).any(), "a point with a tap in a range whose bit is clear"
     assert got.sum() <= 1.25 * exact.sum() + 64, (int(got.sum()), int(exact.sum()))       # a superset, but a tight one
@@ -131,7 +135,7 @@ def test_backward_from_the_masks_equals_backward_from_a_scan(native, oracle, nam
     kw = {"fp32_grad_value": True} if bf16 else {}
     base = native.ms_deform_attn_backward(v, s, i, l, a, g, 64, **kw)
     if table is None:
-        assert name == "cfg4_decoder"
+        assert name in ("cfg4_decoder", "cfg4_encoder")
         return
     got = native.ms_deform_attn_backward(v, s, i, l, a, g, 64, table=table, **kw)
     assert torch.equal(got[1], base[1]) and torch.equal(got[2], base[2])

@@ -102,6 +102,7 @@ __host__ __device__ inline size_t range_header_bytes() { return sizeof(RangeHead
 struct alignas(64) MaskHeader { int magic, W, L, NP, pairs, pad[11]; };
 constexpr int kMaskMagic = 0x4d53444d;
 constexpr int kMaxMaskRanges = 8;                                               // W: one bit per range
+constexpr int kMinMaskRanges = 4;                                               // fewer ranges: the scan is cheaper than the forward's bytes (plan_masks)
 struct MaskOut { MaskHeader *hdr; uint8_t *masks; int W; };                    // forward side (masks = null: none)
 struct MaskIn { const MaskHeader *hdr; const uint8_t *masks; };                // role B side
 
@@ -969,7 +970,12 @@ static MaskPlan plan_masks(int N, int S, int M, int L, int Lq, int P)
     if (!enabled || !plan_lds<float>(N, S, M, L, Lq, P).use) return mp;
     const ValuePlan pl = plan_value_f32(N, S, M, L, Lq, P);
     const long long NP = (long long)Lq * P;
-    if (pl.acc != kAccWide || pl.ppt != kSinglePPT || pl.W > kMaxMaskRanges || (NP & 3) || (long long)L * NP >= (1LL << 31)) return mp;
+    // W >= kMinMaskRanges: the byte costs the forward ~35 instructions per point lane (+10 % of its time), and each range's
+    // workgroup saves the strided float scan of all Lq*P points — a trade that pays from four ranges per level on (cfg-2
+    // encoder, W = 6: forward +1.7 us, backward -2.5 ... -4 us) and loses with two (cfg-4 encoder: forward +4.5 us, backward
+    // +2 us — its scan reads every point twice either way; profiles/r05_notes.md section 1)
+    static const int min_w = env_int("MSDA_MASKS_MIN_W", kMinMaskRanges);
+    if (pl.acc != kAccWide || pl.ppt != kSinglePPT || pl.W > kMaxMaskRanges || pl.W < min_w || (NP & 3) || (long long)L * NP >= (1LL << 31)) return mp;
     mp.use = true; mp.W = pl.W;
     mp.bytes = sizeof(MaskHeader) + (size_t)N * M * L * (size_t)NP;
     return mp;
