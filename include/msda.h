@@ -340,6 +340,13 @@ int msda_add_layernorm_backward_f32(const float *grad_y, const float *x, const f
                                     const float *mean, const float *rstd, long long rows, int d, float *grad_sum,
                                     float *grad_gamma, float *grad_beta, void *workspace, msda_stream_t stream);
 
+/* ---- FFN of the layers (models/arctic_transformer.py:283-287, :366-370) ---------------------------
+ * linear2(dropout(relu(linear1(x)))): with act = dropout(relu(h)) — the tensor linear2 consumed, saved for its weight gradient
+ * anyway — the gradient with respect to h is grad * scale * (act > 0), scale = 1 / (1 - p): one in-place pass over
+ * `grad` [n floats, n a multiple of 4, both pointers 16-byte aligned] instead of PyTorch's masked_scale + threshold_backward,
+ * and neither the dropout mask nor relu's output has to be kept. */
+int msda_relu_dropout_backward_f32(float *grad, const float *act, float scale, long long n, msda_stream_t stream);
+
 /* ---- Transformer input assembly -----------------------------------------------------
  * The flatten block of DeformableTransformer.forward (models/arctic_transformer.py:162-173): per level
  * src_l[N,C,H,W] -> rows [level_start_l, level_start_l + H*W) of src_flatten[N,S,C], and pos_l the same way with

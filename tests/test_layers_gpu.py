@@ -137,3 +137,42 @@ def test_add_layernorm_kernel_matches_fp64(rows, d, with_res):
     norm.zero_grad(); x.grad = None
     add_layer_norm(x, r, norm).backward(gy)
     assert torch.equal(norm.weight.grad, gw1)
+
+
+@pytest.mark.parametrize("rows,d,ffn,p", [(600, 256, 1024, 0.0), (6120, 256, 1024, 0.1), (33, 64, 128, 0.3), (1, 32, 64, 0.5)])
+def test_fused_ffn_equals_the_composition_of_the_same_modules(rows, d, ffn, p):
+    """linear2(dropout(relu(linear1(x)))) as one autograd node (models/arctic_transformer.py:283-287): the
+    same values and the same gradients — input, both weights, both biases — as the reference's composition of nn.Linear / relu /
+    nn.Dropout run from the same seed (the node calls PyTorch's own dropout kernel, so the masks are identical), and the random
+    stream is left where nn.Dropout leaves it."""
+    from uvhand_amd.functions.linear_func import _FusedFFNFn, fused_ffn
+    g = torch.Generator().manual_seed(rows + d)
+    l1, l2, drop = nn.Linear(d, ffn).cuda(), nn.Linear(ffn, d).cuda(), nn.Dropout(p).train()
+    x = torch.randn(2, rows, d, generator=g).cuda().requires_grad_(True) if rows > 1 else torch.randn(rows, d, generator=g).cuda().requires_grad_(True)
+    gy = torch.randn(x.shape, generator=g).cuda()
+    torch.manual_seed(11)
+    y = fused_ffn(x, l1, torch.nn.functional.relu, drop, l2)
+    assert type(y.grad_fn).__name__ == "_FusedFFNFnBackward"
+    after_fused = torch.cuda.get_rng_state()
+    y.backward(gy)
+    got = [y.detach(), x.grad.clone()] + [q.grad.clone() for q in (l1.weight, l1.bias, l2.weight, l2.bias)]
+    for q in (x, l1.weight, l1.bias, l2.weight, l2.bias):
+        q.grad = None
+    torch.manual_seed(11)
+    y2 = l2(drop(torch.relu(l1(x))))
+    assert torch.equal(torch.cuda.get_rng_state(), after_fused), "the node consumed the random stream differently from nn.Dropout"
+    y2.backward(gy)
+    ref = [y2.detach(), x.grad] + [q.grad for q in (l1.weight, l1.bias, l2.weight, l2.bias)]
+    for name, a, b in zip(("out", "grad_x", "grad_w1", "grad_b1", "grad_w2", "grad_b2"), got, ref):
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 2e-5, name
+    # eval mode / frozen parameters: no dropout, and no weight-gradient launch for a layer that needs none
+    drop.eval()
+    for q in (l1.weight, l1.bias):
+        q.requires_grad_(False)
+    x.grad = l1.weight.grad = l1.bias.grad = l2.weight.grad = l2.bias.grad = None
+    y3 = fused_ffn(x, l1, torch.nn.functional.relu, drop, l2)
+    y3.backward(gy)
+    assert l1.weight.grad is None and l2.weight.grad is not None
+    assert rel_err(y3.detach().cpu().numpy(), l2(torch.relu(l1(x))).detach().cpu().numpy()) < 2e-5
+    # other activations / autocast: the composition of the same modules (no node)
+    assert "FusedFFN" not in type(fused_ffn(x, l1, torch.nn.functional.gelu, drop, l2).grad_fn).__name__

@@ -28,6 +28,7 @@ _SYMBOLS = (
     "msda_backward_ws_bf16_gv32",
     "msda_backward_prologue_ws_f32", "msda_forward_prologue_bf16", "msda_backward_prologue_bf16_gv32",
     "msda_add_layernorm_workspace_bytes", "msda_add_layernorm_forward_f32", "msda_add_layernorm_backward_f32",
+    "msda_relu_dropout_backward_f32",
     "msda_flatten_levels_f32", "msda_unflatten_levels_f32", "msda_unflatten_workspace_bytes",
     "msda_linear_wgrad_f32", "msda_linear_wgrad_masked_f32", "msda_linear_wgrad_masked_bf16", "msda_linear_wgrad_workspace_bytes",
     "msda_zero_masked_rows_f32", "msda_linear_forward_f32", "msda_linear_dgrad_f32",
@@ -605,6 +606,22 @@ def ms_deform_attn_backward_prologue(value, spatial_shapes, level_start_index, s
     if rc != 0:
         _raise(lib, rc, "ms_deform_attn_backward_prologue")
     return (gv, goff, glog, gref, both) if merged else (gv, goff, glog, gref)
+
+
+def relu_dropout_backward_(grad, act, scale):
+    """grad *= scale * (act > 0), in place (msda_relu_dropout_backward_f32, include/msda.h): the backward of
+    dropout(relu(h)) from act = dropout(relu(h)).  fp32 CUDA tensors of the same size, contiguous, 16-byte aligned."""
+    lib = _lib or load()
+    n = grad.numel()
+    if not (grad.is_cuda and act.is_cuda and grad.dtype == act.dtype == torch.float32 and act.numel() == n
+            and grad.is_contiguous() and act.is_contiguous()):
+        raise RuntimeError("relu_dropout_backward_: expected two contiguous float32 CUDA tensors of one size")
+    with _DeviceGuard(grad.device):
+        rc = _entry(lib, "msda_relu_dropout_backward_f32", [_VP, _VP, ctypes.c_float, _LL, _VP])(
+            grad.data_ptr(), act.data_ptr(), float(scale), n, _raw_stream(grad.device))
+    if rc != 0:
+        _raise(lib, rc, "relu_dropout_backward_")
+    return grad
 
 
 def add_layernorm_supported(x, residual, weight, bias):

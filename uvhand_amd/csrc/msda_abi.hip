@@ -691,6 +691,15 @@ int msda_add_layernorm_backward_f32(const float *grad_y, const float *x, const f
                                           static_cast<float *>(workspace), (hipStream_t)stream);
 }
 
+int msda_relu_dropout_backward_f32(float *grad, const float *act, float scale, long long n, msda_stream_t stream)
+{
+    if (n < 0 || (n & 3) || (n > 0 && (grad == nullptr || act == nullptr)) || (((uintptr_t)grad | (uintptr_t)act) & 15))
+        return msda::set_error(MSDA_ERR_ARGUMENT, "msda_relu_dropout_backward_f32: n must be a multiple of 4 and both tensors 16-byte aligned");
+    msda::begin_call();
+    if (n == 0) return MSDA_OK;
+    return msda::launch_relu_dropout_bwd(grad, act, scale, n, (hipStream_t)stream);
+}
+
 static int flatten_impl(const char *who, int L, float *const *src_levels, float *const *pos_levels, const float *level_embed,
                         const int *heights, const int *widths, int N, int C, float *src_flatten, float *pos_flatten, bool unflatten,
                         msda_stream_t stream, float *grad_level_embed = nullptr, void *workspace = nullptr,

@@ -139,4 +139,7 @@ int launch_add_layernorm_bwd(const float *dy, const float *x, const float *res, 
                              const float *rstd, long long rows, int d, float *ds, float *dgamma, float *dbeta, float *workspace,
                              hipStream_t stream);
 
+// ---- FFN of the layers: backward of dropout(relu(h)) in one in-place pass (msda_layernorm.hip) ----
+int launch_relu_dropout_bwd(float *grad, const float *act, float scale, long long n, hipStream_t stream);
+
 }  // namespace msda

@@ -202,4 +202,32 @@ int launch_add_layernorm_bwd(const float *dy, const float *x, const float *res, 
     return check_launch("msda layernorm parameter gradients");
 }
 
+// ---- FFN of the layers (models/arctic_transformer.py:283-287, :366-370): linear2(dropout(relu(linear1(x)))) ----------------
+// Backward of dropout(relu(h)) in ONE pass, in place on the incoming gradient: with a = dropout(relu(h)) = relu(h) * keep / (1 - p)
+// (what the forward saved as linear2's input anyway), a > 0 exactly where h > 0 and the element was kept, so
+//     grad_h = grad_a * scale * (a > 0),   scale = 1 / (1 - p)   (1 without dropout)
+// needs neither the dropout mask nor relu's output: PyTorch runs masked_scale (grad, mask -> tmp) and threshold_backward
+// (tmp, relu output -> grad_h), five tensor passes over [rows, d_ffn] against three here.
+__global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(float *__restrict__ grad, const float *__restrict__ act, float scale,
+                                                                long long n4)
+{
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const float4 a = reinterpret_cast<const float4 *>(act)[i];
+        float4 g = reinterpret_cast<float4 *>(grad)[i];
+        g.x = a.x > 0.f ? g.x * scale : 0.f; g.y = a.y > 0.f ? g.y * scale : 0.f;
+        g.z = a.z > 0.f ? g.z * scale : 0.f; g.w = a.w > 0.f ? g.w * scale : 0.f;
+        reinterpret_cast<float4 *>(grad)[i] = g;
+    }
+}
+
+int launch_relu_dropout_bwd(float *grad, const float *act, float scale, long long n, hipStream_t stream)
+{
+    const long long n4 = n / 4;
+    long long blocks = (n4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;                                    // grid-stride: ~32 workgroups per CU at most
+    hipLaunchKernelGGL(relu_dropout_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, grad, act, scale, n4);
+    return check_launch("msda relu+dropout backward");
+}
+
 }  // namespace msda

@@ -18,6 +18,7 @@ import os
 
 import torch
 import torch.nn.functional as F
+from torch import nn
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
@@ -151,6 +152,81 @@ class _MaskedBracketLinearFn(Function):
             if not need_w:
                 grad_w = None
         return grad_x, grad_w, grad_b, None
+
+
+class _FusedFFNFn(Function):
+    """``linear2(dropout(relu(linear1(x))))`` — the FFN of the layers (models/arctic_transformer.py:283-287, :366-370) — as ONE
+    autograd node:
+    * forward: bias + ReLU in the epilogue of linear1's GEMM (``torch._addmm_activation``: hipBLASLt's RELU_BIAS epilogue, or
+      addmm + an in-place relu where the epilogue is not offered); dropout is PyTorch's own fused kernel
+      (``torch.native_dropout``: the very call ``nn.Dropout`` makes, so the Philox stream is consumed exactly as in the
+      reference's loop) — its mask is NOT kept;
+    * backward: the dropout and ReLU gradients are one in-place pass over linear2's input gradient
+      (``grad * scale * (a > 0)`` with ``a`` = linear2's saved input; msda_relu_dropout_backward_f32), and both weight
+      gradients take the split-M MFMA kernel.
+    Saved: x, a = dropout(relu(h)), the two weights — not h, not relu(h), not the mask (at the training shape 137 + 137 + 34
+    MB per encoder layer less).  One difference from the reference's composition: where h is NaN the reference's
+    threshold_backward lets the gradient through and this node blocks it (NaN > 0 is false) — the loss is NaN either way."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, p, training):
+        x2 = x.reshape(-1, x.shape[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        h = torch._addmm_activation(b1, x2, w1.t())                      # relu(x2 @ w1^T + b1)
+        drop = bool(training) and 0.0 < p < 1.0
+        a = torch.native_dropout(h, p, True)[0] if drop else h
+        y = torch.addmm(b2, a, w2.t())
+        ctx.save_for_backward(x2, a, w1, w2)
+        ctx.scale = 1.0 / (1.0 - p) if drop else 1.0
+        ctx.x_shape = x.shape
+        return y.view(*x.shape[:-1], w2.shape[0])
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        x2, a, w1, w2 = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        go2 = grad_out.reshape(-1, grad_out.shape[-1]).contiguous()
+        gw2 = gb2 = gw1 = gb1 = gx = None
+        if need[3] or need[4]:
+            if MSDA.linear_wgrad_supported(go2, a):
+                gw2, gb2 = MSDA.linear_wgrad(go2, a, want_bias=need[4])
+            else:
+                gw2, gb2 = go2.t() @ a, (go2.sum(0) if need[4] else None)
+            if not need[3]:
+                gw2 = None
+        if need[0] or need[1] or need[2]:
+            gh = go2 @ w2                                                  # gradient of a, then of h in place
+            MSDA.relu_dropout_backward_(gh, a, ctx.scale)
+            if need[1] or need[2]:
+                if MSDA.linear_wgrad_supported(gh, x2):
+                    gw1, gb1 = MSDA.linear_wgrad(gh, x2, want_bias=need[2])
+                else:
+                    gw1, gb1 = gh.t() @ x2, (gh.sum(0) if need[2] else None)
+                if not need[1]:
+                    gw1 = None
+            if need[0]:
+                gx = (gh @ w1).view(ctx.x_shape)
+        return gx, gw1, gb1, gw2, gb2, None, None
+
+
+_FUSED_FFN = os.environ.get("MSDA_FUSED_FFN", "1") != "0"            # A/B knob: 0 = the composition of bracket_linear / F.relu / nn.Dropout
+
+
+def fused_ffn(x, linear1, activation, dropout, linear2):
+    """``linear2(dropout(activation(linear1(x))))`` for two ``nn.Linear`` layers and an ``nn.Dropout``: one autograd node
+    (_FusedFFNFn) when the activation is ReLU and the layers are plain float32 CUDA layers with biases outside autocast,
+    else the composition of the same modules (bracket_linear keeps the weight-gradient kernel there)."""
+    if (_FUSED_FFN and _ENABLED and activation is F.relu and type(linear1) is nn.Linear and type(linear2) is nn.Linear
+            and type(dropout) is nn.Dropout and not dropout.inplace and dropout.p < 1.0
+            and linear1.bias is not None and linear2.bias is not None and x.is_cuda and x.dtype == torch.float32
+            and all(t.dtype == torch.float32 and t.is_cuda for t in (linear1.weight, linear1.bias, linear2.weight, linear2.bias))
+            and not torch.is_autocast_enabled() and linear1.out_features % 4 == 0 and linear1.in_features % 4 == 0
+            and linear2.out_features % 4 == 0 and x.numel() > 0):
+        return _FusedFFNFn.apply(x, linear1.weight, linear1.bias, linear2.weight, linear2.bias, float(dropout.p),
+                                 dropout.training)
+    return bracket_linear(dropout(activation(bracket_linear(x, linear1))), linear2)
 
 
 _ENABLED = os.environ.get("MSDA_BRACKET_LINEAR", "1") != "0"       # A/B knob: 0 = always the plain layer

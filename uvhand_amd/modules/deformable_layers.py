@@ -13,8 +13,10 @@ decoder's ``nn.MultiheadAttention`` fed sequence-first exactly as in :374-376.
 What is MI355X-specific: the attention is this package's ``MSDeformAttn`` (HIP kernels); every
 ``x = x + dropout(x2); x = norm(x)`` pair is one fused add+LayerNorm kernel per direction
 (``functions/layernorm_func.py``; the dropout itself stays ``nn.Dropout``, so training uses PyTorch's random stream);
-the FFN's two ``nn.Linear`` layers take the split-M MFMA weight-gradient kernel (``functions/linear_func.py``) — with
-N*S = 33 440 rows per rank at the training shape the weight gradient is the GEMM the vendor BLAS runs worst.
+the FFN ``linear2(dropout(relu(linear1(x))))`` is ONE autograd node (``functions/linear_func.py``: ``fused_ffn``): bias + ReLU
+in the epilogue of linear1's GEMM, PyTorch's own dropout kernel (same random stream), the dropout and ReLU gradients as one
+in-place pass, and both weight gradients on the split-M MFMA kernel — with N*S = 33 440 rows per rank at the training shape
+the weight gradient is the GEMM the vendor BLAS runs worst.
 """
 import copy
 
@@ -23,7 +25,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..functions.layernorm_func import add_layer_norm
-from ..functions.linear_func import bracket_linear
+from ..functions.linear_func import bracket_linear, fused_ffn
 from ..utils.transformer_inputs import decoder_reference_points, encoder_reference_points
 from .ms_deform_attn import MSDeformAttn
 
@@ -58,7 +60,7 @@ class DeformableTransformerEncoderLayer(nn.Module):
         return tensor if pos is None else tensor + pos
 
     def forward_ffn(self, src):
-        src2 = bracket_linear(self.dropout2(self.activation(bracket_linear(src, self.linear1))), self.linear2)
+        src2 = fused_ffn(src, self.linear1, self.activation, self.dropout2, self.linear2)
         return add_layer_norm(src, self.dropout3(src2), self.norm2)
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
@@ -92,7 +94,7 @@ class DeformableTransformerDecoderLayer(nn.Module):
         return tensor if pos is None else tensor + pos
 
     def forward_ffn(self, tgt):
-        tgt2 = bracket_linear(self.dropout3(self.activation(bracket_linear(tgt, self.linear1))), self.linear2)
+        tgt2 = fused_ffn(tgt, self.linear1, self.activation, self.dropout3, self.linear2)
         return add_layer_norm(tgt, self.dropout4(tgt2), self.norm3)
 
     def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, level_start_index, src_padding_mask=None):
