@@ -11,7 +11,8 @@ package: without the built HIP library every call raises.
 """
 from ._native import set_exact_nonfinite
 from .functions import MSDeformAttnFunction
+from .graphs import graphed
 from .modules import MSDeformAttn
 
-__all__ = ["MSDeformAttn", "MSDeformAttnFunction", "set_exact_nonfinite"]
+__all__ = ["MSDeformAttn", "MSDeformAttnFunction", "graphed", "set_exact_nonfinite"]
 __version__ = "0.1.0"
