@@ -254,3 +254,28 @@ def test_deterministic_flag_reaches_the_generic_family(native, oracle, name, dty
         assert all(torch.equal(a, b) for a, b in zip(runs[0], r))
     assert torch.equal(runs[0][1], base[1]) and torch.equal(runs[0][2], base[2])
     _check(z, runs[0], oracle)                           # (the oracle runs in the inputs' precision: float32)
+
+
+@pytest.mark.parametrize("spread", [None, 0.02], ids=["uniform", "pile_up"])
+def test_deterministic_small_problem_body_with_and_without_the_forward_table(native, oracle, spread):
+    """Round 5: small problems (every workgroup resident: the 300-query decoder shape) keep the short fixed-capacity sort under
+    the deterministic flag — per-wavefront counters, ranks in list order — instead of the general prefix-sum body.  The
+    record order is a pure function of the inputs, so the backward from the forward's point table and the backward from a scan
+    of sampling_loc give the SAME BITS (the default kernels agree only up to summation order), run after run; piled-up
+    locations overflow the fixed segments and take the general deterministic body, with the same guarantees."""
+    N, shapes, M, D, Lq, P = 2, [(48, 48), (24, 24), (12, 12), (6, 6)], 8, 32, 300, 4
+    S = sum(h * w for h, w in shapes)
+    assert "fixed,det" in native.describe_plan(N, S, M, D, len(shapes), Lq, P, deterministic=True)
+    z = make_case(21, N, shapes, M, D, Lq, P)
+    if spread is not None:
+        g = torch.Generator().manual_seed(13)
+        z["loc"] = (torch.tensor([0.37, 0.61]) + (torch.rand(z["loc"].shape, generator=g) - 0.5) * spread).numpy().astype(np.float32)
+    t = {k: dev(z[k]) for k in ("value", "loc", "attn", "grad_out")}
+    sh, ls = dev(z["shapes"]), dev(z["level_start"])
+    _, table = native.ms_deform_attn_forward(t["value"], sh, ls, t["loc"], t["attn"], 64, with_table=True)
+    assert table is not None
+    scan = native.ms_deform_attn_backward(t["value"], sh, ls, t["loc"], t["attn"], t["grad_out"], 64, deterministic=True)
+    for i in range(4):
+        tab = native.ms_deform_attn_backward(t["value"], sh, ls, t["loc"], t["attn"], t["grad_out"], 64, deterministic=True, table=table)
+        assert all(torch.equal(a, b) for a, b in zip(scan, tab)), "run %d" % i
+    _check(z, scan, oracle)

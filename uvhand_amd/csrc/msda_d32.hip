@@ -673,8 +673,8 @@ __global__ __launch_bounds__(kSBlock, 4) void bwd_fused_d32_kernel(
     if (bid < nB) {
         if (xcd) bid = xcd_block(bid, nB);
         if constexpr (FIXED) {                        // small problems (plan_fused): every workgroup of the launch resident
-            bwd_value_small_body<VT, GT>(grad_out, shapes, level_start, loc, attn, table, header, S, M, L, Lq, P, p_shift, tp_cap,
-                                         grad_value, bid, W, smem);
+            bwd_value_small_body<VT, GT, DET>(grad_out, shapes, level_start, loc, attn, table, header, S, M, L, Lq, P, p_shift, tp_cap,
+                                              grad_value, bid, W, smem);
         } else {
             int pr, l, ti, Wl;
             value_block_to_range(bid, W, L, shapes, pr, l, ti, Wl, ACC != kAccWide);
@@ -1025,7 +1025,7 @@ static FusedPlan plan_fused(int items, int LP, int split, long long nB, int acc,
     if (nB + n_a(split) > kResident && split == 4 && LP >= 2 && nB + n_a(2) <= kResident &&
         (whole_queries_of == 0 || (64 / 2) % whole_queries_of == 0))
         fp.split = 2;
-    fp.fixed = !det && nB + n_a(fp.split) <= kResident;      // the short sort ranks records in arrival order
+    fp.fixed = nB + n_a(fp.split) <= kResident;              // (det: the small body's per-wavefront-counter variant, round 5)
     return fp;
 }
 
@@ -1152,15 +1152,14 @@ static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *
             if (nB + nA <= 0x7fffffffLL) {
                 const dim3 fgrid((unsigned)(nB + nA));
                 size_t flds = pl.lds > lds_a ? pl.lds : lds_a;
-                if (fp.fixed) flds = max(flds, small_lds_bytes(pl.tp_cap));
+                if (fp.fixed) flds = max(flds, small_lds_bytes(pl.tp_cap, deterministic));
 #define MSDA_LAUNCH_F_(SP, AC, FX, DT)                                                                 \
                 do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_fused_d32_kernel<SP, AC, VT, false, GT, FX, DT>), flds)) return rc; \
                 hipLaunchKernelGGL((bwd_fused_d32_kernel<SP, AC, VT, false, GT, FX, DT>), fgrid, dim3(kSBlock), flds, stream,  \
                                    grad_out, value, shapes, level_start, loc, attn, S, M, L, Lq, P, items, ps, lps, ms,  \
                                    pl.tp_cap, pl.W, (int)nB, grad_value, grad_loc, grad_attn, PrologueOut{nullptr, 0, 0}, xcd,  \
                                    (FX) ? table : nullptr, (FX) ? table_header_of(table, N, M, L, Lq, P, pl.W) : nullptr); } while (0)
-                // (FX, the short sort, is never planned together with the deterministic flag)
-#define MSDA_LAUNCH_F(SP, AC, FX) do { if (deterministic && !(FX)) MSDA_LAUNCH_F_(SP, AC, false, true); else MSDA_LAUNCH_F_(SP, AC, FX, false); } while (0)
+#define MSDA_LAUNCH_F(SP, AC, FX) do { if (deterministic) MSDA_LAUNCH_F_(SP, AC, FX, true); else MSDA_LAUNCH_F_(SP, AC, FX, false); } while (0)
                 if (fp.fixed)                { if (fp.split == 4) MSDA_LAUNCH_F(4, kAccNone, true); else if (fp.split == 2) MSDA_LAUNCH_F(2, kAccNone, true); else MSDA_LAUNCH_F(1, kAccNone, true); }
                 else if (pl.acc == kAccNone) { if (fp.split == 4) MSDA_LAUNCH_F(4, kAccNone, false); else if (fp.split == 2) MSDA_LAUNCH_F(2, kAccNone, false); else MSDA_LAUNCH_F(1, kAccNone, false); }
                 else if (pl.acc == kAccWide) { if (fp.split == 4) MSDA_LAUNCH_F(4, kAccWide, false); else if (fp.split == 2) MSDA_LAUNCH_F(2, kAccWide, false); else MSDA_LAUNCH_F(1, kAccWide, false); }
@@ -1312,8 +1311,8 @@ static int launch_bwd_prologue_t(const VT *grad_out, const VT *value, const int6
     }
     const dim3 fgrid((unsigned)(nB + nA));
     size_t flds = pl.lds > lds_a ? pl.lds : lds_a;
-    if (fp.fixed) flds = max(flds, small_lds_bytes(pl.tp_cap));
-#define MSDA_LAUNCH_BP(SP, AC, FX) do { if (deterministic && !(FX)) MSDA_LAUNCH_BP_(SP, AC, false, true); else MSDA_LAUNCH_BP_(SP, AC, FX, false); } while (0)
+    if (fp.fixed) flds = max(flds, small_lds_bytes(pl.tp_cap, deterministic));
+#define MSDA_LAUNCH_BP(SP, AC, FX) do { if (deterministic) MSDA_LAUNCH_BP_(SP, AC, FX, true); else MSDA_LAUNCH_BP_(SP, AC, FX, false); } while (0)
 #define MSDA_LAUNCH_BP_(SP, AC, FX, DT)                                                                \
     do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_fused_d32_kernel<SP, AC, VT, true, float, FX, DT>), flds)) return rc; \
     hipLaunchKernelGGL((bwd_fused_d32_kernel<SP, AC, VT, true, float, FX, DT>), fgrid, dim3(kSBlock), flds, stream, grad_out, \

@@ -715,10 +715,11 @@ __device__ __forceinline__ void bwd_value_body(
 constexpr int kSmallRecCap = 4096;                  // record slots (32 KB): 8 per row of a 48x48 level's fifth, 256+ of a 6x6 level's third
 constexpr int kSmallListCap = 96;                   // listed points per wavefront (of its 192); the rest take the sparse path
 
-__host__ __device__ inline size_t small_lds_bytes(int tp_cap)
+// (det: four counter words per row + the row totals instead of one counter per row, and two words of 16-bit ranks per listed point)
+__host__ __device__ inline size_t small_lds_bytes(int tp_cap, bool det = false)
 {
-    return ((size_t)2 * tp_cap + 32) * 4 + (size_t)kSmallRecCap * sizeof(SRec) + (size_t)kOvfCap * sizeof(SOvf) +
-           (size_t)kSWaves * kSmallListCap * (sizeof(PointEntry) + 4);
+    return ((size_t)(det ? 5 : 2) * tp_cap + 32) * 4 + (size_t)kSmallRecCap * sizeof(SRec) + (size_t)kOvfCap * sizeof(SOvf) +
+           (size_t)kSWaves * kSmallListCap * (sizeof(PointEntry) + 4 + (det ? 8 : 0));
 }
 
 // The four taps of a point on this workgroup's rows [px0, px0 + npx) of a W-wide level: range-local destinations (-1 = not
@@ -738,21 +739,28 @@ __device__ __forceinline__ void small_weights(const PointEntry &e, float (&tw)[4
     tw[0] = hh * hw * e.a; tw[1] = hh * e.lw * e.a; tw[2] = e.lh * hw * e.a; tw[3] = e.lh * e.lw * e.a;
 }
 
-template <typename VT, typename GT>
+// DET (MSDA_FLAG_DETERMINISTIC, round 5): the same body with a record order that is a pure function of the inputs — one
+// 16-bit counter per (row, wavefront) (det_count), ranks taken in list order, one more barrier for the rows' totals and
+// per-wavefront bases (det_row_prefix), records written behind it from the list (ranks kept in a word per listed point);
+// a row with more records than its fixed-capacity segment holds sends the workgroup to the general deterministic body.
+template <typename VT, typename GT, bool DET = false>
 __device__ __forceinline__ void bwd_value_small_body(
     const VT *__restrict__ grad_out, const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
     const float *__restrict__ loc, const float *__restrict__ attn, const PointEntry *__restrict__ table,
     const RangeHeader *__restrict__ header, int S, int M, int L, int Lq, int P, int p_shift, int tp_cap, GT *__restrict__ grad_value,
     int bid, int W_plan, unsigned char *smem)
 {
-    // LDS: [cnt tp_cap] [start tp_cap] [wsum 32] [rec kSmallRecCap] [ovf kOvfCap] [listed points: 8 x kSmallListCap entries] [their queries]
+    // LDS: [cnt tp_cap (DET: 4 words per row)] [start tp_cap (DET: the rows' totals)] [wsum 32] [rec kSmallRecCap] [ovf kOvfCap]
+    //      [listed points: 8 x kSmallListCap entries] [their queries] [DET: their ranks]
+    constexpr int CW = DET ? 4 : 1;
     int *cnt = reinterpret_cast<int *>(smem);
-    int *start = cnt + tp_cap;
+    int *start = cnt + tp_cap * CW;
     int *wsum = start + tp_cap;
     SRec *rec = reinterpret_cast<SRec *>(wsum + 32);
     SOvf *ovf = reinterpret_cast<SOvf *>(rec + kSmallRecCap);
     PointEntry *list = reinterpret_cast<PointEntry *>(ovf + kOvfCap);
     int *list_q = reinterpret_cast<int *>(list + kSWaves * kSmallListCap);
+    int *list_rk = list_q + kSWaves * kSmallListCap;                         // (DET only; 8-byte aligned: the lists are multiples of 8 entries)
     int *novf_p = wsum + 8, *total_p = wsum + 9;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = tid & 7;
@@ -807,10 +815,135 @@ __device__ __forceinline__ void bwd_value_small_body(
             }
         }
     }
-    for (int i = tid; i < npx; i += kSBlock) cnt[i] = 0;
+    for (int i = tid; i < npx * CW; i += kSBlock) cnt[i] = 0;
     if (tid == 0) { *novf_p = 0; *total_p = 0; }
     __syncthreads();
     MSDA_STAMP(1);
+
+    if constexpr (DET) {
+        if (cap >= 4) {                                                      // slots per row (uniform); below four: the general body
+            PointEntry *mylist = list + wave * kSmallListCap;
+            int *myq = list_q + wave * kSmallListCap;
+            int2 *myrk = reinterpret_cast<int2 *>(list_rk) + wave * kSmallListCap;     // four 16-bit ranks per listed point
+            // ---- list the points with a tap on my rows: ballot order (point slot k, then lane) — a pure function of the inputs ----
+            int listed = 0;
+            bool late[PPT];
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                int dest[4];
+                small_dests(pe[k], Wd, px0, npx, dest);
+                const bool keep = (dest[0] & dest[1] & dest[2] & dest[3]) >= 0;
+                const unsigned long long mask = __ballot(keep);
+                const int pos = listed + __popcll(mask & ((1ull << lane) - 1ull));
+                late[k] = keep && pos >= kSmallListCap;
+                if (keep && pos < kSmallListCap) { mylist[pos] = pe[k]; myq[pos] = fdiv(tid + k * kSBlock, P, p_shift); }
+                listed += __popcll(mask);
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int n_list = min(listed, kSmallListCap);
+            // ranks among THIS wavefront's taps of a row: list order (trips in order, lanes of one atomic in lane order), then
+            // the points beyond the list's capacity in slot order
+            auto ranks_of = [&](const int (&dest)[4]) -> int2 {
+                int r[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) r[t] = dest[t] >= 0 ? det_count(cnt, dest[t], wave) : 0;
+                return make_int2(r[0] | (r[1] << 16), r[2] | (r[3] << 16));
+            };
+            for (int i0 = 0; i0 < n_list; i0 += kWave) {
+                const int i = i0 + lane;
+                PointEntry e; e.cell = 0; e.lh = e.lw = e.a = 0.f;
+                if (i < n_list) e = mylist[i];
+                int dest[4];
+                small_dests(e, Wd, px0, npx, dest);
+                const int2 rk = ranks_of(dest);
+                if (i < n_list) myrk[i] = rk;
+            }
+            int2 late_rk[PPT];
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                late_rk[k] = make_int2(0, 0);
+                if (listed > kSmallListCap) {                                // (uniform per wavefront; rare)
+                    int dest[4];
+                    small_dests(pe[k], Wd, px0, npx, dest);
+                    if (!late[k]) dest[0] = dest[1] = dest[2] = dest[3] = -1;
+                    late_rk[k] = ranks_of(dest);
+                }
+            }
+            __syncthreads();
+            // ---- rows' totals; the packed counts become each wavefront's base inside its row ----
+            for (int r = tid; r < npx; r += kSBlock) start[r] = det_row_prefix(cnt, r);
+            __syncthreads();
+            MSDA_STAMP(2); MSDA_STAMP(3);
+            {
+                // a record's place in its row is (wavefront base + rank): below the segment's capacity it goes there, beyond it
+                // to the overflow list together with that place — the list is sorted by (row, place) below, so a row's overflow
+                // records are added in a fixed order too
+                auto place = [&](const PointEntry &e, int q, int2 rk, const int (&dest)[4]) {
+                    float tw[4];
+                    small_weights(e, tw);
+                    const int rks[4] = {rk.x & 0xffff, (int)((unsigned)rk.x >> 16), rk.y & 0xffff, (int)((unsigned)rk.y >> 16)};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (dest[t] >= 0) {
+                            const int pos = det_wave_base(cnt, dest[t], wave) + rks[t];
+                            if (pos < cap) { SRec r; r.w = tw[t]; r.q = q; rec[__mul24(dest[t], cap) + pos] = r; }
+                            else {
+                                const int o = atomicAdd(novf_p, 1);
+                                if (o < kOvfCap) { SOvf r; r.w = tw[t]; r.q = q; r.row = (dest[t] << 16) | pos; ovf[o] = r; }
+                            }
+                        }
+                };
+                int taps = 0;
+                for (int i0 = 0; i0 < n_list; i0 += kWave) {
+                    const int i = i0 + lane;
+                    if (i < n_list) {
+                        const PointEntry e = mylist[i];
+                        int dest[4];
+                        small_dests(e, Wd, px0, npx, dest);
+                        place(e, myq[i], myrk[i], dest);
+                    }
+                }
+                if (listed > kSmallListCap) {
+#pragma unroll
+                    for (int k = 0; k < PPT; ++k)
+                        if (late[k]) { int dest[4]; small_dests(pe[k], Wd, px0, npx, dest); place(pe[k], fdiv(tid + k * kSBlock, P, p_shift), late_rk[k], dest); }
+                }
+                for (int r = tid; r < npx; r += kSBlock) taps += start[r];
+                taps = wave_sum(taps);
+                if (lane == 0) atomicAdd(total_p, taps);
+                __syncthreads();
+                MSDA_STAMP(4);
+                const int novf = *novf_p;                                    // (uniform)
+                if (novf <= kOvfCap) {
+                    if (novf > 0) {                                          // rare, a handful of entries: rank sort by (row, place)
+                        SOvf mine; mine.w = 0.f; mine.q = 0; mine.row = 0;
+                        int rank = 0;
+                        if (tid < novf) { mine = ovf[tid]; for (int jj = 0; jj < novf; ++jj) rank += (int)(ovf[jj].row < mine.row); }
+                        __syncthreads();
+                        if (tid < novf) { mine.row = (int)((unsigned)mine.row >> 16); ovf[rank] = mine; }
+                        __syncthreads();
+                    }
+                    const int total = *total_p;
+                    if (total <= 4 * npx)       gather_rows<1, kAccNone, VT, GT, MSDA_GATHER_NR1>(go, gv_base, start, start, rec, nullptr, npx, row_stride, true, cap, ovf, novf);
+                    else if (total <= 8 * npx)  gather_rows<2, kAccNone, VT, GT, 2>(go, gv_base, start, start, rec, nullptr, npx, row_stride, true, cap, ovf, novf);
+                    else if (total <= 16 * npx) gather_rows<4, kAccNone, VT, GT, 2>(go, gv_base, start, start, rec, nullptr, npx, row_stride, true, cap, ovf, novf);
+                    else                        gather_rows<8, kAccNone, VT, GT, 2>(go, gv_base, start, start, rec, nullptr, npx, row_stride, true, cap, ovf, novf);
+                    MSDA_STAMP(5);
+                    return;
+                }
+            }
+        }
+        // ---- the overflow list filled up (taps piled on few pixels), or a level too fine for four slots per row: the general
+        // deterministic single-pass body from the top (the launch's LDS covers both layouts) ----
+        __syncthreads();
+        {
+            int pr2, l2, ti2, Wl2;
+            value_block_to_range(bid, W_plan, L, shapes, pr2, l2, ti2, Wl2, true);
+            bwd_value_body<kAccNone, kSinglePPT, VT, GT, false, true>(grad_out, shapes, level_start, loc, attn, S, M, L, Lq, P, p_shift, tp_cap,
+                                                                      grad_value, ti2, Wl2, l2, pr2, smem);
+        }
+        return;
+    }
 
     if (cap >= 4) {                                                          // slots per row (uniform); below four: the general body
         // one point's taps -> ranks from the histogram atomics -> records in their slots
