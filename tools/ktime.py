@@ -8,6 +8,8 @@ from bench import make_inputs, algorithmic_bytes, WORKLOADS
 from uvhand_amd import _native
 if any(k.startswith("MSDA_") for k in os.environ):          # A/B knobs live in the diagnostic build only
     _native.LIB_PATH = os.path.join(ROOT, "uvhand_amd", "libmsda_hip_tuning.so")
+if os.environ.get("KTIME_LIB"):                              # a library built with other compile-time constants (make OUT=... EXTRA=-D...)
+    _native.LIB_PATH = os.path.join(ROOT, os.environ["KTIME_LIB"])
 
 PYRAMIDS = {"p48": [(48, 48), (24, 24), (12, 12), (6, 6)],          # BASELINE configs[1]: Swin-L 4-scale from 384 x 384
             "p28": [(28, 28), (14, 14), (7, 7), (4, 4)],            # configs[3]: the per-rank training shape

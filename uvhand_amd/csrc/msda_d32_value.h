@@ -183,7 +183,10 @@ __device__ __forceinline__ GoBuf<VT> pair_rows(const VT *grad_out, long long ite
     return GoBuf<VT>{uniform_rsrc(grad_out + item_base * kD, bytes), (unsigned)(j * 4 * sizeof(VT)), M * kD * (int)sizeof(VT), Lq};
 }
 
-template <int SLOTS, int ACC, typename VT, typename GT, int NR1 = 2, typename GO = GoBuf<VT>>
+#ifndef MSDA_GATHER_CH1
+#define MSDA_GATHER_CH1 0        // gather_rows, fixed-capacity path, one lane group per row: records of a row per trip (0: 8 / rows in flight)
+#endif
+template <int SLOTS, int ACC, typename VT, typename GT, int NR1 = 2, typename GO = GoBuf<VT>, int CH1 = 0>
 __device__ __forceinline__ void gather_rows(const GO go, GT *__restrict__ gv_base,
                                             const int *cnt, const int *start, const SRec *rec, float *tile,
                                             int npx, int row_stride, bool first_pass, int cap = -1,
@@ -197,7 +200,7 @@ __device__ __forceinline__ void gather_rows(const GO go, GT *__restrict__ gv_bas
     // level: 2), and four rows x 2 keeps the loads real — cfg-2 decoder backward 13.5 -> 13.2 us in kbench.  Elsewhere 2:
     // the wider variant costs the other instantiations 7 VGPRs and cfg-4 decoder 2 us (tools/exp_nr.sh).
     constexpr int NR = SLOTS == 1 ? NR1 : 2;
-    constexpr int CH = 8 / NR;
+    constexpr int CH = (SLOTS == 1 && CH1 > 0) ? CH1 : 8 / NR;
     constexpr int RSTEP = kSWaves * DPW;                     // rows per workgroup trip
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int dsub = lane / (SLOTS * 8), slot = (lane >> 3) % SLOTS, j = lane & 7;
@@ -1008,7 +1011,7 @@ __device__ __forceinline__ void bwd_value_small_body(
         if (novf <= kOvfCap) {
             if (MSDA_DIAG(4)) return;
             const int taps = *total_p;                       // lanes per row from the mean records per row (no division: 2*taps/npx <= k)
-            if (taps <= 4 * npx)       gather_rows<1, kAccNone, VT, GT, MSDA_GATHER_NR1>(go, gv_base, cnt, start, rec, nullptr, npx, row_stride, true, cap, ovf, novf);
+            if (taps <= 4 * npx)       gather_rows<1, kAccNone, VT, GT, MSDA_GATHER_NR1, GoBuf<VT>, MSDA_GATHER_CH1>(go, gv_base, cnt, start, rec, nullptr, npx, row_stride, true, cap, ovf, novf);
             else if (taps <= 8 * npx)  gather_rows<2, kAccNone, VT, GT, 2>(go, gv_base, cnt, start, rec, nullptr, npx, row_stride, true, cap, ovf, novf);
             else if (taps <= 16 * npx) gather_rows<4, kAccNone, VT, GT, 2>(go, gv_base, cnt, start, rec, nullptr, npx, row_stride, true, cap, ovf, novf);
             else                   gather_rows<8, kAccNone, VT, GT, 2>(go, gv_base, cnt, start, rec, nullptr, npx, row_stride, true, cap, ovf, novf);
