@@ -1125,7 +1125,7 @@ static int launch_bwd_d32_t(const VT *grad_out, const VT *value, const int64_t *
             const dim3 fgrid((unsigned)(nB + (long long)N * M * lds_a.chunks));
             // (at least what the dense coarse-level body needs: two such workgroups still share a CU)
             const size_t flds = max(max(pl.lds, lds_a.lds), (size_t)dense_lds_bytes());
-            const bool dense = dense_on() && pl.W <= 2 && !no_dense;
+            const bool dense = dense_on() && pl.W <= MSDA_DENSE_MAX_W && !no_dense;
             const MaskIn masks = mask_in(table, N, S, M, L, Lq, P, pl.acc, pl.W, deterministic);
 #define MSDA_LAUNCH_FLD__(AC, NS_, DT, DN)                                                             \
             do { if (int rc = allow_lds(reinterpret_cast<const void *>(bwd_fused_lds_d32_kernel<AC, VT, false, GT, NS_, DT, DN>), flds)) return rc; \
@@ -1289,7 +1289,7 @@ static int launch_bwd_prologue_t(const VT *grad_out, const VT *value, const int6
         const dim3 lgrid((unsigned)(nB + (long long)N * M * lq.chunks));
         const size_t llds = max(max(pl.lds, lq.lds), (size_t)dense_lds_bytes());
 #define MSDA_LAUNCH_BPL(AC, NS_) do { if (deterministic) MSDA_LAUNCH_BPL_(AC, NS_, true); else MSDA_LAUNCH_BPL_(AC, NS_, false); } while (0)
-        const bool dense = dense_on() && pl.W <= 2 && !no_dense;
+        const bool dense = dense_on() && pl.W <= MSDA_DENSE_MAX_W && !no_dense;
         const MaskIn masks = mask_in(table, N, S, M, L, Lq, P, pl.acc, pl.W, deterministic);
 #define MSDA_LAUNCH_BPL_(AC, NS_, DT) do { if (dense) MSDA_LAUNCH_BPL__(AC, NS_, DT, true); else MSDA_LAUNCH_BPL__(AC, NS_, DT, false); } while (0)
 #define MSDA_LAUNCH_BPL__(AC, NS_, DT, DN)                                                             \
@@ -1446,7 +1446,7 @@ static int describe_plan_t(int N, int S, int M, int L, int Lq, int P, bool prolo
         // dense_px: a level of at most this many pixels (that the launch deals W workgroups) goes to the matrix cores
         // masks: role B finds its points through the per-point range masks a forward with a workspace leaves (msda_forward_ws_*)
         put(" bwd=fused_lds(acc=%s,W=%d,tp_cap=%d,roleB=%lld,roleA=%d,qw=%d,dense_px=%d%s%s%s)", acc, pl.W, pl.tp_cap, nB, N * M * la.chunks, la.qw,
-            !dense_on() || no_dense || pl.W > 2 ? 0 : pl.W == 2 ? kDenseMaxRows : kDensePassRows, det ? ",det" : "", prologue ? ",heads_reduce" : "",
+            !dense_on() || no_dense || pl.W > MSDA_DENSE_MAX_W ? 0 : pl.W >= 2 ? kDenseMaxRows : kDensePassRows, det ? ",det" : "", prologue ? ",heads_reduce" : "",
             (!det && pl.acc == kAccWide && plan_masks(N, S, M, L, Lq, P).use && plan_masks(N, S, M, L, Lq, P).W == pl.W) ? ",masks" : "");
     else if (pl.ppt == kSinglePPT && pl.acc != kAccTile) {
         const FusedPlan fp = plan_fused(items, LP, pick_split(items, LP), nB, pl.acc, prologue ? M : 0, det);

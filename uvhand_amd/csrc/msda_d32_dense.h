@@ -30,6 +30,9 @@
 
 namespace msda {
 
+#ifndef MSDA_DENSE_MAX_W
+#define MSDA_DENSE_MAX_W 2          // ranges per level up to which a coarse level goes dense (A/B: 8; dense_level below)
+#endif
 constexpr int kDenseMaxRows = 64;                  // pixels of a level served this way (four 16-row tiles)
 constexpr int kDenseChunk = 512;                   // queries per chunk (QC): one per thread
 constexpr int kDenseStride = kDenseChunk + 2;      // Wt row stride in words: the MFMA operand reads hit 32 different banks
@@ -46,7 +49,7 @@ __device__ __forceinline__ bool dense_level(long long H, long long Wd, long long
     // Wl <= 2: the level's work sits in one or two workgroups either way, and this body has a third of their instructions
     // (cfg-4 encoder backward 212 -> 196 us).  With more ranges per level (cfg-2 encoder: 6) one dense workgroup would take
     // over what six short ones share, and become the launch's longest: 57.4 -> 59.2 us.
-    return Wl <= 2 && H * Wd <= (Wl == 2 ? kDenseMaxRows : kDensePassRows) && H * Wd > 0 && level_fits(H, Wd, start, S) &&
+    return Wl <= MSDA_DENSE_MAX_W && H * Wd <= (Wl >= 2 ? kDenseMaxRows : kDensePassRows) && H * Wd > 0 && level_fits(H, Wd, start, S) &&
            lds_bytes >= dense_lds_bytes();
 }
 
