@@ -277,7 +277,10 @@ def measure_op(workload, dtype, device, stream, seed, locations="uniform", budge
         with torch.cuda.stream(stream):
             for name, fn in (("step", step), ("fwd", fwd), ("bwd", bwd)):
                 g = graph_of(fn, stream)
-                row[name + "_us"] = timed_us(g.replay if g is not None else fn, 10 if g is not None else 1, stream, budget_s)
+                call, per = (g.replay, 10) if g is not None else (fn, 1)
+                # the better of two timed batches: single batches of these side rows were seen 20 % off (a 14.4 / 17.4 us pair
+                # for one step on two runs of the same code) while the kernels' own times agreed to 1 %
+                row[name + "_us"] = min(timed_us(call, per, stream, budget_s / 2), timed_us(call, per, stream, budget_s / 2))
                 del g
             stream.synchronize()
     finally:

@@ -32,12 +32,6 @@ def native():
     return _native
 
 
-@pytest.fixture(scope="module")
-def oracle():
-    from oracle import msda_oracle
-    return msda_oracle
-
-
 def _case(name, seed=0, spread=1.3, shift=-0.15):
     N, Lq, shapes = BIG[name]
     g = torch.Generator().manual_seed(4321 + seed)
