@@ -308,6 +308,29 @@ def test_a_backward_workspace_with_the_forward_table_is_table_then_scratch(nativ
     assert lib.msda_backward_workspace_bytes(32, 1045, 8, 32, 4, 300, 4, 4) == 0
 
 
+def test_range_masks_are_planned_from_four_ranges_per_level_on(native):
+    """plan_masks (uvhand_amd/csrc/msda_d32.hip) is host logic: the forward of a large problem leaves per-point range masks exactly
+    where the backward's kept-taps pass cuts the levels into 4..8 ranges — never for single-pass plans, small problems, the
+    deterministic flag, or two / three ranges (measured: the forward's bytes cost more than those scans, profiles/r05_notes.md)."""
+    lib = native._lib
+    lib.msda_forward_workspace_bytes.restype = ctypes.c_ulonglong
+    lib.msda_forward_workspace_bytes.argtypes = [ctypes.c_int] * 7 + [ctypes.c_uint]
+    cases = [  # (N, shapes, Lq, W in the plan text, masks?)
+        (2, [(48, 48), (24, 24), (12, 12), (6, 6)], 3060, "W=6", True),           # cfg-2 encoder
+        (4, [(40, 40), (20, 20), (10, 10)], 2100, "W=4", True),
+        (4, [(32, 32), (16, 16), (8, 8), (4, 4)], 1600, "W=3", False),
+        (32, [(28, 28), (14, 14), (7, 7), (4, 4)], 1045, "W=2", False),           # cfg-4 encoder
+        (32, [(28, 28), (14, 14), (7, 7), (4, 4)], 300, "W=1", False),            # cfg-4 decoder: one pass
+    ]
+    for N, shapes, Lq, w, masks in cases:
+        S, L = sum(h * x for h, x in shapes), len(shapes)
+        plan = native.describe_plan(N, S, 8, 32, L, Lq, 4)
+        assert "bwd=fused_lds(" in plan and w + "," in plan, plan
+        assert ("masks" in plan) == masks, plan
+        assert lib.msda_forward_workspace_bytes(N, S, 8, 32, L, Lq, 4, 0) == (64 + N * 8 * L * Lq * 4 if masks else 0)
+        assert "masks" not in native.describe_plan(N, S, 8, 32, L, Lq, 4, deterministic=True)
+
+
 def test_int32_row_offsets_bound_the_d32_family():
     """Role B's gathers read a (batch, head) pair's grad_out rows through a buffer descriptor with 32-bit BYTE offsets
     q * M * 128: the tiled family only takes geometries with Lq * M * 128 B < 2^31 (others go to the generic kernels, whose
