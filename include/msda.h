@@ -308,6 +308,11 @@ int msda_linear_wgrad_masked_f32(const float *grad_out, const float *input, cons
 int msda_linear_wgrad_masked_bf16(const uint16_t *grad_out, const uint16_t *input, const uint8_t *row_mask, int M, int N, int K,
                                   float *grad_weight, float *grad_bias, void *workspace, msda_stream_t stream);
 int msda_zero_masked_rows_f32(float *x, const uint8_t *row_mask, long long rows, int cols, msda_stream_t stream);
+/* Up to four fp32 -> bf16 conversions (round to nearest even) in ONE launch: the weights and biases of value_proj / output_proj
+ * that torch.autocast(bfloat16) casts on every call (models/ops/modules/ms_deform_attn.py:96,139 under the reference's --amp) —
+ * four ~3 us kernels otherwise.  src / dst / n: host arrays of `count` (1..4) device pointers and element counts (each a
+ * multiple of 2; sources 8-byte, destinations 4-byte aligned). */
+int msda_cast_bf16_multi_f32(int count, const float *const *src, uint16_t *const *dst, const long long *n, msda_stream_t stream);
 
 /* Forward and input gradient of the same fp32 layers (nn.Linear semantics, models/ops/modules/ms_deform_attn.py:96,100,101,139
  * and what autograd derives for them):

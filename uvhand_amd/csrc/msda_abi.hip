@@ -691,6 +691,17 @@ int msda_add_layernorm_backward_f32(const float *grad_y, const float *x, const f
                                           static_cast<float *>(workspace), (hipStream_t)stream);
 }
 
+int msda_cast_bf16_multi_f32(int count, const float *const *src, uint16_t *const *dst, const long long *n, msda_stream_t stream)
+{
+    if (count < 1 || count > 4 || src == nullptr || dst == nullptr || n == nullptr)
+        return msda::set_error(MSDA_ERR_ARGUMENT, "msda_cast_bf16_multi_f32: 1..4 segments");
+    for (int k = 0; k < count; ++k)
+        if (n[k] < 0 || (n[k] & 1) || (n[k] > 0 && (src[k] == nullptr || dst[k] == nullptr)) || ((uintptr_t)src[k] & 7) || ((uintptr_t)dst[k] & 3))
+            return msda::set_error(MSDA_ERR_ARGUMENT, "msda_cast_bf16_multi_f32: element counts must be even, sources 8-byte and destinations 4-byte aligned");
+    msda::begin_call();
+    return msda::launch_cast_bf16_multi(count, src, dst, n, (hipStream_t)stream);
+}
+
 int msda_relu_dropout_backward_f32(float *grad, const float *act, float scale, long long n, msda_stream_t stream)
 {
     if (n < 0 || (n & 3) || (n > 0 && (grad == nullptr || act == nullptr)) || (((uintptr_t)grad | (uintptr_t)act) & 15))

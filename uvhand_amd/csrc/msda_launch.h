@@ -113,6 +113,8 @@ int launch_linear_wgrad(const float *dY, const float *X, const uint8_t *row_mask
 int launch_linear_wgrad_bf16(const uint16_t *dY, const uint16_t *X, const uint8_t *row_mask, int M, int N, int K, float *dW,
                              float *db, float *workspace, hipStream_t stream);
 int launch_zero_masked_rows(float *x, const uint8_t *mask, long long rows, int cols, hipStream_t stream);
+// up to four fp32 -> bf16 conversions in one launch (msda_linear.hip)
+int launch_cast_bf16_multi(int count, const float *const *src, uint16_t *const *dst, const long long *n, hipStream_t stream);
 
 // ---- forward and input gradient of the same layers (msda_gemm.hip); row_mask (may be null): rows written as zeros ----
 int launch_linear_forward(const float *x, const float *w, const float *bias, const uint8_t *row_mask, long long rows,

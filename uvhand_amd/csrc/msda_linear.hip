@@ -470,6 +470,38 @@ __global__ __launch_bounds__(256) void zero_masked_rows_kernel(float *__restrict
     for (int c = threadIdx.x & 63; c < cols / 4; c += 64) row[c] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// Up to four fp32 -> bf16 conversions in ONE launch (the weights and biases of value_proj / output_proj under autocast: four
+// 3 us kernels with a dependent boundary each became a visible share of a 110 us module step).  Round to nearest even, NaN
+// stays NaN (v_cvt_pk_bf16_f32).  Segment k: n[k] elements, a multiple of 2, 8-byte aligned source / 4-byte aligned destination.
+struct CastSegs { const float *src[4]; uint16_t *dst[4]; long long n[4]; };
+__global__ __launch_bounds__(256) void cast_bf16_multi_kernel(const CastSegs segs)
+{
+    const int k = (int)blockIdx.y;
+    const long long n2 = segs.n[k] / 2, stride = (long long)gridDim.x * 256;
+    const float2 *s2 = reinterpret_cast<const float2 *>(segs.src[k]);
+    unsigned *d2 = reinterpret_cast<unsigned *>(segs.dst[k]);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n2; i += stride) {
+        const float2 v = s2[i];
+        const __bf16 a = static_cast<__bf16>(v.x), b = static_cast<__bf16>(v.y);
+        d2[i] = (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+    }
+}
+
+int launch_cast_bf16_multi(int count, const float *const *src, uint16_t *const *dst, const long long *n, hipStream_t stream)
+{
+    CastSegs segs;
+    long long most = 0;
+    for (int k = 0; k < 4; ++k) {
+        segs.src[k] = k < count ? src[k] : nullptr; segs.dst[k] = k < count ? dst[k] : nullptr; segs.n[k] = k < count ? n[k] : 0;
+        if (segs.n[k] > most) most = segs.n[k];
+    }
+    if (most == 0) return MSDA_OK;
+    long long blocks = (most / 2 + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(cast_bf16_multi_kernel, dim3((unsigned)blocks, (unsigned)count), dim3(256), 0, stream, segs);
+    return check_launch("msda fp32 -> bf16 (multi)");
+}
+
 int launch_zero_masked_rows(float *x, const uint8_t *mask, long long rows, int cols, hipStream_t stream)
 {
     if (rows == 0) return MSDA_OK;

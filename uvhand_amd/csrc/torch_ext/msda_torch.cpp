@@ -586,8 +586,27 @@ public:
         at::Tensor rmask;
         if (mask.has_value() && mask->defined()) rmask = mask->reshape({-1}).contiguous();
         // value_proj on bf16 operands, then the padding mask
-        const at::Tensor xb = input_flatten.to(at::kBFloat16).contiguous(), wvb = w_val.to(at::kBFloat16);
-        at::Tensor value = at::linear(xb, wvb, b_val.to(at::kBFloat16));                // [N, S, C] bf16
+        const at::Tensor xb = input_flatten.to(at::kBFloat16).contiguous();
+        // the four parameter casts autocast would run one by one — in ONE launch into one slab (msda_cast_bf16_multi_f32)
+        at::Tensor wvb, bvb, wob, bob;
+        {
+            const int64_t cc = (int64_t)C * C;
+            const at::Tensor wv = w_val.contiguous(), bv = b_val.contiguous(), wo = w_out.contiguous(), bo = b_out.contiguous();
+            if (C % 2 == 0 && ((reinterpret_cast<uintptr_t>(wv.data_ptr()) | reinterpret_cast<uintptr_t>(bv.data_ptr()) |
+                                reinterpret_cast<uintptr_t>(wo.data_ptr()) | reinterpret_cast<uintptr_t>(bo.data_ptr())) & 7) == 0) {
+                const at::Tensor slab = at::empty({2 * cc + 2 * C}, xb.options());
+                wvb = slab.narrow(0, 0, cc).view({C, C}); wob = slab.narrow(0, cc, cc).view({C, C});
+                bvb = slab.narrow(0, 2 * cc, C); bob = slab.narrow(0, 2 * cc + C, C);
+                const float *src[4] = {wv.data_ptr<float>(), wo.data_ptr<float>(), bv.data_ptr<float>(), bo.data_ptr<float>()};
+                uint16_t *dst[4] = {reinterpret_cast<uint16_t *>(wvb.data_ptr<at::BFloat16>()), reinterpret_cast<uint16_t *>(wob.data_ptr<at::BFloat16>()),
+                                    reinterpret_cast<uint16_t *>(bvb.data_ptr<at::BFloat16>()), reinterpret_cast<uint16_t *>(bob.data_ptr<at::BFloat16>())};
+                const long long cnt[4] = {cc, cc, C, C};
+                raise_if(msda_cast_bf16_multi_f32(4, src, dst, cnt, stream), "msda_cast_bf16_multi");
+            } else {
+                wvb = w_val.to(at::kBFloat16); bvb = b_val.to(at::kBFloat16); wob = w_out.to(at::kBFloat16); bob = b_out.to(at::kBFloat16);
+            }
+        }
+        at::Tensor value = at::linear(xb, wvb, bvb);                                     // [N, S, C] bf16
         if (rmask.defined()) value = value.masked_fill(rmask.view({N, S, 1}), 0);
         // the query projection stays float32
         // (the caller may hand over the concatenation it keeps while the four parameters are unchanged: two launches less)
@@ -611,12 +630,11 @@ public:
                                                loc.data_ptr<float>(), attn.data_ptr<float>(), table.defined() ? table.data_ptr() : nullptr,
                                                table.defined() ? (unsigned long long)table.numel() : 0, stream),
                  "ms_deform_attn_forward_prologue (bf16 rows)");
-        const at::Tensor wob = w_out.to(at::kBFloat16);
         ctx->save_for_backward({q2, xb, rmask.defined() ? rmask : at::Tensor(), value, loc, attn, sampled, wm, wvb, wob, shapes, lsi, table});
         ctx->saved_data["dims"] = std::vector<int64_t>{N, S, M, D, L, Lq, P, C};
         ctx->saved_data["det"] = deterministic;
         ctx->saved_data["x_float"] = input_flatten.scalar_type() == at::kFloat;
-        return at::linear(sampled, wob, b_out.to(at::kBFloat16));                       // [N, Lq, C] bf16
+        return at::linear(sampled, wob, bob);                                           // [N, Lq, C] bf16
     }
 
     static torch::autograd::variable_list backward(torch::autograd::AutogradContext *ctx, torch::autograd::variable_list grads)
