@@ -262,3 +262,35 @@ def test_linear_forward_handles_nan_free_padding_and_empty():
         _native.linear_forward(torch.randn(8, 6, device="cuda"), torch.randn(8, 6, device="cuda"))     # 6 % 4 != 0
     with pytest.raises(RuntimeError):
         _native.linear_forward(x.double(), w.double())
+
+
+def test_several_weight_gradients_in_one_call_equal_the_single_calls():
+    """msda_linear_wgrad_multi_f32 (round 5: the module's three weight gradients, one second-stage launch for all): bitwise the
+    results of the single calls — sizes of the module at the decoder shape (600 x 256 -> 256, 600 x 256 -> 768, 6120 x 256 -> 256
+    with a row mask), plus a problem small enough to need no second stage."""
+    import ctypes
+    from uvhand_amd import _native
+    lib = _native.load()
+    g = torch.Generator().manual_seed(9)
+    probs = [(600, 256, 256, False), (600, 768, 256, False), (6120, 256, 256, True), (64, 8, 4, False)]
+    dys = [torch.randn(m, n, generator=g).cuda() for m, n, k, _ in probs]
+    xs = [torch.randn(m, k, generator=g).cuda() for m, n, k, _ in probs]
+    masks = [(torch.rand(m, generator=g) < 0.1).cuda() if mk else None for m, n, k, mk in probs]
+    single = [_native.linear_wgrad(dy, x, want_bias=True, row_mask=mk) for dy, x, mk in zip(dys, xs, masks)]
+    gws = [torch.empty(n, k, device="cuda") for m, n, k, _ in probs]
+    gbs = [torch.empty(n, device="cuda") for m, n, k, _ in probs]
+    lib.msda_linear_wgrad_workspace_bytes.restype = ctypes.c_ulonglong
+    wss = [torch.empty(max(16, int(lib.msda_linear_wgrad_workspace_bytes(m, n, k))), dtype=torch.uint8, device="cuda") for m, n, k, _ in probs]
+    VP, I = ctypes.c_void_p, ctypes.c_int
+    arr = lambda ts: (VP * 4)(*[t.data_ptr() if t is not None else None for t in ts])
+    ints = lambda vs: (I * 4)(*vs)
+    lib.msda_linear_wgrad_multi_f32.restype = I
+    lib.msda_linear_wgrad_multi_f32.argtypes = [I] + [VP] * 10
+    rc = lib.msda_linear_wgrad_multi_f32(4, arr(dys), arr(xs), arr(masks), ints([p[0] for p in probs]), ints([p[1] for p in probs]),
+                                         ints([p[2] for p in probs]), arr(gws), arr(gbs), arr(wss), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, _native._lib.msda_last_error()
+    torch.cuda.synchronize()
+    for (gw1, gb1), gw, gb, pr in zip(single, gws, gbs, probs):
+        assert torch.equal(gw, gw1) and torch.equal(gb, gb1), pr
+    assert lib.msda_linear_wgrad_multi_f32(5, arr(dys), arr(xs), arr(masks), ints([1] * 4), ints([4] * 4), ints([4] * 4), arr(gws), arr(gbs),
+                                           arr(wss), None) != 0                     # more than four problems: refused

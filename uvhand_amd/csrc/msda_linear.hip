@@ -459,6 +459,50 @@ __global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(const float *_
     }
 }
 
+// The same second stage for up to four weight gradients in ONE launch (blockIdx.y = problem): the module's backward has three
+// of them (output_proj, the merged offsets / attention projection, value_proj), and at decoder sizes three 3-us launches with a
+// dependent boundary each weigh as much as one of the first stages.  Same arithmetic, same order per problem: bitwise equal
+// to linear_wgrad_reduce_kernel.
+struct ReduceBatch { const float *part[4]; float *dW[4]; float *db[4]; long long nw[4], n[4]; int splits[4]; };
+__global__ __launch_bounds__(256) void linear_wgrad_reduce_batched_kernel(const ReduceBatch rb)
+{
+    __shared__ float4 sums[4][64];
+    const int p = (int)blockIdx.y;
+    const float *__restrict__ part = rb.part[p];
+    float *__restrict__ dW = rb.dW[p], *__restrict__ db = rb.db[p];
+    const long long nw = rb.nw[p], n = rb.n[p];
+    const int splits = rb.splits[p];
+    const int g = threadIdx.x >> 6, col = threadIdx.x & 63;
+    const long long e = ((long long)blockIdx.x * 64 + col) * 4;
+    const bool live = splits > 1 && e < n && !(e >= nw && db == nullptr);
+    const int per = (splits + 3) / 4, k0 = g * per, k1 = min(splits, k0 + per);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+        int k = k0;
+        for (; k + 4 <= k1; k += 4) {
+            const float4 v0 = *reinterpret_cast<const float4 *>(part + (long long)k * n + e);
+            const float4 v1 = *reinterpret_cast<const float4 *>(part + (long long)(k + 1) * n + e);
+            const float4 v2 = *reinterpret_cast<const float4 *>(part + (long long)(k + 2) * n + e);
+            const float4 v3 = *reinterpret_cast<const float4 *>(part + (long long)(k + 3) * n + e);
+            s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+            s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
+            s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
+            s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
+        }
+        for (; k < k1; ++k) {
+            const float4 v = *reinterpret_cast<const float4 *>(part + (long long)k * n + e);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    sums[g][col] = s;
+    __syncthreads();
+    if (g == 0 && live) {
+#pragma unroll
+        for (int w = 1; w < 4; ++w) { const float4 v = sums[w][col]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+        *reinterpret_cast<float4 *>(e < nw ? dW + e : db + (e - nw)) = s;
+    }
+}
+
 // x[r, :] = 0 for every row with mask[r] != 0; one wavefront per row, float4 per lane.  Unmasked rows
 // cost one byte of mask.
 __global__ __launch_bounds__(256) void zero_masked_rows_kernel(float *__restrict__ x, const uint8_t *__restrict__ mask,
@@ -544,10 +588,13 @@ size_t linear_wgrad_workspace_bytes(int M, int N, int K)
     return splits <= 1 ? 0 : sizeof(float) * (size_t)splits * ((size_t)N * K + (size_t)N);
 }
 
+// `defer` (may be null): instead of launching the second stage, describe it there (splits == 0: nothing to reduce)
+struct DeferredReduce { const float *part; float *dW, *db; long long nw, n; int splits; };
 template <typename OT>
 static int launch_linear_wgrad_t(const OT *dY, const OT *X, const uint8_t *row_mask, int M, int N, int K, float *dW, float *db,
-                                 float *workspace, hipStream_t stream)
+                                 float *workspace, hipStream_t stream, DeferredReduce *defer = nullptr)
 {
+    if (defer) defer->splits = 0;
     const WgradPlan pl = wgrad_plan(M, N, K, sizeof(OT) == 4);
     const int splits = pl.splits;
     int chunk = (M + splits - 1) / splits;
@@ -576,6 +623,7 @@ static int launch_linear_wgrad_t(const OT *dY, const OT *X, const uint8_t *row_m
     hipLaunchKernelGGL(partial, grid, dim3(kWgBlock), 0, stream, dY, X, row_mask, M, N, K, chunk, tiles, splits, slab, workspace,
                        db ? workspace + nw : nullptr);
     if (int rc = check_launch("msda linear wgrad (partial)")) return rc;
+    if (defer) { *defer = DeferredReduce{workspace, dW, db, nw, slab, splits}; return MSDA_OK; }
     hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((unsigned)((slab / 4 + 63) / 64)), dim3(256), 0, stream, workspace,
                        splits, nw, slab, dW, db);
     return check_launch("msda linear wgrad (reduce)");
@@ -586,6 +634,29 @@ int launch_linear_wgrad(const float *dY, const float *X, const uint8_t *row_mask
 {
     return launch_linear_wgrad_t<float>(dY, X, row_mask, M, N, K, dW, db, workspace, stream);
 }
+// `count` (1..4) fp32 weight gradients: their first stages one after the other (independent launches), then ONE second stage.
+int launch_linear_wgrad_multi(int count, const float *const *dY, const float *const *X, const uint8_t *const *row_mask, const int *M,
+                              const int *N, const int *K, float *const *dW, float *const *db, float *const *workspace, hipStream_t stream)
+{
+    ReduceBatch rb;
+    long long most = 0;
+    int pending = 0;
+    for (int p = 0; p < 4; ++p) { rb.part[p] = nullptr; rb.dW[p] = rb.db[p] = nullptr; rb.nw[p] = rb.n[p] = 0; rb.splits[p] = 0; }
+    for (int p = 0; p < count; ++p) {
+        DeferredReduce d;
+        if (int rc = launch_linear_wgrad_t<float>(dY[p], X[p], row_mask ? row_mask[p] : nullptr, M[p], N[p], K[p], dW[p], db ? db[p] : nullptr,
+                                                  workspace[p], stream, &d)) return rc;
+        if (d.splits > 1) {
+            rb.part[p] = d.part; rb.dW[p] = d.dW; rb.db[p] = d.db; rb.nw[p] = d.nw; rb.n[p] = d.n; rb.splits[p] = d.splits;
+            if (d.n > most) most = d.n;
+            ++pending;
+        }
+    }
+    if (pending == 0) return MSDA_OK;
+    hipLaunchKernelGGL(linear_wgrad_reduce_batched_kernel, dim3((unsigned)((most / 4 + 63) / 64), (unsigned)count), dim3(256), 0, stream, rb);
+    return check_launch("msda linear wgrad (batched reduce)");
+}
+
 int launch_linear_wgrad_bf16(const uint16_t *dY, const uint16_t *X, const uint8_t *row_mask, int M, int N, int K, float *dW,
                              float *db, float *workspace, hipStream_t stream)
 {

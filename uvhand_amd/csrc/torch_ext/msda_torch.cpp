@@ -342,6 +342,33 @@ inline at::Tensor wgrad_into(const at::Tensor &dY2, const at::Tensor &X2, const 
     return gw;
 }
 
+// Several weight gradients of one backward in ONE library call (msda_linear_wgrad_multi_f32: first stages back to back, one second
+// stage for all); a job the kernel's preconditions exclude takes wgrad_into's fallback on its own.
+struct WgradJob { at::Tensor dY, X; const at::Tensor *mask; at::Tensor *gw, *gb; };
+inline void wgrad_jobs(std::vector<WgradJob> &jobs, msda_stream_t stream)
+{
+    const float *dy[4], *x[4]; const uint8_t *mk[4]; int M[4], N[4], K[4]; float *gw[4], *gb[4]; void *ws[4];
+    std::vector<at::Tensor> keep;
+    int n = 0;
+    for (auto &j : jobs) {
+        const int m = (int)j.dY.size(0), nn = (int)j.dY.size(1), k = (int)j.X.size(1);
+        if (n == 4 || nn % 4 != 0 || k % 4 != 0 || m <= 0 || !j.dY.is_contiguous() || !j.X.is_contiguous() || !aligned16(j.dY) || !aligned16(j.X)) {
+            *j.gw = wgrad_into(j.dY, j.X, j.mask, *j.gb, true, stream);
+            continue;
+        }
+        *j.gw = at::empty({nn, k}, j.dY.options());
+        *j.gb = at::empty({nn}, j.dY.options());
+        const unsigned long long nbytes = msda_linear_wgrad_workspace_bytes(m, nn, k);
+        ws[n] = nullptr;
+        if (nbytes) { keep.push_back(at::empty({(int64_t)nbytes}, j.dY.options().dtype(at::kByte))); ws[n] = keep.back().data_ptr(); }
+        dy[n] = j.dY.data_ptr<float>(); x[n] = j.X.data_ptr<float>();
+        mk[n] = j.mask ? reinterpret_cast<const uint8_t *>(j.mask->data_ptr<bool>()) : nullptr;
+        M[n] = m; N[n] = nn; K[n] = k; gw[n] = j.gw->data_ptr<float>(); gb[n] = j.gb->data_ptr<float>();
+        ++n;
+    }
+    if (n > 0) raise_if(msda_linear_wgrad_multi_f32(n, dy, x, mk, M, N, K, gw, gb, ws, stream), "msda_linear_wgrad_multi");
+}
+
 // nn.Linear forward / input gradient of the module's projections.  While the problem is small the library's own fp32-MFMA
 // kernels (msda_linear_forward_f32 / msda_linear_dgrad_f32: one plain launch, ~7 us on the host against ~18-27 us for a GEMM
 // through torch, and as fast on the GPU up to ~5000 rows at 256 features — tools/gemm_time.py); the vendor BLAS beyond, where
@@ -503,7 +530,8 @@ public:
         at::Tensor gb_out, gb_m, gb_val;
         const at::Tensor g_sampled = linear_rows_dgrad(go2, w_out, nullptr, stream);           // [N*Lq, C]
         at::Tensor gw_out, gw_m, gw_val;
-        if (need_out) gw_out = wgrad_into(go2, sampled.view({(int64_t)N * Lq, C}), nullptr, gb_out, true, stream);
+        std::vector<WgradJob> jobs;                          // the (up to three) weight gradients: one call at the end
+        if (need_out) jobs.push_back(WgradJob{go2, sampled.view({(int64_t)N * Lq, C}), nullptr, &gw_out, &gb_out});
         // the sampling kernels: gradients of value, of the raw offsets / logits (one tensor, the projection's layout) and of
         // the reference points
         const bool det = ctx->saved_data["det"].toBool() || at::globalContext().deterministicAlgorithms();
@@ -525,12 +553,13 @@ public:
         // merged projection
         at::Tensor g_query;
         if (ctx->needs_input_grad(0)) g_query = linear_rows_dgrad(gproj, wm, nullptr, stream).view({N, Lq, C});
-        if (need_m) gw_m = wgrad_into(gproj, q2.view({(int64_t)N * Lq, C}), nullptr, gb_m, true, stream);
+        if (need_m) jobs.push_back(WgradJob{gproj, q2.view({(int64_t)N * Lq, C}), nullptr, &gw_m, &gb_m});
         // value_proj: masked rows of grad_value count as zero (weight gradient) and get a zero input gradient
         const at::Tensor gv2 = gv.view({(int64_t)N * S, C});
         at::Tensor g_input;
         if (ctx->needs_input_grad(2)) g_input = linear_rows_dgrad(gv2, w_val, maskp, stream).view({N, S, C});
-        if (need_val) gw_val = wgrad_into(gv2, x2.view({(int64_t)N * S, C}), maskp, gb_val, true, stream);
+        if (need_val) jobs.push_back(WgradJob{gv2, x2.view({(int64_t)N * S, C}), maskp, &gw_val, &gb_val});
+        wgrad_jobs(jobs, stream);
         const at::Tensor none;
         return {g_query, gref, g_input, none, none, none,
                 need_m ? gw_m.narrow(0, 0, 2 * mlp) : none, need_m ? gb_m.narrow(0, 0, 2 * mlp) : none,
