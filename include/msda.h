@@ -305,16 +305,23 @@ int msda_linear_wgrad_masked_f32(const float *grad_out, const float *input, cons
 /* bf16 operands (what the layer sees under torch.autocast(bfloat16)), fp32 products, accumulation and results: the weight
  * gradient reaches the fp32 master parameter without a rounding to bf16 in between, at half the operand bytes.  Same
  * workspace size as the f32 entry point; grad_out / input 8-byte aligned. */
-/* `count` (1..4) fp32 weight gradients in one call: the first stages one after the other, then ONE fixed-order second stage for
+int msda_linear_wgrad_masked_bf16(const uint16_t *grad_out, const uint16_t *input, const uint8_t *row_mask, int M, int N, int K,
+                                  float *grad_weight, float *grad_bias, void *workspace, msda_stream_t stream);
+/* `count` (1..4) weight gradients in one call: the first stages one after the other, then ONE fixed-order second stage for
  * all of them (the module's backward has three: output_proj, the merged projection, value_proj — at decoder sizes the three
  * separate second stages cost as much as a first stage).  Host arrays of `count` entries; row_mask / grad_bias may be NULL
  * (array) or hold NULL entries; workspace[p] as for msda_linear_wgrad_f32 with that problem's sizes.  Results are bitwise
- * those of `count` msda_linear_wgrad_masked_f32 calls. */
+ * those of `count` msda_linear_wgrad_masked_{f32,bf16} calls.
+ *   msda_linear_wgrad_multi      operands fp32 or bf16 PER PROBLEM: operands_bf16[p] != 0 -> grad_out[p] / input[p] are bf16
+ *                                (uint16_t), as under autocast, where the merged projection stays fp32 and the other two are bf16;
+ *                                operands_bf16 == NULL: all fp32;
+ *   msda_linear_wgrad_multi_f32  the all-fp32 spelling. */
+int msda_linear_wgrad_multi(int count, const void *const *grad_out, const void *const *input, const int *operands_bf16,
+                            const uint8_t *const *row_mask, const int *M, const int *N, const int *K, float *const *grad_weight,
+                            float *const *grad_bias, void *const *workspace, msda_stream_t stream);
 int msda_linear_wgrad_multi_f32(int count, const float *const *grad_out, const float *const *input, const uint8_t *const *row_mask,
                                 const int *M, const int *N, const int *K, float *const *grad_weight, float *const *grad_bias,
                                 void *const *workspace, msda_stream_t stream);
-int msda_linear_wgrad_masked_bf16(const uint16_t *grad_out, const uint16_t *input, const uint8_t *row_mask, int M, int N, int K,
-                                  float *grad_weight, float *grad_bias, void *workspace, msda_stream_t stream);
 int msda_zero_masked_rows_f32(float *x, const uint8_t *row_mask, long long rows, int cols, msda_stream_t stream);
 /* Up to four fp32 -> bf16 conversions (round to nearest even) in ONE launch: the weights and biases of value_proj / output_proj
  * that torch.autocast(bfloat16) casts on every call (models/ops/modules/ms_deform_attn.py:96,139 under the reference's --amp) —

@@ -294,3 +294,33 @@ def test_several_weight_gradients_in_one_call_equal_the_single_calls():
         assert torch.equal(gw, gw1) and torch.equal(gb, gb1), pr
     assert lib.msda_linear_wgrad_multi_f32(5, arr(dys), arr(xs), arr(masks), ints([1] * 4), ints([4] * 4), ints([4] * 4), arr(gws), arr(gbs),
                                            arr(wss), None) != 0                     # more than four problems: refused
+
+
+def test_mixed_operand_weight_gradients_in_one_call_equal_the_single_calls():
+    """msda_linear_wgrad_multi with operand types per problem (the module node under autocast: output_proj and value_proj on bf16
+    operands, the merged projection on fp32): bitwise the results of msda_linear_wgrad_masked_bf16 / _f32 called one by one."""
+    import ctypes
+    from uvhand_amd import _native
+    lib = _native.load()
+    g = torch.Generator().manual_seed(10)
+    probs = [(600, 256, 256, True), (600, 384, 256, False), (6120, 256, 256, True)]              # (M, N, K, bf16 operands)
+    cast = lambda t, h: t.to(torch.bfloat16) if h else t
+    dys = [cast(torch.randn(m, n, generator=g), h).cuda() for m, n, k, h in probs]
+    xs = [cast(torch.randn(m, k, generator=g), h).cuda() for m, n, k, h in probs]
+    single = [_native.linear_wgrad(dy, x, want_bias=True) for dy, x in zip(dys, xs)]
+    gws = [torch.empty(n, k, device="cuda") for m, n, k, _ in probs]
+    gbs = [torch.empty(n, device="cuda") for m, n, k, _ in probs]
+    lib.msda_linear_wgrad_workspace_bytes.restype = ctypes.c_ulonglong
+    wss = [torch.empty(max(16, int(lib.msda_linear_wgrad_workspace_bytes(m, n, k))), dtype=torch.uint8, device="cuda") for m, n, k, _ in probs]
+    VP, I = ctypes.c_void_p, ctypes.c_int
+    arr = lambda ts: (VP * 4)(*[t.data_ptr() for t in ts])
+    ints = lambda vs: (I * 4)(*vs)
+    lib.msda_linear_wgrad_multi.restype = I
+    lib.msda_linear_wgrad_multi.argtypes = [I] + [VP] * 11
+    rc = lib.msda_linear_wgrad_multi(3, arr(dys), arr(xs), ints([int(p[3]) for p in probs]), None, ints([p[0] for p in probs]),
+                                     ints([p[1] for p in probs]), ints([p[2] for p in probs]), arr(gws), arr(gbs), arr(wss),
+                                     torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, _native._lib.msda_last_error()
+    torch.cuda.synchronize()
+    for (gw1, gb1), gw, gb, pr in zip(single, gws, gbs, probs):
+        assert torch.equal(gw, gw1) and torch.equal(gb, gb1), pr

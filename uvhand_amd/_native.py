@@ -30,7 +30,7 @@ _SYMBOLS = (
     "msda_add_layernorm_workspace_bytes", "msda_add_layernorm_forward_f32", "msda_add_layernorm_backward_f32",
     "msda_relu_dropout_backward_f32", "msda_cast_bf16_multi_f32",
     "msda_flatten_levels_f32", "msda_unflatten_levels_f32", "msda_unflatten_workspace_bytes",
-    "msda_linear_wgrad_f32", "msda_linear_wgrad_masked_f32", "msda_linear_wgrad_masked_bf16", "msda_linear_wgrad_multi_f32", "msda_linear_wgrad_workspace_bytes",
+    "msda_linear_wgrad_f32", "msda_linear_wgrad_masked_f32", "msda_linear_wgrad_masked_bf16", "msda_linear_wgrad_multi_f32", "msda_linear_wgrad_multi", "msda_linear_wgrad_workspace_bytes",
     "msda_zero_masked_rows_f32", "msda_linear_forward_f32", "msda_linear_dgrad_f32",
     "msda_prologue_supported", "msda_forward_prologue_f32", "msda_backward_prologue_f32",
     "msda_last_error", "msda_version", "msda_path_for", "msda_force_path", "msda_describe_plan",

@@ -578,26 +578,37 @@ int msda_linear_wgrad_masked_f32(const float *grad_out, const float *input, cons
                                      static_cast<float *>(workspace), (hipStream_t)stream);
 }
 
+int msda_linear_wgrad_multi(int count, const void *const *grad_out, const void *const *input, const int *operands_bf16,
+                            const uint8_t *const *row_mask, const int *M, const int *N, const int *K, float *const *grad_weight,
+                            float *const *grad_bias, void *const *workspace, msda_stream_t stream)
+{
+    if (count < 1 || count > 4 || !grad_out || !input || !M || !N || !K || !grad_weight || !workspace)
+        return msda::set_error(MSDA_ERR_ARGUMENT, "msda_linear_wgrad_multi: 1..4 problems, non-null arrays");
+    float *ws[4];
+    for (int p = 0; p < count; ++p) {
+        if (M[p] <= 0 || N[p] <= 0 || K[p] <= 0 || (N[p] & 3) || (K[p] & 3))
+            return msda::set_error(MSDA_ERR_ARGUMENT, "msda_linear_wgrad_multi: need M, N, K > 0 and N, K multiples of 4");
+        if (grad_weight[p] == nullptr || grad_out[p] == nullptr || input[p] == nullptr)
+            return msda::set_error(MSDA_ERR_ARGUMENT, "msda_linear_wgrad_multi: null device pointer");
+        // (bf16 operands: 8-byte alignment is what msda_linear_wgrad_masked_bf16 asks for)
+        const size_t al = operands_bf16 && operands_bf16[p] ? 8 : 16;
+        if (!msda::aligned_to(grad_out[p], al) || !msda::aligned_to(input[p], al) || !msda::aligned_to(workspace[p], 16))
+            return msda::set_error(MSDA_ERR_ARGUMENT, "msda_linear_wgrad_multi: grad_out, input (16 bytes; bf16: 8) and workspace (16) alignment");
+        if (msda::linear_wgrad_workspace_bytes(M[p], N[p], K[p]) > 0 && workspace[p] == nullptr)
+            return msda::set_error(MSDA_ERR_ARGUMENT, "msda_linear_wgrad_multi: workspace required");
+        ws[p] = static_cast<float *>(workspace[p]);
+    }
+    msda::begin_call();
+    return msda::launch_linear_wgrad_multi(count, grad_out, input, operands_bf16, row_mask, M, N, K, grad_weight, grad_bias, ws,
+                                           (hipStream_t)stream);
+}
+
 int msda_linear_wgrad_multi_f32(int count, const float *const *grad_out, const float *const *input, const uint8_t *const *row_mask,
                                 const int *M, const int *N, const int *K, float *const *grad_weight, float *const *grad_bias,
                                 void *const *workspace, msda_stream_t stream)
 {
-    if (count < 1 || count > 4 || !grad_out || !input || !M || !N || !K || !grad_weight || !workspace)
-        return msda::set_error(MSDA_ERR_ARGUMENT, "msda_linear_wgrad_multi_f32: 1..4 problems, non-null arrays");
-    float *ws[4];
-    for (int p = 0; p < count; ++p) {
-        if (M[p] <= 0 || N[p] <= 0 || K[p] <= 0 || (N[p] & 3) || (K[p] & 3))
-            return msda::set_error(MSDA_ERR_ARGUMENT, "msda_linear_wgrad_multi_f32: need M, N, K > 0 and N, K multiples of 4");
-        if (grad_weight[p] == nullptr || grad_out[p] == nullptr || input[p] == nullptr)
-            return msda::set_error(MSDA_ERR_ARGUMENT, "msda_linear_wgrad_multi_f32: null device pointer");
-        if (!msda::aligned_to(grad_out[p], 16) || !msda::aligned_to(input[p], 16) || !msda::aligned_to(workspace[p], 16))
-            return msda::set_error(MSDA_ERR_ARGUMENT, "msda_linear_wgrad_multi_f32: grad_out, input and workspace must be 16-byte aligned");
-        if (msda::linear_wgrad_workspace_bytes(M[p], N[p], K[p]) > 0 && workspace[p] == nullptr)
-            return msda::set_error(MSDA_ERR_ARGUMENT, "msda_linear_wgrad_multi_f32: workspace required");
-        ws[p] = static_cast<float *>(workspace[p]);
-    }
-    msda::begin_call();
-    return msda::launch_linear_wgrad_multi(count, grad_out, input, row_mask, M, N, K, grad_weight, grad_bias, ws, (hipStream_t)stream);
+    return msda_linear_wgrad_multi(count, reinterpret_cast<const void *const *>(grad_out), reinterpret_cast<const void *const *>(input),
+                                   nullptr, row_mask, M, N, K, grad_weight, grad_bias, workspace, stream);
 }
 
 int msda_linear_wgrad_masked_bf16(const uint16_t *grad_out, const uint16_t *input, const uint8_t *row_mask, int M, int N, int K,

@@ -110,8 +110,9 @@ size_t linear_wgrad_workspace_bytes(int M, int N, int K);
 int launch_linear_wgrad(const float *dY, const float *X, const uint8_t *row_mask, int M, int N, int K, float *dW, float *db,
                         float *workspace, hipStream_t stream);
 // several fp32 weight gradients: first stages back to back, ONE second stage for all (count <= 4; per-problem arrays)
-int launch_linear_wgrad_multi(int count, const float *const *dY, const float *const *X, const uint8_t *const *row_mask, const int *M,
-                              const int *N, const int *K, float *const *dW, float *const *db, float *const *workspace, hipStream_t stream);
+int launch_linear_wgrad_multi(int count, const void *const *dY, const void *const *X, const int *bf16, const uint8_t *const *row_mask,
+                              const int *M, const int *N, const int *K, float *const *dW, float *const *db, float *const *workspace,
+                              hipStream_t stream);
 // bf16 operands (uint16_t bits), fp32 products / accumulation / results
 int launch_linear_wgrad_bf16(const uint16_t *dY, const uint16_t *X, const uint8_t *row_mask, int M, int N, int K, float *dW,
                              float *db, float *workspace, hipStream_t stream);

@@ -634,9 +634,11 @@ int launch_linear_wgrad(const float *dY, const float *X, const uint8_t *row_mask
 {
     return launch_linear_wgrad_t<float>(dY, X, row_mask, M, N, K, dW, db, workspace, stream);
 }
-// `count` (1..4) fp32 weight gradients: their first stages one after the other (independent launches), then ONE second stage.
-int launch_linear_wgrad_multi(int count, const float *const *dY, const float *const *X, const uint8_t *const *row_mask, const int *M,
-                              const int *N, const int *K, float *const *dW, float *const *db, float *const *workspace, hipStream_t stream)
+// `count` (1..4) weight gradients, operands fp32 or bf16 per problem (bf16[p] != 0): their first stages one after the other
+// (independent launches), then ONE second stage.
+int launch_linear_wgrad_multi(int count, const void *const *dY, const void *const *X, const int *bf16, const uint8_t *const *row_mask,
+                              const int *M, const int *N, const int *K, float *const *dW, float *const *db, float *const *workspace,
+                              hipStream_t stream)
 {
     ReduceBatch rb;
     long long most = 0;
@@ -644,8 +646,14 @@ int launch_linear_wgrad_multi(int count, const float *const *dY, const float *co
     for (int p = 0; p < 4; ++p) { rb.part[p] = nullptr; rb.dW[p] = rb.db[p] = nullptr; rb.nw[p] = rb.n[p] = 0; rb.splits[p] = 0; }
     for (int p = 0; p < count; ++p) {
         DeferredReduce d;
-        if (int rc = launch_linear_wgrad_t<float>(dY[p], X[p], row_mask ? row_mask[p] : nullptr, M[p], N[p], K[p], dW[p], db ? db[p] : nullptr,
-                                                  workspace[p], stream, &d)) return rc;
+        const uint8_t *mask = row_mask ? row_mask[p] : nullptr;
+        float *bias = db ? db[p] : nullptr;
+        const int rc = bf16 && bf16[p]
+            ? launch_linear_wgrad_t<uint16_t>(static_cast<const uint16_t *>(dY[p]), static_cast<const uint16_t *>(X[p]), mask, M[p], N[p],
+                                              K[p], dW[p], bias, workspace[p], stream, &d)
+            : launch_linear_wgrad_t<float>(static_cast<const float *>(dY[p]), static_cast<const float *>(X[p]), mask, M[p], N[p], K[p],
+                                           dW[p], bias, workspace[p], stream, &d);
+        if (rc) return rc;
         if (d.splits > 1) {
             rb.part[p] = d.part; rb.dW[p] = d.dW; rb.db[p] = d.db; rb.nw[p] = d.nw; rb.n[p] = d.n; rb.splits[p] = d.splits;
             if (d.n > most) most = d.n;

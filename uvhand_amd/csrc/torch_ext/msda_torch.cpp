@@ -342,31 +342,36 @@ inline at::Tensor wgrad_into(const at::Tensor &dY2, const at::Tensor &X2, const 
     return gw;
 }
 
-// Several weight gradients of one backward in ONE library call (msda_linear_wgrad_multi_f32: first stages back to back, one second
-// stage for all); a job the kernel's preconditions exclude takes wgrad_into's fallback on its own.
+// Several weight gradients of one backward in ONE library call (msda_linear_wgrad_multi: first stages back to back, one second
+// stage for all; operands fp32 or bf16 per job, results fp32); a job the kernel's preconditions exclude takes wgrad_into's
+// fallback on its own (fp32 jobs; the bf16 node's operands are its own dense tensors).
 struct WgradJob { at::Tensor dY, X; const at::Tensor *mask; at::Tensor *gw, *gb; };
 inline void wgrad_jobs(std::vector<WgradJob> &jobs, msda_stream_t stream)
 {
-    const float *dy[4], *x[4]; const uint8_t *mk[4]; int M[4], N[4], K[4]; float *gw[4], *gb[4]; void *ws[4];
+    const void *dy[4], *x[4]; const uint8_t *mk[4]; int bf[4], M[4], N[4], K[4]; float *gw[4], *gb[4]; void *ws[4];
     std::vector<at::Tensor> keep;
     int n = 0;
     for (auto &j : jobs) {
         const int m = (int)j.dY.size(0), nn = (int)j.dY.size(1), k = (int)j.X.size(1);
-        if (n == 4 || nn % 4 != 0 || k % 4 != 0 || m <= 0 || !j.dY.is_contiguous() || !j.X.is_contiguous() || !aligned16(j.dY) || !aligned16(j.X)) {
+        const bool half = j.dY.scalar_type() == at::kBFloat16;
+        if (!half && (n == 4 || nn % 4 != 0 || k % 4 != 0 || m <= 0 || !j.dY.is_contiguous() || !j.X.is_contiguous() || !aligned16(j.dY) ||
+                      !aligned16(j.X))) {
             *j.gw = wgrad_into(j.dY, j.X, j.mask, *j.gb, true, stream);
             continue;
         }
-        *j.gw = at::empty({nn, k}, j.dY.options());
-        *j.gb = at::empty({nn}, j.dY.options());
+        TORCH_CHECK(n < 4, "wgrad_jobs: at most four weight gradients per call");
+        const auto f32 = j.dY.options().dtype(at::kFloat);
+        *j.gw = at::empty({nn, k}, f32);
+        *j.gb = at::empty({nn}, f32);
         const unsigned long long nbytes = msda_linear_wgrad_workspace_bytes(m, nn, k);
         ws[n] = nullptr;
         if (nbytes) { keep.push_back(at::empty({(int64_t)nbytes}, j.dY.options().dtype(at::kByte))); ws[n] = keep.back().data_ptr(); }
-        dy[n] = j.dY.data_ptr<float>(); x[n] = j.X.data_ptr<float>();
+        dy[n] = j.dY.data_ptr(); x[n] = j.X.data_ptr(); bf[n] = half ? 1 : 0;
         mk[n] = j.mask ? reinterpret_cast<const uint8_t *>(j.mask->data_ptr<bool>()) : nullptr;
         M[n] = m; N[n] = nn; K[n] = k; gw[n] = j.gw->data_ptr<float>(); gb[n] = j.gb->data_ptr<float>();
         ++n;
     }
-    if (n > 0) raise_if(msda_linear_wgrad_multi_f32(n, dy, x, mk, M, N, K, gw, gb, ws, stream), "msda_linear_wgrad_multi");
+    if (n > 0) raise_if(msda_linear_wgrad_multi(n, dy, x, bf, mk, M, N, K, gw, gb, ws, stream), "msda_linear_wgrad_multi");
 }
 
 // nn.Linear forward / input gradient of the module's projections.  While the problem is small the library's own fp32-MFMA
@@ -568,23 +573,6 @@ public:
     }
 };
 
-// Weight / bias gradient from bf16 operands on the bf16 MFMA (fp32 result for the fp32 master parameter).
-inline at::Tensor wgrad_into_bf16(const at::Tensor &dY2, const at::Tensor &X2, at::Tensor &gb, msda_stream_t stream)
-{
-    const int M = (int)dY2.size(0), N = (int)dY2.size(1), K = (int)X2.size(1);
-    const auto f32 = dY2.options().dtype(at::kFloat);
-    auto gw = at::empty({N, K}, f32);
-    gb = at::empty({N}, f32);
-    const unsigned long long nbytes = msda_linear_wgrad_workspace_bytes(M, N, K);
-    at::Tensor ws;
-    if (nbytes) ws = at::empty({(int64_t)nbytes}, dY2.options().dtype(at::kByte));
-    raise_if(msda_linear_wgrad_masked_bf16(reinterpret_cast<const uint16_t *>(dY2.data_ptr<at::BFloat16>()),
-                                           reinterpret_cast<const uint16_t *>(X2.data_ptr<at::BFloat16>()), nullptr, M, N, K,
-                                           gw.data_ptr<float>(), gb.data_ptr<float>(), nbytes ? ws.data_ptr() : nullptr, stream),
-             "msda_linear_wgrad (bf16 operands)");
-    return gw;
-}
-
 // The module under torch.autocast(bfloat16) with bf16 rows (MSDeformAttn.bf16_storage) as ONE node — the same steps, in the same
 // order, as the Python composition takes there (modules/ms_deform_attn.py; functions/linear_func.py: _BracketLinearAmpFn):
 // value_proj and output_proj on bf16 operands (what autocast runs), the query projection, offsets, logits, reference points
@@ -685,7 +673,9 @@ public:
         at::Tensor gb_out, gb_m, gb_val;
         const at::Tensor g_sampled = at::mm(go2, wob);                                  // [N*Lq, C] bf16
         at::Tensor gw_out, gw_m, gw_val;
-        if (need_out) gw_out = wgrad_into_bf16(go2, sampled.view({(int64_t)N * Lq, C}), gb_out, stream);
+        // (the three weight gradients are queued and run at the end: ONE second stage for all of them, wgrad_jobs)
+        std::vector<WgradJob> jobs;
+        if (need_out) jobs.push_back({go2, sampled.view({(int64_t)N * Lq, C}), nullptr, &gw_out, &gb_out});
         // the sampling kernels: bf16 rows in, float32 gradients out
         const bool det = ctx->saved_data["det"].toBool() || at::globalContext().deterministicAlgorithms();
         const unsigned flags = MSDA_FLAG_PROLOGUE | (det ? MSDA_FLAG_DETERMINISTIC : 0u);
@@ -708,7 +698,7 @@ public:
         // merged projection (float32)
         at::Tensor g_query;
         if (ctx->needs_input_grad(0)) g_query = linear_rows_dgrad(gproj, wm, nullptr, stream).view({N, Lq, C});
-        if (need_m) gw_m = wgrad_into(gproj, q2.view({(int64_t)N * Lq, C}), nullptr, gb_m, true, stream);
+        if (need_m) jobs.push_back({gproj, q2.view({(int64_t)N * Lq, C}), nullptr, &gw_m, &gb_m});
         // value_proj: grad_value goes back to the rows' type, the mask's rows to zero, then the two GEMMs on bf16 operands
         at::Tensor gvb = gv.to(at::kBFloat16);
         if (rmask.defined()) gvb = gvb.masked_fill(rmask.view({N, S, 1}), 0);
@@ -718,7 +708,8 @@ public:
             g_input = at::mm(gvb2, wvb).view({N, S, C});
             if (ctx->saved_data["x_float"].toBool()) g_input = g_input.to(at::kFloat);
         }
-        if (need_val) gw_val = wgrad_into_bf16(gvb2, xb.view({(int64_t)N * S, C}), gb_val, stream);
+        if (need_val) jobs.push_back({gvb2, xb.view({(int64_t)N * S, C}), nullptr, &gw_val, &gb_val});
+        wgrad_jobs(jobs, stream);
         const at::Tensor none;
         return {g_query, gref, g_input, none, none, none,
                 need_m ? gw_m.narrow(0, 0, 2 * mlp) : none, need_m ? gb_m.narrow(0, 0, 2 * mlp) : none,
