@@ -35,3 +35,36 @@ def test_add_layer_norm_falls_back_on_cpu():
     x, r = torch.randn(5, 12), torch.randn(5, 12)
     assert torch.equal(add_layer_norm(x, r, norm), norm(x + r))
     assert torch.equal(add_layer_norm(x, None, norm), norm(x))
+
+
+def test_decoder_layer_computes_the_attention_matrix_only_for_a_listener():
+    """The reference's decoder layer passes the head-averaged self-attention matrix through a parameter-free `attn_matrix` module
+    (a tap for hooks, models/arctic_transformer.py:374-378).  Here the matrix is computed when a hook on that module listens — or
+    always with `always_attention_matrix` — and skipped otherwise (nn.MultiheadAttention's fused path); in eval mode the layer's
+    output is the same either way."""
+    from uvhand_amd.modules import DeformableTransformerDecoderLayer
+
+    class NoSampling(nn.Module):                   # the sampling module needs the GPU library: not this test's subject
+        def forward(self, query, *args):
+            return query * 0.5
+
+    torch.manual_seed(0)
+    layer = DeformableTransformerDecoderLayer(32, 64, 0.1, "relu", 2, 4, 2)
+    layer.cross_attn = NoSampling()
+    layer.eval()
+    tgt, pos, ref = torch.randn(2, 7, 32), torch.randn(2, 7, 32), torch.rand(2, 7, 2, 2)
+    args = (tgt, pos, ref, torch.randn(2, 20, 32), torch.tensor([[4, 4], [2, 2]]), torch.tensor([0, 16]))
+    assert layer.always_attention_matrix is False
+    calls = []
+    real = layer.self_attn.forward
+    layer.self_attn.forward = lambda *a, **k: (calls.append(k.get("need_weights")), real(*a, **k))[1]
+    plain = layer(*args)
+    seen = []
+    handle = layer.attn_matrix.register_forward_hook(lambda mod, inp, out: seen.append(inp[0]))
+    hooked = layer(*args)
+    handle.remove()
+    layer.always_attention_matrix = True
+    always = layer(*args)
+    assert calls == [False, True, True]
+    assert len(seen) == 1 and seen[0].shape == (2, 7, 7) and torch.allclose(seen[0].sum(-1), torch.ones(2, 7), atol=1e-5)
+    assert torch.allclose(plain, hooked, atol=1e-5) and torch.equal(hooked, always)

@@ -19,6 +19,7 @@ in-place pass, and both weight gradients on the split-M MFMA kernel — with N*S
 the weight gradient is the GEMM the vendor BLAS runs worst.
 """
 import copy
+import os
 
 import torch
 import torch.nn.functional as F
@@ -88,6 +89,11 @@ class DeformableTransformerDecoderLayer(nn.Module):
         # two parameter-free modules the reference's forward calls on the reference points / attention matrix (hook points)
         self.inter_rp = nn.ReLU()
         self.attn_matrix = nn.ReLU()
+        # True: compute the head-averaged attention matrix on every call, as the reference's forward does, hook or no hook
+        # (and with it nn.functional.dropout's random stream for the attention dropout); UVHAND_ALWAYS_ATTENTION_MATRIX=1
+        # sets it for every layer built afterwards.  Default: only when a hook on `attn_matrix` listens — 12-layer training
+        # step 26.7 -> 25.2 ms (tools/ddp_step.py, profiles/r05_notes.md section 9).
+        self.always_attention_matrix = os.environ.get("UVHAND_ALWAYS_ATTENTION_MATRIX", "0") != "0"
 
     @staticmethod
     def with_pos_embed(tensor, pos):
@@ -101,8 +107,13 @@ class DeformableTransformerDecoderLayer(nn.Module):
         self.inter_rp(reference_points)
         # the queries attend to each other first (sequence-first, as the reference feeds nn.MultiheadAttention)
         q = k = self.with_pos_embed(tgt, query_pos)
-        tgt2, attn_matrix = self.self_attn(q.transpose(0, 1), k.transpose(0, 1), tgt.transpose(0, 1))
-        self.attn_matrix(attn_matrix)
+        # The head-averaged attention matrix exists for whoever hooks `attn_matrix`; with no hook registered nothing reads it,
+        # and `need_weights=False` lets nn.MultiheadAttention take its fused scaled-dot-product path (same values in eval;
+        # in training the attention dropout then draws from the fused kernel's random stream, not nn.functional.dropout's).
+        listened = self.always_attention_matrix or bool(self.attn_matrix._forward_hooks or self.attn_matrix._forward_pre_hooks)
+        tgt2, attn_matrix = self.self_attn(q.transpose(0, 1), k.transpose(0, 1), tgt.transpose(0, 1), need_weights=listened)
+        if listened:
+            self.attn_matrix(attn_matrix)
         tgt = add_layer_norm(tgt, self.dropout2(tgt2.transpose(0, 1)), self.norm2)
         # then sample the feature pyramid
         tgt2 = self.cross_attn(self.with_pos_embed(tgt, query_pos), reference_points, src, src_spatial_shapes,
