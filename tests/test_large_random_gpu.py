@@ -10,18 +10,19 @@ from conftest import near_boundary_mask, rel_err
 pytestmark = pytest.mark.gpu
 
 
-def _large_geometries(count, seed):
+def _large_geometries(count, seed, pow2=False):
+    """pow2: L*P and P powers of two, M a divisor of 64 — what the fused prologue takes (msda_prologue_supported, include/msda.h)."""
     rng = np.random.RandomState(seed)
     cases = []
     while len(cases) < count:
-        L = int(rng.randint(1, 6))
-        P = int(rng.choice([1, 2, 3, 4]))
+        L = int(rng.choice([1, 2, 4, 4])) if pow2 else int(rng.randint(1, 6))
+        P = int(rng.choice([1, 2, 4, 4])) if pow2 else int(rng.choice([1, 2, 3, 4]))
         h, w = int(rng.randint(6, 57)), int(rng.randint(6, 57))
         if rng.rand() < 0.7:                                             # a pyramid (odd sizes halve unevenly on purpose)
             shapes = [(max(1, -(-h >> k)), max(1, -(-w >> k))) for k in range(L)]
         else:
             shapes = [(int(rng.randint(1, 41)), int(rng.randint(1, 41))) for _ in range(L)]
-        M = int(rng.choice([4, 8, 8, 8, 6]))
+        M = int(rng.choice([4, 8, 8])) if pow2 else int(rng.choice([4, 8, 8, 8, 6]))      # (the prologue: M divides 64)
         N = int(rng.randint(1, 7))
         lq_min = -(-32768 // (N * M))
         Lq = int(rng.randint(lq_min, max(lq_min + 1, min(4 * lq_min, 3500))))
@@ -111,7 +112,7 @@ def test_large_random_geometries_bf16_rows(oracle, idx, case):
             assert rel_err(gl.cpu().numpy()[keep], r_gl[keep]) < 2e-5, (case, gv32)
 
 
-@pytest.mark.parametrize("idx,case", list(enumerate(_large_geometries(12, 31337))))
+@pytest.mark.parametrize("idx,case", list(enumerate(_large_geometries(12, 31337, pow2=True))))
 def test_large_random_geometries_through_the_fused_prologue(oracle, idx, case):
     """What the MODULE runs (reference points + raw offsets + logits in, their gradients out; the forward's table handed to the
     backward): the oracle on the locations / weights the prologue forward returns, the chain rule of
@@ -120,6 +121,7 @@ def test_large_random_geometries_through_the_fused_prologue(oracle, idx, case):
     from uvhand_amd import _native
     _native.load()
     N, shapes, M, Lq, P, spread = case
+    assert _native.prologue_geometry_supported(N, sum(h * w for h, w in shapes), M, 32, len(shapes), Lq, P), case
     g = torch.Generator().manual_seed(4000 + idx)
     sh = torch.tensor(shapes, dtype=torch.long)
     L, S = len(shapes), sum(h * w for h, w in shapes)
