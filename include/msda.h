@@ -367,6 +367,29 @@ int msda_add_layernorm_backward_f32(const float *grad_y, const float *x, const f
  * and neither the dropout mask nor relu's output has to be kept. */
 int msda_relu_dropout_backward_f32(float *grad, const float *act, float scale, long long n, msda_stream_t stream);
 
+/* ---- Decoder self-attention core (models/arctic_transformer.py:351,374-376) -------------------------------
+ * nn.MultiheadAttention over the 300 queries (8 heads of 32, batch = frames) computes, between its in- and out-projections,
+ *     out = dropout(softmax(q k^T * scale), p) v          for N*H independent (batch, head) problems.
+ * These entry points are that core for head_dim 32, fp32, 1 <= Lq, Lk <= 320 (msda_attn32_supported), with neither the
+ * [N*H, Lq, Lk] score tensor nor a dropout mask in memory: the forward keeps log-sum-exp per (batch, head, query) [N*H, Lq],
+ * the backward (two launches: dK/dV, dQ) recomputes the probabilities and the mask from it.
+ * Tensors are views with the head's 32 channels contiguous: element (n, h, l, d) at p + n*sn + h*32 + l*sl + d (strides in
+ * floats, multiples of 4; 16-byte aligned bases) — the column blocks of a packed in-projection output [L, N, 3E] are such views.
+ * Dropout: keep(seed, pair, query, key) is an integer hash compared with p * 2^32 — the kernel's own random stream.  `seed` is a
+ * DEVICE pointer to one 64-bit value (drawn by the caller with its generator; the same value must reach the backward); NULL is
+ * allowed when dropout_p == 0.  No attention mask / key-padding mask (the reference's decoder passes none). */
+int msda_attn32_supported(int Lq, int Lk, int head_dim);
+int msda_attn32_forward_f32(const float *q, long long q_sn, long long q_sl, const float *k, long long k_sn, long long k_sl,
+                            const float *v, long long v_sn, long long v_sl, int N, int H, int Lq, int Lk, float scale,
+                            float dropout_p, const unsigned long long *seed, float *out, long long o_sn, long long o_sl, float *lse,
+                            msda_stream_t stream);
+int msda_attn32_backward_f32(const float *q, long long q_sn, long long q_sl, const float *k, long long k_sn, long long k_sl,
+                             const float *v, long long v_sn, long long v_sl, const float *out, long long o_sn, long long o_sl,
+                             const float *lse, const float *grad_out, long long go_sn, long long go_sl, int N, int H, int Lq, int Lk,
+                             float scale, float dropout_p, const unsigned long long *seed, float *grad_q, long long gq_sn,
+                             long long gq_sl, float *grad_k, long long gk_sn, long long gk_sl, float *grad_v, long long gv_sn,
+                             long long gv_sl, msda_stream_t stream);
+
 /* ---- Transformer input assembly -----------------------------------------------------
  * The flatten block of DeformableTransformer.forward (models/arctic_transformer.py:162-173): per level
  * src_l[N,C,H,W] -> rows [level_start_l, level_start_l + H*W) of src_flatten[N,S,C], and pos_l the same way with

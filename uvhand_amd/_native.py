@@ -30,7 +30,8 @@ _SYMBOLS = (
     "msda_add_layernorm_workspace_bytes", "msda_add_layernorm_forward_f32", "msda_add_layernorm_backward_f32",
     "msda_relu_dropout_backward_f32", "msda_cast_bf16_multi_f32",
     "msda_flatten_levels_f32", "msda_unflatten_levels_f32", "msda_unflatten_workspace_bytes",
-    "msda_linear_wgrad_f32", "msda_linear_wgrad_masked_f32", "msda_linear_wgrad_masked_bf16", "msda_linear_wgrad_multi_f32", "msda_linear_wgrad_multi", "msda_linear_wgrad_workspace_bytes",
+    "msda_linear_wgrad_f32", "msda_linear_wgrad_masked_f32", "msda_linear_wgrad_masked_bf16", "msda_linear_wgrad_multi_f32", "msda_linear_wgrad_multi", "msda_attn32_supported", "msda_attn32_forward_f32",
+    "msda_attn32_backward_f32", "msda_linear_wgrad_workspace_bytes",
     "msda_zero_masked_rows_f32", "msda_linear_forward_f32", "msda_linear_dgrad_f32",
     "msda_prologue_supported", "msda_forward_prologue_f32", "msda_backward_prologue_f32",
     "msda_last_error", "msda_version", "msda_path_for", "msda_force_path", "msda_describe_plan",
@@ -622,6 +623,63 @@ def relu_dropout_backward_(grad, act, scale):
     if rc != 0:
         _raise(lib, rc, "relu_dropout_backward_")
     return grad
+
+
+def _attn_view(t, name, heads):
+    """[L, N, heads*32] float32 CUDA view with the last dimension contiguous -> (pointer, batch stride, sequence stride)."""
+    if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 3 and t.shape[2] == heads * 32
+            and t.stride(2) == 1):
+        raise RuntimeError("attn32: %s must be a float32 CUDA tensor [L, N, heads*32] with a contiguous last dimension" % name)
+    return t.data_ptr(), t.stride(1), t.stride(0)
+
+
+def attn32_supported(Lq, Lk, head_dim):
+    lib = _lib or load()
+    return bool(lib.msda_attn32_supported(int(Lq), int(Lk), int(head_dim)))
+
+
+def attn32_forward(q, k, v, heads, scale, dropout_p=0.0, seed=None):
+    """msda_attn32_forward_f32 (include/msda.h): dropout(softmax(q k^T * scale)) v per (batch, head), head_dim 32.
+    q [Lq, N, E], k / v [Lk, N, E] (sequence first, as nn.MultiheadAttention projects them; column-block views allowed);
+    seed: a one-element int64 CUDA tensor (required when dropout_p > 0).  Returns (out [Lq, N, E], lse [N*heads, Lq])."""
+    lib = _lib or load()
+    Lq, N, Lk = q.shape[0], q.shape[1], k.shape[0]
+    qv, kv, vv = _attn_view(q, "q", heads), _attn_view(k, "k", heads), _attn_view(v, "v", heads)
+    if dropout_p > 0 and not (torch.is_tensor(seed) and seed.is_cuda and seed.dtype == torch.int64 and seed.numel() == 1):
+        raise RuntimeError("attn32_forward: dropout needs a one-element int64 CUDA seed tensor")
+    with _DeviceGuard(q.device):
+        out = torch.empty((Lq, N, heads * 32), dtype=torch.float32, device=q.device)
+        lse = torch.empty((N * heads, Lq), dtype=torch.float32, device=q.device)
+        ov = _attn_view(out, "out", heads)
+        rc = _entry(lib, "msda_attn32_forward_f32", [_VP, _LL, _LL] * 3 + [_CI] * 4 + [ctypes.c_float] * 2 + [_VP] + [_VP, _LL, _LL] + [_VP, _VP])(
+            *qv, *kv, *vv, N, heads, Lq, Lk, float(scale), float(dropout_p), seed.data_ptr() if dropout_p > 0 else None, *ov,
+            lse.data_ptr(), _raw_stream(q.device))
+    if rc != 0:
+        _raise(lib, rc, "attn32_forward")
+    return out, lse
+
+
+def attn32_backward(q, k, v, out, lse, grad_out, heads, scale, dropout_p=0.0, seed=None, grad_q=None, grad_k=None, grad_v=None):
+    """msda_attn32_backward_f32: gradients of q, k, v (written into grad_q / grad_k / grad_v when given — views like the inputs,
+    e.g. the two column blocks of one packed [L, N, 2E] tensor — else into new contiguous tensors)."""
+    lib = _lib or load()
+    Lq, N, Lk = q.shape[0], q.shape[1], k.shape[0]
+    with _DeviceGuard(q.device):
+        grad_q = torch.empty((Lq, N, heads * 32), dtype=torch.float32, device=q.device) if grad_q is None else grad_q
+        grad_k = torch.empty((Lk, N, heads * 32), dtype=torch.float32, device=q.device) if grad_k is None else grad_k
+        grad_v = torch.empty((Lk, N, heads * 32), dtype=torch.float32, device=q.device) if grad_v is None else grad_v
+        if grad_out.stride(2) != 1:
+            grad_out = grad_out.contiguous()
+        views = [_attn_view(t, nm, heads) for t, nm in ((q, "q"), (k, "k"), (v, "v"), (out, "out"))]
+        gov = _attn_view(grad_out, "grad_out", heads)
+        gviews = [_attn_view(t, nm, heads) for t, nm in ((grad_q, "grad_q"), (grad_k, "grad_k"), (grad_v, "grad_v"))]
+        rc = _entry(lib, "msda_attn32_backward_f32", [_VP, _LL, _LL] * 4 + [_VP] + [_VP, _LL, _LL] + [_CI] * 4 + [ctypes.c_float] * 2 + [_VP]
+                    + [_VP, _LL, _LL] * 3 + [_VP])(
+            *views[0], *views[1], *views[2], *views[3], lse.data_ptr(), *gov, N, heads, Lq, Lk, float(scale), float(dropout_p),
+            seed.data_ptr() if dropout_p > 0 else None, *gviews[0], *gviews[1], *gviews[2], _raw_stream(q.device))
+    if rc != 0:
+        _raise(lib, rc, "attn32_backward")
+    return grad_q, grad_k, grad_v
 
 
 def add_layernorm_supported(x, residual, weight, bias):

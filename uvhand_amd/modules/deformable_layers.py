@@ -25,6 +25,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from ..functions.attention_func import self_attention
 from ..functions.layernorm_func import add_layer_norm
 from ..functions.linear_func import bracket_linear, fused_ffn
 from ..utils.transformer_inputs import decoder_reference_points, encoder_reference_points
@@ -108,12 +109,14 @@ class DeformableTransformerDecoderLayer(nn.Module):
         # the queries attend to each other first (sequence-first, as the reference feeds nn.MultiheadAttention)
         q = k = self.with_pos_embed(tgt, query_pos)
         # The head-averaged attention matrix exists for whoever hooks `attn_matrix`; with no hook registered nothing reads it,
-        # and `need_weights=False` lets nn.MultiheadAttention take its fused scaled-dot-product path (same values in eval;
-        # in training the attention dropout then draws from the fused kernel's random stream, not nn.functional.dropout's).
+        # and the attention core runs without ever writing a [N*heads, L, L] tensor (same values in eval; in training the
+        # attention dropout then draws from that kernel's random stream, not nn.functional.dropout's).
         listened = self.always_attention_matrix or bool(self.attn_matrix._forward_hooks or self.attn_matrix._forward_pre_hooks)
-        tgt2, attn_matrix = self.self_attn(q.transpose(0, 1), k.transpose(0, 1), tgt.transpose(0, 1), need_weights=listened)
         if listened:
+            tgt2, attn_matrix = self.self_attn(q.transpose(0, 1), k.transpose(0, 1), tgt.transpose(0, 1), need_weights=True)
             self.attn_matrix(attn_matrix)
+        else:                                            # the library's attention core where it applies (functions/attention_func.py)
+            tgt2 = self_attention(self.self_attn, q.transpose(0, 1), tgt.transpose(0, 1))
         tgt = add_layer_norm(tgt, self.dropout2(tgt2.transpose(0, 1)), self.norm2)
         # then sample the feature pyramid
         tgt2 = self.cross_attn(self.with_pos_embed(tgt, query_pos), reference_points, src, src_spatial_shapes,
