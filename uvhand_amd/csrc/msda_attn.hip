@@ -3,7 +3,8 @@
 // The vendor's fused path spends 77 + 112 + 100 us per decoder layer on it at 32 frames (attn_fwd, bwd_kernel_dk_dv,
 // bwd_kernel_dq, profiles/r05_layers_kernel_stats_fused.csv) — for 256 independent 300 x 300 x 32 problems that fit a CU's LDS.
 //
-// All three kernels: a workgroup of 10 wavefronts owns half of one (batch, head) pair's 16-row tiles, one tile per wavefront;
+// All three kernels: a workgroup of 10 wavefronts owns one (batch, head) pair — its 16-row tiles dealt to the wavefronts, two each at
+// 300 rows (two workgroups per pair, a tile per wavefront, re-load the pair's operands and measured 8 % slower: MSDA_ATTN_HALVES);
 // the pair's other operand(s) sit in LDS row-major ([rows][36 floats]: 16-byte aligned rows, the 16 lanes of a ds_read_b128 on
 // different bank groups).  Every product runs on v_mfma_f32_16x16x4_f32 (fp32 in, fp32 accumulate: the arithmetic of an fmaf
 // chain), and the score tile never changes layout between the two products it takes part in:
@@ -31,25 +32,41 @@ using at_f4 = __attribute__((ext_vector_type(4))) float;
 
 struct AtView { float *p; long long sn, sl; };          // element (n, h, l, d) at p + n*sn + h*32 + l*sl + d
 
+// 32 bits per (pair, query, key): the counter, offset by the seed and the pair, through the two multiply-xorshift rounds of
+// the usual 32-bit finalizer (v_mul_lo_u32 is a quarter-rate instruction: the hash is most of the vector work per probability)
 __device__ __forceinline__ unsigned at_hash(unsigned seed_lo, unsigned seed_hi, unsigned pair, unsigned q, unsigned key)
 {
-    unsigned x = ((q << 16) | key) ^ seed_lo;
-    x *= 0x9E3779B1u; x ^= x >> 16;
-    x += pair * 0x85EBCA6Bu + seed_hi;
-    x *= 0xC2B2AE35u; x ^= x >> 15;
-    x *= 0x27D4EB2Fu; x ^= x >> 13;
+    unsigned x = (((q << 16) | key) ^ seed_lo) + (pair * 0x9E3779B1u + seed_hi);      // (the second term is uniform: scalar unit)
+    x ^= x >> 16; x *= 0x85EBCA6Bu;
+    x ^= x >> 13; x *= 0xC2B2AE35u;
+    x ^= x >> 16;
     return x;
 }
 
 __device__ __forceinline__ float4 at_ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ float4 at_zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
-// rows [0, L) of a [L][32] slice (row stride sl) -> dst[Lp][kAtRow]; rows [L, Lp) zero
-__device__ __forceinline__ void at_load_rows(float *dst, const float *src, long long sl, int L, int Lp)
+// rows [0, L) of two [L][32] slices (row strides sl0 / sl1) -> dst0 / dst1 [Lp][kAtRow]; rows [L, Lp) zero.  Lp * 8 float4 per
+// slice on 640 threads: at most four rounds (Lp <= 320); all the loads of a thread are issued before its first LDS store.
+__device__ __forceinline__ void at_load_rows2(float *dst0, const float *src0, long long sl0, float *dst1, const float *src1,
+                                              long long sl1, int L, int Lp)
 {
-    for (int i = threadIdx.x; i < Lp * 8; i += kAtBlock) {
-        const int row = i >> 3, c = (i & 7) * 4;
-        *reinterpret_cast<float4 *>(dst + row * kAtRow + c) = row < L ? at_ld4(src + (long long)row * sl + c) : at_zero4();
+    constexpr int R = (kAtMaxLen * 8 + kAtBlock - 1) / kAtBlock;
+    float4 v0[R], v1[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int i = threadIdx.x + k * kAtBlock, row = i >> 3, c = (i & 7) * 4;
+        const bool live = row < L;
+        v0[k] = live ? at_ld4(src0 + (long long)row * sl0 + c) : at_zero4();
+        v1[k] = live ? at_ld4(src1 + (long long)row * sl1 + c) : at_zero4();
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int i = threadIdx.x + k * kAtBlock, row = i >> 3, c = (i & 7) * 4;
+        if (row < Lp) {
+            *reinterpret_cast<float4 *>(dst0 + row * kAtRow + c) = v0[k];
+            *reinterpret_cast<float4 *>(dst1 + row * kAtRow + c) = v1[k];
+        }
     }
 }
 
@@ -62,7 +79,19 @@ __device__ __forceinline__ at_f4 at_dot32(const float *arow, const float4 &b0, c
     at_f4 acc = {0.f, 0.f, 0.f, 0.f};
     acc = AT_MFMA(a0.x, b0.x, acc); acc = AT_MFMA(a0.y, b0.y, acc); acc = AT_MFMA(a0.z, b0.z, acc); acc = AT_MFMA(a0.w, b0.w, acc);
     acc = AT_MFMA(a1.x, b1.x, acc); acc = AT_MFMA(a1.y, b1.y, acc); acc = AT_MFMA(a1.z, b1.z, acc); acc = AT_MFMA(a1.w, b1.w, acc);
-    return acc;
+    return acc;                                      // (one chain: the sum's association is the channel order)
+}
+
+// the same for this tile and the next one (16 rows further), the two accumulators' chains interleaved
+__device__ __forceinline__ void at_dot32x2(const float *arow, const float4 &b0, const float4 &b1, at_f4 &acc0, at_f4 &acc1)
+{
+    const float4 a0 = at_ld4(arow), a1 = at_ld4(arow + 16), c0 = at_ld4(arow + 16 * kAtRow), c1 = at_ld4(arow + 16 * kAtRow + 16);
+    at_f4 x = {0.f, 0.f, 0.f, 0.f}, y = x;
+    x = AT_MFMA(a0.x, b0.x, x); y = AT_MFMA(c0.x, b0.x, y); x = AT_MFMA(a0.y, b0.y, x); y = AT_MFMA(c0.y, b0.y, y);
+    x = AT_MFMA(a0.z, b0.z, x); y = AT_MFMA(c0.z, b0.z, y); x = AT_MFMA(a0.w, b0.w, x); y = AT_MFMA(c0.w, b0.w, y);
+    x = AT_MFMA(a1.x, b1.x, x); y = AT_MFMA(c1.x, b1.x, y); x = AT_MFMA(a1.y, b1.y, x); y = AT_MFMA(c1.y, b1.y, y);
+    x = AT_MFMA(a1.z, b1.z, x); y = AT_MFMA(c1.z, b1.z, y); x = AT_MFMA(a1.w, b1.w, x); y = AT_MFMA(c1.w, b1.w, y);
+    acc0 = x; acc1 = y;
 }
 
 // o[half] += X^T-rows . w over the tile's 16 rows: X = LDS tile base (row 16t), w = accumulator-layout weights of this lane
@@ -104,8 +133,7 @@ __global__ __launch_bounds__(kAtBlock) void attn32_fwd_kernel(const AtArgs a)
     const int Lkp = (a.Lk + 15) & ~15, ntk = Lkp >> 4, ntq = (a.Lq + 15) >> 4;
     float *Ks = at_smem, *Vs = at_smem + Lkp * kAtRow;
     const int pair = (int)blockIdx.x / a.halves, part = (int)blockIdx.x % a.halves, n = pair / a.H, h = pair % a.H;
-    at_load_rows(Ks, a.k.p + n * a.k.sn + h * 32, a.k.sl, a.Lk, Lkp);
-    at_load_rows(Vs, a.v.p + n * a.v.sn + h * 32, a.v.sl, a.Lk, Lkp);
+    at_load_rows2(Ks, a.k.p + n * a.k.sn + h * 32, a.k.sl, Vs, a.v.p + n * a.v.sn + h * 32, a.v.sl, a.Lk, Lkp);
     const unsigned seed_lo = a.thresh ? (unsigned)a.seed[0] : 0u, seed_hi = a.thresh ? (unsigned)(a.seed[0] >> 32) : 0u;
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, r = lane >> 4;
@@ -122,13 +150,18 @@ __global__ __launch_bounds__(kAtBlock) void attn32_fwd_kernel(const AtArgs a)
         // S^T tiles: s[t][v] = score of key 16 t + 4 r + v for query qi
         at_f4 s[kAtMaxTiles];
         float m = -INFINITY;
+        // (all the products first — independent chains, the matrix pipe runs them back to back — then the row maximum)
+#pragma unroll
+        for (int t = 0; t < kAtMaxTiles; t += 2) {               // two tiles' chains interleaved (a dependent MFMA waits 40 cycles, an issue takes 32)
+            if (t + 1 < ntk) at_dot32x2(Ks + (16 * t + c) * kAtRow + 4 * r, q0, q1, s[t], s[t + 1]);
+            else if (t < ntk) s[t] = at_dot32(Ks + (16 * t + c) * kAtRow + 4 * r, q0, q1);
+        }
 #pragma unroll
         for (int t = 0; t < kAtMaxTiles; ++t) {
             if (t < ntk) {
-                s[t] = at_dot32(Ks + (16 * t + c) * kAtRow + 4 * r, q0, q1);
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
-                    if (16 * t + 4 * r + v >= a.Lk) s[t][v] = -INFINITY;
+                    s[t][v] = 16 * t + 4 * r + v < a.Lk ? s[t][v] : -INFINITY;
                     m = fmaxf(m, s[t][v]);
                 }
             }
@@ -151,7 +184,7 @@ __global__ __launch_bounds__(kAtBlock) void attn32_fwd_kernel(const AtArgs a)
             if (t < ntk) {
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
-                    const bool keep = a.thresh == 0 || at_hash(seed_lo, seed_hi, pair, qi, 16 * t + 4 * r + v) >= a.thresh;
+                    const bool keep = at_hash(seed_lo, seed_hi, pair, qi, 16 * t + 4 * r + v) >= a.thresh;      // (thresh 0: always)
                     s[t][v] = keep ? s[t][v] * inv : 0.f;
                 }
                 at_accum_t(Vs + 16 * t * kAtRow, r, c, s[t], o0, o1);       // O^T[channel][query] += V^T . P
@@ -172,8 +205,7 @@ __global__ __launch_bounds__(kAtBlock) void attn32_bwd_kv_kernel(const AtArgs a)
     const int Lqp = (a.Lq + 15) & ~15, ntq = Lqp >> 4, ntk = (a.Lk + 15) >> 4;
     float *Qs = at_smem, *Gs = at_smem + Lqp * kAtRow, *lse_s = Gs + Lqp * kAtRow, *del_s = lse_s + Lqp;
     const int pair = (int)blockIdx.x / a.halves, part = (int)blockIdx.x % a.halves, n = pair / a.H, h = pair % a.H;
-    at_load_rows(Qs, a.q.p + n * a.q.sn + h * 32, a.q.sl, a.Lq, Lqp);
-    at_load_rows(Gs, a.go.p + n * a.go.sn + h * 32, a.go.sl, a.Lq, Lqp);
+    at_load_rows2(Qs, a.q.p + n * a.q.sn + h * 32, a.q.sl, Gs, a.go.p + n * a.go.sn + h * 32, a.go.sl, a.Lq, Lqp);
     const unsigned seed_lo = a.thresh ? (unsigned)a.seed[0] : 0u, seed_hi = a.thresh ? (unsigned)(a.seed[0] >> 32) : 0u;
     __syncthreads();
     // per query: log-sum-exp (+inf for the padding rows: their probabilities vanish) and delta = <dO, O>
@@ -205,23 +237,28 @@ __global__ __launch_bounds__(kAtBlock) void attn32_bwd_kv_kernel(const AtArgs a)
         k0.x *= a.scale; k0.y *= a.scale; k0.z *= a.scale; k0.w *= a.scale;
         k1.x *= a.scale; k1.y *= a.scale; k1.z *= a.scale; k1.w *= a.scale;
         at_f4 dv0 = {0.f, 0.f, 0.f, 0.f}, dv1 = dv0, dk0 = dv0, dk1 = dv0;
+        // S and dP tiles: entry v = (query 16 t + 4 r + v, key).  The next tile's two products are issued before this tile's
+        // exponentials and hashes: the matrix pipe works through them while the vector unit is busy.
+        at_f4 s = at_dot32(Qs + c * kAtRow + 4 * r, k0, k1), dp = at_dot32(Gs + c * kAtRow + 4 * r, v0, v1);
 #pragma unroll 1
         for (int t = 0; t < ntq; ++t) {
-            // S and dP tiles: entry v = (query 16 t + 4 r + v, key)
-            const at_f4 s = at_dot32(Qs + (16 * t + c) * kAtRow + 4 * r, k0, k1);
-            const at_f4 dp = at_dot32(Gs + (16 * t + c) * kAtRow + 4 * r, v0, v1);
+            const int tn = min(t + 1, ntq - 1);
+            const at_f4 s_next = at_dot32(Qs + (16 * tn + c) * kAtRow + 4 * r, k0, k1);
+            const at_f4 dp_next = at_dot32(Gs + (16 * tn + c) * kAtRow + 4 * r, v0, v1);
+            __builtin_amdgcn_sched_barrier(0);
             const float4 ls = at_ld4(lse_s + 16 * t + 4 * r), dl = at_ld4(del_s + 16 * t + 4 * r);
             const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, dlv[4] = {dl.x, dl.y, dl.z, dl.w};
             at_f4 pd, ds;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const float p = __expf(s[v] - lsv[v]);
-                const bool keep = a.thresh == 0 || at_hash(seed_lo, seed_hi, pair, 16 * t + 4 * r + v, key) >= a.thresh;
+                const bool keep = at_hash(seed_lo, seed_hi, pair, 16 * t + 4 * r + v, key) >= a.thresh;
                 pd[v] = keep ? p * a.keep_scale : 0.f;
                 ds[v] = p * ((keep ? dp[v] * a.keep_scale : 0.f) - dlv[v]);
             }
             at_accum_t(Gs + 16 * t * kAtRow, r, c, pd, dv0, dv1);           // dV^T[channel][key] += dO^T . P_drop
             at_accum_t(Qs + 16 * t * kAtRow, r, c, ds, dk0, dk1);           // dK^T[channel][key] += Q^T . dS
+            s = s_next; dp = dp_next;
         }
         if (kok) {
             float *gvr = a.gv.p + n * a.gv.sn + h * 32 + (long long)key * a.gv.sl + 4 * r;
@@ -241,8 +278,7 @@ __global__ __launch_bounds__(kAtBlock) void attn32_bwd_q_kernel(const AtArgs a)
     const int Lkp = (a.Lk + 15) & ~15, ntk = Lkp >> 4, ntq = (a.Lq + 15) >> 4;
     float *Ks = at_smem, *Vs = at_smem + Lkp * kAtRow;
     const int pair = (int)blockIdx.x / a.halves, part = (int)blockIdx.x % a.halves, n = pair / a.H, h = pair % a.H;
-    at_load_rows(Ks, a.k.p + n * a.k.sn + h * 32, a.k.sl, a.Lk, Lkp);
-    at_load_rows(Vs, a.v.p + n * a.v.sn + h * 32, a.v.sl, a.Lk, Lkp);
+    at_load_rows2(Ks, a.k.p + n * a.k.sn + h * 32, a.k.sl, Vs, a.v.p + n * a.v.sn + h * 32, a.v.sl, a.Lk, Lkp);
     const unsigned seed_lo = a.thresh ? (unsigned)a.seed[0] : 0u, seed_hi = a.thresh ? (unsigned)(a.seed[0] >> 32) : 0u;
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, r = lane >> 4;
@@ -264,20 +300,24 @@ __global__ __launch_bounds__(kAtBlock) void attn32_bwd_q_kernel(const AtArgs a)
         const float delta = at_rsum(g0.x * o0.x + g0.y * o0.y + g0.z * o0.z + g0.w * o0.w + g1.x * o1.x + g1.y * o1.y + g1.z * o1.z +
                                     g1.w * o1.w);
         at_f4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = dq0;
+        // S^T and dP^T tiles: entry v = (key 16 t + 4 r + v, query qi); the next tile's products issued ahead, as in the dK / dV kernel
+        at_f4 s = at_dot32(Ks + c * kAtRow + 4 * r, q0, q1), dp = at_dot32(Vs + c * kAtRow + 4 * r, g0, g1);
 #pragma unroll 1
         for (int t = 0; t < ntk; ++t) {
-            // S^T and dP^T tiles: entry v = (key 16 t + 4 r + v, query qi)
-            const at_f4 s = at_dot32(Ks + (16 * t + c) * kAtRow + 4 * r, q0, q1);
-            const at_f4 dp = at_dot32(Vs + (16 * t + c) * kAtRow + 4 * r, g0, g1);
+            const int tn = min(t + 1, ntk - 1);
+            const at_f4 s_next = at_dot32(Ks + (16 * tn + c) * kAtRow + 4 * r, q0, q1);
+            const at_f4 dp_next = at_dot32(Vs + (16 * tn + c) * kAtRow + 4 * r, g0, g1);
+            __builtin_amdgcn_sched_barrier(0);
             at_f4 ds;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int key = 16 * t + 4 * r + v;
                 const float p = key < a.Lk ? __expf(s[v] - lse) : 0.f;
-                const bool keep = a.thresh == 0 || at_hash(seed_lo, seed_hi, pair, qi, key) >= a.thresh;
+                const bool keep = at_hash(seed_lo, seed_hi, pair, qi, key) >= a.thresh;
                 ds[v] = p * ((keep ? dp[v] * a.keep_scale : 0.f) - delta);
             }
             at_accum_t(Ks + 16 * t * kAtRow, r, c, ds, dq0, dq1);           // dQ^T[channel][query] += K^T . dS^T
+            s = s_next; dp = dp_next;
         }
         if (qok) {
             float *gq = a.gq.p + n * a.gq.sn + h * 32 + (long long)qi * a.gq.sl + 4 * r;
@@ -315,7 +355,7 @@ static int at_fill(AtArgs &a, const char *who, int N, int H, int Lq, int Lk, flo
 {
     if (N <= 0 || H <= 0 || !msda_attn32_supported(Lq, Lk, 32)) return msda::set_error(MSDA_ERR_ARGUMENT, who);
     if (!(dropout_p >= 0.f && dropout_p < 1.f) || (dropout_p > 0.f && seed == nullptr)) return msda::set_error(MSDA_ERR_ARGUMENT, who);
-    a.H = H; a.Lq = Lq; a.Lk = Lk; a.halves = 2; a.scale = scale;
+    a.H = H; a.Lq = Lq; a.Lk = Lk; a.halves = msda::tuning_int("MSDA_ATTN_HALVES", 1) == 2 ? 2 : 1; a.scale = scale;
     a.keep_scale = 1.f / (1.f - dropout_p);
     a.thresh = dropout_p > 0.f ? (unsigned)fmin(4294967295.0, (double)dropout_p * 4294967296.0) : 0u;
     a.seed = seed;
