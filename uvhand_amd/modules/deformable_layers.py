@@ -16,7 +16,9 @@ What is MI355X-specific: the attention is this package's ``MSDeformAttn`` (HIP k
 the FFN ``linear2(dropout(relu(linear1(x))))`` is ONE autograd node (``functions/linear_func.py``: ``fused_ffn``): bias + ReLU
 in the epilogue of linear1's GEMM, PyTorch's own dropout kernel (same random stream), the dropout and ReLU gradients as one
 in-place pass, and both weight gradients on the split-M MFMA kernel — with N*S = 33 440 rows per rank at the training shape
-the weight gradient is the GEMM the vendor BLAS runs worst.
+the weight gradient is the GEMM the vendor BLAS runs worst; the decoder's self-attention keeps the ``nn.MultiheadAttention``
+module and its parameters, but unless a hook on ``attn_matrix`` asks for the head-averaged attention matrix (or
+``always_attention_matrix``) its core runs on the library's fp32-MFMA attention kernels (``functions/attention_func.py``).
 """
 import copy
 import os
