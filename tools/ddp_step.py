@@ -207,6 +207,11 @@ def main():
         # whole-network capture (forward, loss, backward); the gradients the capture allocates stay where they are and every
         # replay refreshes them, so the optimizer reads them as usual.  Nothing in the modules or the library synchronises,
         # allocates outside the capture pool or reads spatial_shapes back (tests/test_module_gpu.py captures one module).
+        # (PyTorch-ROCm 2.10: ending a capture while the autograd graph of an earlier EAGER step is still alive segfaults in
+        # capture_end — drop the warm-up's loss first; uvhand_amd/graphs.py does the same for make_graphed_callables)
+        loss = None
+        gc.collect()
+        torch.cuda.synchronize(device)
         side = torch.cuda.Stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side):
