@@ -29,7 +29,8 @@ DESIGN.md's performance table, measured in the same run (none of it is `value`):
 bf16 rows, model-like locations (SURVEY 8d distribution B) at cfg2_decoder / cfg4_encoder and one
 row per shape with the deterministic flag: graph-replay step, the two kernels on their own,
 algorithmic bytes and fractions — and `modules` — the MSDeformAttn module forward+backward at cfg2_decoder and
-cfg4_encoder, fp32 and autocast-bf16, per HIP graph and eager wall time (--no-table skips both).
+cfg4_encoder, fp32 and autocast-bf16, per HIP graph and eager wall time — and `layers` — the decoder self-attention core
+(msda_attn32_*) at 300 queries x 32 frames x 8 heads with torch's fused attention beside it (--no-table skips all three).
 """
 import argparse
 import json
@@ -352,6 +353,46 @@ def measure_module(workload, device, stream, amp=False, budget_s=0.6):
     return row
 
 
+def measure_attention(device, stream, budget_s=0.4, L=300, N=32, H=8, p=0.1):
+    """the decoder self-attention core (msda_attn32_*_f32, head_dim 32) at the training shape — 300 queries, 32 frames,
+    8 heads, dropout 0.1 — forward and backward per HIP graph of 10 calls, with torch's scaled_dot_product_attention beside it."""
+    import math
+    import torch.nn.functional as F
+    from uvhand_amd import _native
+    E = H * 32
+    gen = torch.Generator(device="cpu").manual_seed(1)
+    qk = torch.randn(L, N, 2 * E, generator=gen).to(device)
+    v, go = torch.randn(L, N, E, generator=gen).to(device), torch.randn(L, N, E, generator=gen).to(device)
+    q, k = qk[..., :E], qk[..., E:]
+    seed = torch.tensor([20240607], dtype=torch.int64, device=device)
+    scale = 1.0 / math.sqrt(32)
+    row = {"what": "decoder self-attention core", "queries": L, "frames": N, "heads": H, "head_dim": 32, "dropout": p, "dtype": "f32"}
+    with torch.cuda.stream(stream):
+        out, lse = _native.attn32_forward(q, k, v, H, scale, p, seed)
+        gqk, gv = torch.empty_like(qk), torch.empty_like(v)
+        fwd = lambda: _native.attn32_forward(q, k, v, H, scale, p, seed)
+        bwd = lambda: _native.attn32_backward(q, k, v, out, lse, go, H, scale, p, seed, grad_q=gqk[..., :E], grad_k=gqk[..., E:], grad_v=gv)
+        for name, fn in (("fwd_us", fwd), ("bwd_us", bwd)):
+            fn()
+            g = graph_of(fn, stream, per=10)
+            row[name] = timed_us(g.replay, 10, stream, budget_s) if g is not None else None
+        q4, k4, v4 = (t.contiguous().view(L, N * H, 32).transpose(0, 1).reshape(N, H, L, 32).detach().requires_grad_(True) for t in (q, k, v))
+        g4 = go.view(L, N * H, 32).transpose(0, 1).reshape(N, H, L, 32).contiguous()
+
+        def torch_step():
+            q4.grad = k4.grad = v4.grad = None
+            F.scaled_dot_product_attention(q4, k4, v4, dropout_p=p).backward(g4)
+        torch_step()
+        g = graph_of(torch_step, stream, per=10)
+        row["torch_sdpa_fwd_bwd_us"] = timed_us(g.replay, 10, stream, budget_s) if g is not None else None
+    flops = 4.0 * N * H * L * L * 32
+    if row.get("fwd_us") and row.get("bwd_us"):
+        row["fwd_bwd_us"] = row["fwd_us"] + row["bwd_us"]
+        row["fwd_tflops"], row["bwd_tflops"] = flops / row["fwd_us"] / 1e6, 2.5 * flops / row["bwd_us"] / 1e6
+        row["mfma_f32_peak_tflops"] = 157.3
+    return row
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -613,6 +654,11 @@ def main():
                 except Exception as exc:
                     result["modules"].append({"workload": w, "amp": amp, "error": "%s: %s" % (type(exc).__name__, exc)})
                 torch.cuda.empty_cache()
+            try:
+                result["layers"] = [measure_attention(device, stream)]
+            except Exception as exc:
+                result["layers"] = [{"what": "decoder self-attention core", "error": "%s: %s" % (type(exc).__name__, exc)}]
+            torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = time_cpu_baseline(args.workload)
             result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]

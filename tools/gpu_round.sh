@@ -22,4 +22,6 @@ for w in r.get("workloads", []):
         w["fwd_frac"], w["bwd_us"], w["bwd_frac"], w["samples_per_s"]))
 for m in r.get("modules", []):
     print("module", m)
+for m in r.get("layers", []):
+    print("layer", m)
 PY
