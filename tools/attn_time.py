@@ -10,6 +10,8 @@ import torch.nn.functional as F
 from uvhand_amd import _native
 if any(k.startswith("MSDA_") for k in os.environ):
     _native.LIB_PATH = os.path.join(ROOT, "uvhand_amd", "libmsda_hip_tuning.so")
+if os.environ.get("ATTN_LIB"):                               # a library built with other compile-time constants
+    _native.LIB_PATH = os.path.join(ROOT, os.environ["ATTN_LIB"])
 dev = torch.device("cuda", 0)
 st = torch.cuda.Stream(dev)
 L, N, H = int(os.environ.get("ATTN_L", 300)), int(os.environ.get("ATTN_N", 32)), 8

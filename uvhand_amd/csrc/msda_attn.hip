@@ -3,8 +3,9 @@
 // The vendor's fused path spends 77 + 112 + 100 us per decoder layer on it at 32 frames (attn_fwd, bwd_kernel_dk_dv,
 // bwd_kernel_dq, profiles/r05_layers_kernel_stats_fused.csv) — for 256 independent 300 x 300 x 32 problems that fit a CU's LDS.
 //
-// All three kernels: a workgroup of 10 wavefronts owns one (batch, head) pair — its 16-row tiles dealt to the wavefronts, two each at
-// 300 rows (two workgroups per pair, a tile per wavefront, re-load the pair's operands and measured 8 % slower: MSDA_ATTN_HALVES);
+// All three kernels: a workgroup of 12 wavefronts (three per SIMD; with 10 two SIMDs carry three and two carry two: 201 us forward +
+// backward against 167 with 12 or 16, 174 with 8) owns one (batch, head) pair — its 16-row tiles dealt to the wavefronts, up to two
+// each at 300 rows (two workgroups per pair re-load the pair's operands and measured 8 % slower: MSDA_ATTN_HALVES);
 // the pair's other operand(s) sit in LDS row-major ([rows][36 floats]: 16-byte aligned rows, the 16 lanes of a ds_read_b128 on
 // different bank groups).  Every product runs on v_mfma_f32_16x16x4_f32 (fp32 in, fp32 accumulate: the arithmetic of an fmaf
 // chain), and the score tile never changes layout between the two products it takes part in:
@@ -27,7 +28,10 @@
 
 namespace msda {
 
-constexpr int kAtRow = 36, kAtWaves = 10, kAtBlock = kAtWaves * 64, kAtMaxTiles = 20, kAtMaxLen = 16 * kAtMaxTiles;
+#ifndef MSDA_AT_WAVES
+#define MSDA_AT_WAVES 12
+#endif
+constexpr int kAtRow = 36, kAtWaves = MSDA_AT_WAVES, kAtBlock = kAtWaves * 64, kAtMaxTiles = 20, kAtMaxLen = 16 * kAtMaxTiles;
 using at_f4 = __attribute__((ext_vector_type(4))) float;
 
 struct AtView { float *p; long long sn, sl; };          // element (n, h, l, d) at p + n*sn + h*32 + l*sl + d
