@@ -245,6 +245,18 @@ def test_argument_errors_are_reported_before_anything_is_launched(native):
     # MSDA_FLAG_PROLOGUE (2): large problems keep per-head reference-point gradients [N, Lq, M, L, 2] in scratch
     assert lib.msda_backward_workspace_bytes(2, 3060, 8, 32, 4, 3060, 4, 2) == 2 * 3060 * 8 * 4 * 8
     assert lib.msda_backward_workspace_bytes(2, 3060, 8, 32, 4, 300, 4, 2) == 0            # small problem: the fused launch
+    # the decoder self-attention core: head_dim 32, at most 320 queries / keys, 0 <= p < 1 with a seed, aligned views
+    assert lib.msda_attn32_supported(300, 300, 32) == 1 and lib.msda_attn32_supported(321, 300, 32) == 0
+    assert lib.msda_attn32_supported(300, 0, 32) == 0 and lib.msda_attn32_supported(300, 300, 64) == 0
+    fn = lib.msda_attn32_forward_f32
+    fn.argtypes = [V, LL, LL] * 3 + [I] * 4 + [ctypes.c_float] * 2 + [V] + [V, LL, LL] + [V, V]
+    fn.restype = I
+    assert fn(*([None, 256, 256] * 3), 2, 8, 400, 400, 0.17, 0.0, None, None, 256, 256, None, None) == 1      # too long
+    assert b"320" in lib.msda_last_error()
+    assert fn(*([None, 256, 256] * 3), 2, 8, 300, 300, 0.17, 0.1, None, None, 256, 256, None, None) == 1      # dropout without a seed
+    assert fn(*([None, 256, 256] * 3), 2, 8, 300, 300, 0.17, 1.0, None, None, 256, 256, None, None) == 1      # p = 1
+    assert fn(*([None, 256, 256] * 3), 2, 8, 300, 300, 0.17, 0.0, None, None, 256, 256, None, None) == 1      # null tensors
+    assert b"aligned" in lib.msda_last_error()
     lib.msda_unflatten_workspace_bytes.restype = ctypes.c_ulonglong
     lib.msda_unflatten_workspace_bytes.argtypes = [I, V, V, I, I]
     hs4, ws4 = (I * 4)(28, 14, 7, 4), (I * 4)(28, 14, 7, 4)
