@@ -2,8 +2,9 @@
 ``nn.MultiheadAttention(d_model, n_heads, dropout)`` called sequence-first with q = k = tgt + query_pos, v = tgt, no masks) with
 the attention core — ``dropout(softmax(q k^T / sqrt(d))) v`` — on the library's own kernels (msda_attn32_*_f32, include/msda.h)
 when it fits them: head_dim 32, at most 320 queries, fp32, no masks.  The module, its parameters and state_dict keys stay
-``nn.MultiheadAttention``'s; the in- and out-projections stay ``F.linear`` (q and k share their input, so their two
-projections are ONE GEMM on the first two thirds of ``in_proj_weight``).
+``nn.MultiheadAttention``'s; the in- and out-projections are ``nn.Linear``'s arithmetic on the module's own weights (q and k share
+their input, so their two projections are ONE GEMM on the first two thirds of ``in_proj_weight``), with the weight gradients on the
+library's MFMA kernel like every other projection of the drop-in layers (``functions/linear_func.py``).
 
 What differs from the stock module: no [N*heads, L, L] tensor is ever written (scores, probabilities, dropout mask), and the
 attention dropout draws its mask from the kernel's own hash of (seed, head, query, key) — the seed comes from torch's generator
@@ -12,12 +13,12 @@ attention dropout draws its mask from the kernel's own hash of (seed, head, quer
 import math
 
 import torch
-import torch.nn.functional as F
 from torch import nn
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from .. import _native as MSDA
+from .linear_func import bracket_linear_wb
 
 
 class _Attn32Fn(Function):
@@ -61,7 +62,9 @@ def self_attention(mha, x_qk, x_v):
         return mha(x_qk, x_qk, x_v, need_weights=False)[0]
     E = mha.embed_dim
     w, b = mha.in_proj_weight, mha.in_proj_bias
-    qk = F.linear(x_qk, w[:2 * E], b[:2 * E])
-    v = F.linear(x_v, w[2 * E:], b[2 * E:])
+    # (the three projections through bracket_linear_wb: nn.Linear's forward, the weight gradients on the library's split-M MFMA
+    # kernel — torch runs the 9600-row ones at a third of its rate, 61 against 26 us each, tools/wgrad_time.py)
+    qk = bracket_linear_wb(x_qk, w[:2 * E], b[:2 * E])
+    v = bracket_linear_wb(x_v, w[2 * E:], b[2 * E:])
     core = _Attn32Fn.apply(qk, v, mha.num_heads, float(mha.dropout) if mha.training else 0.0)
-    return F.linear(core, mha.out_proj.weight, mha.out_proj.bias)
+    return bracket_linear_wb(core, mha.out_proj.weight, mha.out_proj.bias)
