@@ -20,6 +20,13 @@ p = float(os.environ.get("ATTN_P", 0.1))
 
 def gpu_us(fn):
     fn(); st.synchronize()
+    if os.environ.get("ATTN_EAGER"):                      # plain launches (counter passes: tools/attn_pmc.sh)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(st)
+        for _ in range(20):
+            fn()
+        b.record(st); b.synchronize()
+        return a.elapsed_time(b) * 1e3 / 20
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g, stream=st):
         for _ in range(10):
