@@ -66,5 +66,16 @@ def test_decoder_layer_computes_the_attention_matrix_only_for_a_listener():
     layer.always_attention_matrix = True
     always = layer(*args)
     assert calls == [False, True, True]
+    # hooks registered for EVERY module and backward hooks on the tap count as listeners too
+    calls.clear()
+    layer.always_attention_matrix = False
+    g = torch.nn.modules.module.register_module_forward_hook(lambda mod, inp, out: None)
+    layer(*args)
+    g.remove()
+    b = layer.attn_matrix.register_full_backward_hook(lambda mod, gi, go: None)
+    layer(*args)
+    b.remove()
+    layer(*args)
+    assert calls == [True, True, False]
     assert len(seen) == 1 and seen[0].shape == (2, 7, 7) and torch.allclose(seen[0].sum(-1), torch.ones(2, 7), atol=1e-5)
     assert torch.allclose(plain, hooked, atol=1e-5) and torch.equal(hooked, always)

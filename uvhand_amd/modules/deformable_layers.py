@@ -113,7 +113,7 @@ class DeformableTransformerDecoderLayer(nn.Module):
         # The head-averaged attention matrix exists for whoever hooks `attn_matrix`; with no hook registered nothing reads it,
         # and the attention core runs without ever writing a [N*heads, L, L] tensor (same values in eval; in training the
         # attention dropout then draws from that kernel's random stream, not nn.functional.dropout's).
-        listened = self.always_attention_matrix or bool(self.attn_matrix._forward_hooks or self.attn_matrix._forward_pre_hooks)
+        listened = self.always_attention_matrix or _has_listener(self.attn_matrix)
         if listened:
             tgt2, attn_matrix = self.self_attn(q.transpose(0, 1), k.transpose(0, 1), tgt.transpose(0, 1), need_weights=True)
             self.attn_matrix(attn_matrix)
@@ -125,6 +125,17 @@ class DeformableTransformerDecoderLayer(nn.Module):
                                level_start_index, src_padding_mask)
         tgt = add_layer_norm(tgt, self.dropout1(tgt2), self.norm1)
         return self.forward_ffn(tgt)
+
+
+def _has_listener(module):
+    """Does anything observe calls of this (parameter-free tap) module: its own forward / backward hooks, or hooks registered
+    for every module (torch.nn.modules.module.register_module_forward_hook and friends)?"""
+    from torch.nn.modules import module as _m
+    own = (module._forward_hooks, module._forward_pre_hooks, module._backward_hooks, getattr(module, "_backward_pre_hooks", None))
+    glob = (getattr(_m, "_global_forward_hooks", None), getattr(_m, "_global_forward_pre_hooks", None),
+            getattr(_m, "_global_backward_hooks", None), getattr(_m, "_global_backward_pre_hooks", None),
+            getattr(_m, "_global_forward_hooks_always_called", None))
+    return any(bool(h) for h in own + glob)
 
 
 def _get_clones(module, n):
