@@ -22,10 +22,9 @@ def _keep_mask(seed, pairs, Lq, Lk, p):
     key = np.arange(Lk, dtype=np.uint32)[None, None, :]
     pair = np.arange(pairs, dtype=np.uint32)[:, None, None]
     with np.errstate(over="ignore"):
-        x = (((q << np.uint32(16)) | key) ^ lo) + (pair * np.uint32(0x9E3779B1) + hi)
+        x = (q << np.uint32(16)) + key + (lo + pair * np.uint32(0x9E3779B1) + hi * np.uint32(0x85EBCA6B))
         x = x ^ (x >> np.uint32(16)); x = x * np.uint32(0x85EBCA6B)
         x = x ^ (x >> np.uint32(13)); x = x * np.uint32(0xC2B2AE35)
-        x = x ^ (x >> np.uint32(16))
     thresh = np.uint32(min(4294967295.0, float(np.float32(p)) * 4294967296.0))
     return x >= thresh
 

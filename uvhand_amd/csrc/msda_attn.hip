@@ -18,7 +18,7 @@
 //   * the head dimension is relabelled likewise (step (half, v): k index r = channel 16 half + 4r + v), so the operand whose
 //     row index is the lane's column reads four steps with one ds_read_b128 / one float4 global load.
 // Softmax statistics: the forward keeps log-sum-exp per (pair, query); the backward recomputes the probabilities from it.
-// Dropout: keep(seed, pair, query, key) is a 32-bit integer hash compared with p * 2^32 — recomputed in the backward, no mask
+// Dropout: keep(seed, pair, query, key) is a 32-bit integer hash (at_hash) compared with p * 2^32 — recomputed in the backward, no mask
 // tensor; the seed is READ FROM DEVICE MEMORY (the caller draws it with torch's generator: reproducible under manual_seed,
 // safe under HIP-graph capture).  This is the kernel's own random stream, not nn.functional.dropout's.
 #include <math.h>
@@ -36,14 +36,19 @@ using at_f4 = __attribute__((ext_vector_type(4))) float;
 
 struct AtView { float *p; long long sn, sl; };          // element (n, h, l, d) at p + n*sn + h*32 + l*sl + d
 
-// 32 bits per (pair, query, key): the counter, offset by the seed and the pair, through the two multiply-xorshift rounds of
-// the usual 32-bit finalizer (v_mul_lo_u32 is a quarter-rate instruction: the hash is most of the vector work per probability)
-__device__ __forceinline__ unsigned at_hash(unsigned seed_lo, unsigned seed_hi, unsigned pair, unsigned q, unsigned key)
+// 32 bits per (pair, query, key): the counter (query << 16) + key + mix — mix = seed and pair, uniform — through the two
+// multiply-xorshift rounds of the usual 32-bit finalizer; its last xor-shift is left out (it only folds high bits into low ones,
+// and the result is compared with a threshold).  v_mul_lo_u32 is a quarter-rate instruction and the vector unit is as busy as the
+// matrix pipe in these kernels: a lane adds its part of the counter once per tile, an element one constant.
+__device__ __forceinline__ unsigned at_mix(unsigned long long seed, unsigned pair)
 {
-    unsigned x = (((q << 16) | key) ^ seed_lo) + (pair * 0x9E3779B1u + seed_hi);      // (the second term is uniform: scalar unit)
+    return (unsigned)seed + pair * 0x9E3779B1u + (unsigned)(seed >> 32) * 0x85EBCA6Bu;
+}
+__device__ __forceinline__ unsigned at_hash(unsigned counter)
+{
+    unsigned x = counter;
     x ^= x >> 16; x *= 0x85EBCA6Bu;
     x ^= x >> 13; x *= 0xC2B2AE35u;
-    x ^= x >> 16;
     return x;
 }
 
@@ -127,7 +132,7 @@ struct AtArgs {
     float *lse;                         // [N*H][Lq]
     const unsigned long long *seed;     // device; null when thresh == 0
     int H, Lq, Lk, halves;
-    float scale, keep_scale;            // keep_scale = 1 / (1 - p)
+    float scale, scale2, keep_scale;    // scale2 = scale * log2(e): scores are kept in base 2; keep_scale = 1 / (1 - p)
     unsigned thresh;                    // keep iff hash >= thresh (p * 2^32; 0: no dropout)
 };
 
@@ -138,7 +143,7 @@ __global__ __launch_bounds__(kAtBlock) void attn32_fwd_kernel(const AtArgs a)
     float *Ks = at_smem, *Vs = at_smem + Lkp * kAtRow;
     const int pair = (int)blockIdx.x / a.halves, part = (int)blockIdx.x % a.halves, n = pair / a.H, h = pair % a.H;
     at_load_rows2(Ks, a.k.p + n * a.k.sn + h * 32, a.k.sl, Vs, a.v.p + n * a.v.sn + h * 32, a.v.sl, a.Lk, Lkp);
-    const unsigned seed_lo = a.thresh ? (unsigned)a.seed[0] : 0u, seed_hi = a.thresh ? (unsigned)(a.seed[0] >> 32) : 0u;
+    const unsigned mix = at_mix(a.thresh ? a.seed[0] : 0ull, (unsigned)pair);
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, r = lane >> 4;
     const int per = (ntq + a.halves - 1) / a.halves, t_end = min(ntq, (part + 1) * per);
@@ -149,9 +154,9 @@ __global__ __launch_bounds__(kAtBlock) void attn32_fwd_kernel(const AtArgs a)
         const bool qok = qi < a.Lq;
         float4 q0 = at_zero4(), q1 = at_zero4();
         if (qok) { q0 = at_ld4(qp + (long long)qi * a.q.sl + 4 * r); q1 = at_ld4(qp + (long long)qi * a.q.sl + 16 + 4 * r); }
-        q0.x *= a.scale; q0.y *= a.scale; q0.z *= a.scale; q0.w *= a.scale;
-        q1.x *= a.scale; q1.y *= a.scale; q1.z *= a.scale; q1.w *= a.scale;
-        // S^T tiles: s[t][v] = score of key 16 t + 4 r + v for query qi
+        q0.x *= a.scale2; q0.y *= a.scale2; q0.z *= a.scale2; q0.w *= a.scale2;
+        q1.x *= a.scale2; q1.y *= a.scale2; q1.z *= a.scale2; q1.w *= a.scale2;
+        // S^T tiles: s[t][v] = score (times log2 e) of key 16 t + 4 r + v for query qi
         at_f4 s[kAtMaxTiles];
         float m = -INFINITY;
         // (all the products first — independent chains, the matrix pipe runs them back to back — then the row maximum)
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(kAtBlock) void attn32_fwd_kernel(const AtArgs a)
             if (t < ntk) {
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
-                    s[t][v] = 16 * t + 4 * r + v < a.Lk ? s[t][v] : -INFINITY;
+                    if (t == ntk - 1) s[t][v] = 16 * t + 4 * r + v < a.Lk ? s[t][v] : -INFINITY;      // (only the last tile has padding keys)
                     m = fmaxf(m, s[t][v]);
                 }
             }
@@ -176,19 +181,20 @@ __global__ __launch_bounds__(kAtBlock) void attn32_fwd_kernel(const AtArgs a)
         for (int t = 0; t < kAtMaxTiles; ++t) {
             if (t < ntk) {
 #pragma unroll
-                for (int v = 0; v < 4; ++v) { s[t][v] = __expf(s[t][v] - m); sum += s[t][v]; }
+                for (int v = 0; v < 4; ++v) { s[t][v] = __builtin_amdgcn_exp2f(s[t][v] - m); sum += s[t][v]; }
             }
         }
         sum = at_rsum(sum);
-        if (qok && r == 0) a.lse[(long long)pair * a.Lq + qi] = m + __logf(sum);
+        if (qok && r == 0) a.lse[(long long)pair * a.Lq + qi] = (m + __builtin_amdgcn_logf(sum)) * 0.6931471805599453f;   // natural log
         const float inv = a.keep_scale / sum;
         at_f4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+        const unsigned ctr = ((unsigned)qi << 16) + 4 * r + mix;
 #pragma unroll
         for (int t = 0; t < kAtMaxTiles; ++t) {
             if (t < ntk) {
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
-                    const bool keep = at_hash(seed_lo, seed_hi, pair, qi, 16 * t + 4 * r + v) >= a.thresh;      // (thresh 0: always)
+                    const bool keep = at_hash(ctr + (16 * t + v)) >= a.thresh;      // (thresh 0: always)
                     s[t][v] = keep ? s[t][v] * inv : 0.f;
                 }
                 at_accum_t(Vs + 16 * t * kAtRow, r, c, s[t], o0, o1);       // O^T[channel][query] += V^T . P
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(kAtBlock) void attn32_bwd_kv_kernel(const AtArgs a)
     float *Qs = at_smem, *Gs = at_smem + Lqp * kAtRow, *lse_s = Gs + Lqp * kAtRow, *del_s = lse_s + Lqp;
     const int pair = (int)blockIdx.x / a.halves, part = (int)blockIdx.x % a.halves, n = pair / a.H, h = pair % a.H;
     at_load_rows2(Qs, a.q.p + n * a.q.sn + h * 32, a.q.sl, Gs, a.go.p + n * a.go.sn + h * 32, a.go.sl, a.Lq, Lqp);
-    const unsigned seed_lo = a.thresh ? (unsigned)a.seed[0] : 0u, seed_hi = a.thresh ? (unsigned)(a.seed[0] >> 32) : 0u;
+    const unsigned mix = at_mix(a.thresh ? a.seed[0] : 0ull, (unsigned)pair);
     __syncthreads();
     // per query: log-sum-exp (+inf for the padding rows: their probabilities vanish) and delta = <dO, O>
     for (int qi = threadIdx.x; qi < Lqp; qi += kAtBlock) {
@@ -224,7 +230,7 @@ __global__ __launch_bounds__(kAtBlock) void attn32_bwd_kv_kernel(const AtArgs a)
             }
         }
         del_s[qi] = d;
-        lse_s[qi] = qi < a.Lq ? a.lse[(long long)pair * a.Lq + qi] : INFINITY;
+        lse_s[qi] = qi < a.Lq ? a.lse[(long long)pair * a.Lq + qi] * 1.4426950408889634f : INFINITY;      // base 2, like the scores
     }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, r = lane >> 4;
@@ -238,8 +244,9 @@ __global__ __launch_bounds__(kAtBlock) void attn32_bwd_kv_kernel(const AtArgs a)
             const float *vr = a.v.p + n * a.v.sn + h * 32 + (long long)key * a.v.sl + 4 * r;
             k0 = at_ld4(kr); k1 = at_ld4(kr + 16); v0 = at_ld4(vr); v1 = at_ld4(vr + 16);
         }
-        k0.x *= a.scale; k0.y *= a.scale; k0.z *= a.scale; k0.w *= a.scale;
-        k1.x *= a.scale; k1.y *= a.scale; k1.z *= a.scale; k1.w *= a.scale;
+        k0.x *= a.scale2; k0.y *= a.scale2; k0.z *= a.scale2; k0.w *= a.scale2;
+        k1.x *= a.scale2; k1.y *= a.scale2; k1.z *= a.scale2; k1.w *= a.scale2;
+        const unsigned ctr = (unsigned)key + ((unsigned)(4 * r) << 16) + mix;
         at_f4 dv0 = {0.f, 0.f, 0.f, 0.f}, dv1 = dv0, dk0 = dv0, dk1 = dv0;
         // S and dP tiles: entry v = (query 16 t + 4 r + v, key).  The next tile's two products are issued before this tile's
         // exponentials and hashes: the matrix pipe works through them while the vector unit is busy.
@@ -255,8 +262,8 @@ __global__ __launch_bounds__(kAtBlock) void attn32_bwd_kv_kernel(const AtArgs a)
             at_f4 pd, ds;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const float p = __expf(s[v] - lsv[v]);
-                const bool keep = at_hash(seed_lo, seed_hi, pair, 16 * t + 4 * r + v, key) >= a.thresh;
+                const float p = __builtin_amdgcn_exp2f(s[v] - lsv[v]);
+                const bool keep = at_hash(ctr + ((unsigned)(16 * t + v) << 16)) >= a.thresh;
                 pd[v] = keep ? p * a.keep_scale : 0.f;
                 ds[v] = p * ((keep ? dp[v] * a.keep_scale : 0.f) - dlv[v]);
             }
@@ -283,7 +290,7 @@ __global__ __launch_bounds__(kAtBlock) void attn32_bwd_q_kernel(const AtArgs a)
     float *Ks = at_smem, *Vs = at_smem + Lkp * kAtRow;
     const int pair = (int)blockIdx.x / a.halves, part = (int)blockIdx.x % a.halves, n = pair / a.H, h = pair % a.H;
     at_load_rows2(Ks, a.k.p + n * a.k.sn + h * 32, a.k.sl, Vs, a.v.p + n * a.v.sn + h * 32, a.v.sl, a.Lk, Lkp);
-    const unsigned seed_lo = a.thresh ? (unsigned)a.seed[0] : 0u, seed_hi = a.thresh ? (unsigned)(a.seed[0] >> 32) : 0u;
+    const unsigned mix = at_mix(a.thresh ? a.seed[0] : 0ull, (unsigned)pair);
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, r = lane >> 4;
     const int per = (ntq + a.halves - 1) / a.halves, t_end = min(ntq, (part + 1) * per);
@@ -297,10 +304,11 @@ __global__ __launch_bounds__(kAtBlock) void attn32_bwd_q_kernel(const AtArgs a)
             const float *gr = a.go.p + n * a.go.sn + h * 32 + (long long)qi * a.go.sl + 4 * r;
             const float *orw = a.o.p + n * a.o.sn + h * 32 + (long long)qi * a.o.sl + 4 * r;
             q0 = at_ld4(qr); q1 = at_ld4(qr + 16); g0 = at_ld4(gr); g1 = at_ld4(gr + 16); o0 = at_ld4(orw); o1 = at_ld4(orw + 16);
-            lse = a.lse[(long long)pair * a.Lq + qi];
+            lse = a.lse[(long long)pair * a.Lq + qi] * 1.4426950408889634f;
         }
-        q0.x *= a.scale; q0.y *= a.scale; q0.z *= a.scale; q0.w *= a.scale;
-        q1.x *= a.scale; q1.y *= a.scale; q1.z *= a.scale; q1.w *= a.scale;
+        q0.x *= a.scale2; q0.y *= a.scale2; q0.z *= a.scale2; q0.w *= a.scale2;
+        q1.x *= a.scale2; q1.y *= a.scale2; q1.z *= a.scale2; q1.w *= a.scale2;
+        const unsigned ctr = ((unsigned)qi << 16) + 4 * r + mix;
         const float delta = at_rsum(g0.x * o0.x + g0.y * o0.y + g0.z * o0.z + g0.w * o0.w + g1.x * o1.x + g1.y * o1.y + g1.z * o1.z +
                                     g1.w * o1.w);
         at_f4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = dq0;
@@ -315,9 +323,9 @@ __global__ __launch_bounds__(kAtBlock) void attn32_bwd_q_kernel(const AtArgs a)
             at_f4 ds;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const int key = 16 * t + 4 * r + v;
-                const float p = key < a.Lk ? __expf(s[v] - lse) : 0.f;
-                const bool keep = at_hash(seed_lo, seed_hi, pair, qi, key) >= a.thresh;
+                float p = __builtin_amdgcn_exp2f(s[v] - lse);
+                if (t == ntk - 1) p = 16 * t + 4 * r + v < a.Lk ? p : 0.f;      // (uniform: only the last tile has padding keys)
+                const bool keep = at_hash(ctr + (16 * t + v)) >= a.thresh;
                 ds[v] = p * ((keep ? dp[v] * a.keep_scale : 0.f) - delta);
             }
             at_accum_t(Ks + 16 * t * kAtRow, r, c, ds, dq0, dq1);           // dQ^T[channel][query] += K^T . dS^T
@@ -360,6 +368,7 @@ static int at_fill(AtArgs &a, const char *who, int N, int H, int Lq, int Lk, flo
     if (N <= 0 || H <= 0 || !msda_attn32_supported(Lq, Lk, 32)) return msda::set_error(MSDA_ERR_ARGUMENT, who);
     if (!(dropout_p >= 0.f && dropout_p < 1.f) || (dropout_p > 0.f && seed == nullptr)) return msda::set_error(MSDA_ERR_ARGUMENT, who);
     a.H = H; a.Lq = Lq; a.Lk = Lk; a.halves = msda::tuning_int("MSDA_ATTN_HALVES", 1) == 2 ? 2 : 1; a.scale = scale;
+    a.scale2 = scale * 1.4426950408889634f;
     a.keep_scale = 1.f / (1.f - dropout_p);
     a.thresh = dropout_p > 0.f ? (unsigned)fmin(4294967295.0, (double)dropout_p * 4294967296.0) : 0u;
     a.seed = seed;
