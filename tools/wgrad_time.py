@@ -11,7 +11,7 @@ if any(k.startswith("MSDA_") for k in os.environ):
     _native.LIB_PATH = os.path.join(ROOT, "uvhand_amd", "libmsda_hip_tuning.so")
 dev = torch.device("cuda", 0)
 st = torch.cuda.Stream(dev)
-shapes = [(9600, 256, 256), (9600, 1024, 256), (33440, 256, 256), (33440, 384, 256), (33440, 1024, 256), (33440, 256, 1024)]
+shapes = [(6120, 256, 256), (9600, 256, 256), (9600, 1024, 256), (33440, 256, 256), (33440, 384, 256), (33440, 1024, 256), (33440, 256, 1024)]
 
 
 def gpu_us(fn):
